@@ -1,0 +1,54 @@
+"""CPU oracle: a NumPy float64 restatement of befelix/safe_learning's Lyapunov sweep.
+
+THIS PACKAGE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it.  ``safe_learning_amd`` (the product) never imports
+it and has no CPU fallback: without the HIP extension the product raises.
+
+What it restates (reference file:line, relative to the upstream checkout):
+
+* ``oracle.np_utilities``  - ``safe_learning/utilities.py:224-249`` (batchify),
+  ``:327-357`` (dlqr).
+* ``oracle.np_grid``    - ``safe_learning/functions.py:579-817`` (GridWorld).
+* ``oracle.np_functions``  - ``safe_learning/functions.py:254-354`` (FunctionStack,
+  Saturation), ``:357-546`` (GPRCached / GaussianProcess), ``:981-1370``
+  (_Triangulation), ``:1513-1583`` (QuadraticFunction, LinearSystem) and
+  ``examples/utilities.py:48-104, 144-437`` (LyapunovNetwork, InvertedPendulum,
+  CartPole).
+* ``oracle.np_lyapunov`` - ``safe_learning/lyapunov.py:22-56, 142-606``.
+* ``oracle.np_rl`` - ``safe_learning/reinforcement_learning.py:26-140,
+  213-279``.
+
+Third-party arithmetic that is not in the upstream checkout: the RBF kernel and
+``GPR.build_predict`` of gpflow==0.4.0 (pinned in the reference's
+``requirements.txt:3``).  The published algorithm is restated in
+``oracle.np_functions.RBF`` and pinned by the reference's own known-answer test
+``safe_learning/tests/test_functions.py:237-261``.
+
+Pinning: the reference cannot be imported in the build container (no tensorflow /
+gpflow).  The oracle is therefore pinned by the literal known-answer values of the
+reference's own tests, transcribed in ``tests/golden/reference_known_answers.json``
+and checked by ``tests/test_oracle_golden.py``.  Two things are pinned only by
+reading the code and are flagged "parity unpinned" in DESIGN.md: the order of
+equal-valued cells in ``update_safe_set`` (the reference uses NumPy's unstable
+default argsort; the oracle fixes ascending (value, flat index)), and the 4-D
+unit-cell triangulation (Qhull output frozen in ``tests/golden``).
+
+Canonical arithmetic: small linear-algebra forms (policy, linear dynamics,
+quadratic V, thresholds) are evaluated left-to-right, one IEEE-754 rounding per
+multiply and per add (no FMA, no BLAS), see ``oracle.np_functions.ordered_matmul``.
+TensorFlow/Eigen's summation order in the reference is not specified, so this is
+a definition, and it is what the HIP kernels reproduce bit-for-bit
+(compiled with ``-ffp-contract=off``).
+"""
+
+from .np_utilities import batchify, dlqr
+from .np_grid import GridWorld, DimensionError
+from .np_functions import (ordered_matmul, QuadraticFunction, LinearSystem, Saturation,
+                        RBF, GPRCached, GaussianProcess, FunctionStack, Triangulation,
+                        InvertedPendulum, CartPole, LyapunovNetwork, AbsFunction,
+                        Norm1Function, NegatedFunction, ConstantPolicy,
+                        TriangulationGradient)
+from .np_lyapunov import Lyapunov, smallest_boundary_value, config
+from .np_rl import PolicyIteration

@@ -1,0 +1,162 @@
+"""Oracle (test infrastructure): Lyapunov safe-set computation, NumPy float64.
+
+Restates ``safe_learning/lyapunov.py:142-606`` (class ``Lyapunov``) and ``:22-56``
+(``smallest_boundary_value``).  The TensorFlow graph is replaced by direct calls of NumPy
+callables; the batch loop, the prefix rule, the early exit and the ``c_max`` index
+arithmetic of ``update_safe_set`` are kept as they are in the reference, quirks included.
+
+Tie order: the reference sorts with NumPy's default (unstable) argsort
+(``lyapunov.py:512``); the oracle defines the canonical order as ascending
+``(value, flat index)`` - "parity unpinned" for cells with exactly equal values.
+"""
+
+import numpy as np
+
+from .np_utilities import batchify
+from .np_functions import ordered_rowsum
+
+
+class _Config(object):
+    """``safe_learning/configuration.py:8-32``: float64, 10 000-cell verification batches."""
+
+    def __init__(self):
+        self.np_dtype = np.float64
+        self.gp_batch_size = 10000
+
+
+config = _Config()
+
+
+def smallest_boundary_value(fun, discretization):
+    """Minimum of ``fun`` over the grid's boundary faces.  Reference: ``lyapunov.py:22-56``."""
+    min_value = np.inf
+    for i in range(discretization.ndim):
+        tmp = list(discretization.discrete_points)
+        tmp[i] = discretization.discrete_points[i][[0, -1]]
+        columns = [x.ravel() for x in np.meshgrid(*tmp, indexing='ij')]
+        all_points = np.column_stack(columns)
+        min_value = min(min_value, np.min(fun(all_points)))
+    return min_value
+
+
+class Lyapunov(object):
+    """Reference: ``lyapunov.py:142-225`` (constructor contract kept)."""
+
+    def __init__(self, discretization, lyapunov_function, dynamics, lipschitz_dynamics,
+                 lipschitz_lyapunov, tau, policy, initial_set=None, adaptive=False):
+        self.discretization = discretization
+        self.policy = policy
+        self.safe_set = np.zeros(np.prod(discretization.num_points), dtype=bool)
+        self.initial_safe_set = initial_set
+        if initial_set is not None:
+            self.safe_set[initial_set] = True
+        self.tau = tau
+        self.dynamics = dynamics
+        self.lyapunov_function = lyapunov_function
+        self.values = None
+        self.c_max = 0.
+        self._lipschitz_dynamics = lipschitz_dynamics
+        self._lipschitz_lyapunov = lipschitz_lyapunov
+        self.update_values()
+        self.adaptive = adaptive
+        self._refinement = np.zeros(discretization.nindex, dtype=int)
+        if initial_set is not None:
+            self._refinement[initial_set] = 1
+
+    def lipschitz_dynamics(self, states):
+        """Reference: ``lyapunov.py:227-244``."""
+        if hasattr(self._lipschitz_dynamics, '__call__'):
+            return self._lipschitz_dynamics(states)
+        return self._lipschitz_dynamics
+
+    def lipschitz_lyapunov(self, states):
+        """Reference: ``lyapunov.py:246-263``."""
+        if hasattr(self._lipschitz_lyapunov, '__call__'):
+            return self._lipschitz_lyapunov(states)
+        return self._lipschitz_lyapunov
+
+    def threshold(self, states, tau=None):
+        """``-||L_v||_1 (1 + L_f) tau``.  Reference: ``lyapunov.py:265-288``."""
+        if tau is None:
+            tau = self.tau
+        lv = self.lipschitz_lyapunov(states)
+        if hasattr(self._lipschitz_lyapunov, '__call__') and lv.shape[1] > 1:
+            lv = ordered_rowsum(np.abs(lv))
+        lf = self.lipschitz_dynamics(states)
+        return - lv * (1. + lf) * tau
+
+    def is_safe(self, state):
+        """Reference: ``lyapunov.py:290-303``."""
+        return self.safe_set[self.discretization.state_to_index(state)]
+
+    def update_values(self):
+        """Reference: ``lyapunov.py:305-322``."""
+        self.values = np.asarray(
+            self.lyapunov_function(self.discretization.all_points)).squeeze()
+
+    def v_decrease_confidence(self, states, next_states):
+        """Reference: ``lyapunov.py:324-354``."""
+        if isinstance(next_states, (tuple, list)):
+            next_states, error_bounds = next_states
+            lv = self.lipschitz_lyapunov(next_states)
+            bound = ordered_rowsum(np.atleast_2d(lv * error_bounds))
+        else:
+            bound = 0.
+        v_decrease = self.lyapunov_function(next_states) - self.lyapunov_function(states)
+        return v_decrease, bound
+
+    def v_decrease_bound(self, states, next_states):
+        """Reference: ``lyapunov.py:356-376``."""
+        v_dot, v_dot_error = self.v_decrease_confidence(states, next_states)
+        return v_dot + v_dot_error
+
+    def negative(self, states):
+        """The per-batch graph of ``lyapunov.py:436-441``: strict ``decrease < threshold``."""
+        actions = self.policy(states)
+        next_states = self.dynamics(states, actions)
+        decrease = self.v_decrease_bound(states, next_states)
+        threshold = self.threshold(states, self.tau)
+        return np.squeeze(np.less(decrease, threshold), axis=1)
+
+    def update_safe_set(self, can_shrink=True, max_refinement=1, safety_factor=1.,
+                        parallel_iterations=1):
+        """Non-adaptive branch of ``lyapunov.py:407-606``."""
+        if self.adaptive and max_refinement > 1:
+            raise NotImplementedError('adaptive refinement is outside the oracle (SURVEY 8f-2)')
+
+        if can_shrink:                                                    # :500-506
+            safe_sorted_src = np.zeros_like(self.safe_set, dtype=bool)
+            refinement_src = np.zeros_like(self._refinement, dtype=int)
+            if self.initial_safe_set is not None:
+                safe_sorted_src[self.initial_safe_set] = True
+                refinement_src[self.initial_safe_set] = 1
+        else:                                                             # :507-510
+            safe_sorted_src = self.safe_set
+            refinement_src = self._refinement
+
+        order = np.argsort(self.values, kind='stable')                    # :512 (canonical ties)
+        safe_sorted = safe_sorted_src[order]                              # :513 (copy)
+        refinement = refinement_src[order]
+
+        start = bound = 0
+        for start, (indices, safe_batch, refine_batch) in batchify(
+                (order, safe_sorted, refinement), config.gp_batch_size):  # :517-524
+            states = self.discretization.index_to_state(indices)
+            negative = self.negative(states)                              # :529
+            safe_batch |= negative                                        # :530
+            refine_batch[negative] = 1                                    # :531
+            bound = int(np.argmin(safe_batch))                            # :535 first False, 0 if none
+            if bound > 0 or not safe_batch[0]:                            # :539
+                safe_batch[bound:] = False                                # :585
+                refine_batch[bound:] = 0                                  # :586
+                break                                                     # :587
+
+        max_index = start + bound - 1                                     # :590 (refine_bound = 0)
+        self.c_max = self.values[order[max_index]]                        # :595
+
+        self.safe_set[:] = False                                          # :598-601
+        self.safe_set[order[safe_sorted]] = True
+        self._refinement[order] = refinement
+        if self.initial_safe_set is not None:                             # :604-606
+            self.safe_set[self.initial_safe_set] = True
+            self._refinement[self.initial_safe_set] = 1

@@ -1,0 +1,291 @@
+"""Pin the CPU oracle against the reference's own known-answer tests.
+
+Every expected value below comes from ``tests/golden/reference_known_answers.json``,
+a hand transcription of the literals in the reference's ``safe_learning/tests/*.py``.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg
+from numpy.testing import assert_allclose, assert_equal
+
+import oracle
+from oracle import (GridWorld, QuadraticFunction, LinearSystem, RBF, GPRCached,
+                    GaussianProcess, Triangulation, Lyapunov, PolicyIteration, dlqr,
+                    smallest_boundary_value)
+
+from conftest import GOLDEN_DIR
+
+
+def test_safe_set_init(golden):
+    g = golden["lyapunov_safe_set_init"]
+    grid = GridWorld(g["limits"], g["num_points"])
+    lyap_fun = lambda x: np.sum(np.square(x), axis=1)
+    dynamics = LinearSystem(np.array(g["dynamics_matrix"]))
+    policy = lambda x: 0. * x
+    lyap = Lyapunov(grid, lyap_fun, dynamics, g["lf"], g["lv"], g["tau"], policy)
+    assert not lyap.safe_set.any()
+    lyap = Lyapunov(grid, lyap_fun, dynamics, g["lf"], g["lv"], g["tau"], policy,
+                    initial_set=g["initial_set"])
+    assert_equal(lyap.safe_set, np.array(g["expected_safe_set"]))
+
+
+def test_update_safe_set_known_answers(golden):
+    g = golden["lyapunov_update_safe_set"]
+    grid = GridWorld(g["limits"], g["num_points"])
+    lyap_fun = lambda x: np.sum(np.square(x), axis=1, keepdims=True)
+    policy = lambda x: g["policy_gain"] * x
+    dynamics = LinearSystem(np.array(g["dynamics_matrix"]))
+    for case in g["cases"]:
+        lyap = Lyapunov(grid, lyap_fun, dynamics, g["lf"], g["lv"], case["tau"], policy,
+                        initial_set=g["initial_set"])
+        lyap.update_safe_set()
+        assert_equal(lyap.safe_set, np.array(case["expected_safe_set"]))
+
+
+def test_smallest_boundary_value(golden):
+    g = golden["smallest_boundary_value"]
+    fun = lambda x: 2 * np.sum(np.abs(x), axis=1)
+    grid = GridWorld(g["limits"], g["num_points"])
+    assert smallest_boundary_value(fun, grid) == g["expected"]
+
+
+def test_gp_known_answer(golden):
+    g = golden["gp_known_answer"]
+    X, Y = np.array(g["X"], dtype=float), np.array(g["Y"], dtype=float)
+    # the reference builds the GP with two points and adds the third (full cache rebuild)
+    gp = GPRCached(X[:2], Y[:2], RBF(2))
+    ufun = GaussianProcess(gp, beta=g["beta"])
+    ufun.add_data_point(X[2:], Y[2:])
+    assert_allclose(ufun.X, X)
+    assert_allclose(ufun.Y, Y)
+    test_points = np.array(g["test_points"], dtype=float)
+    mean, error = ufun(test_points)
+    assert_allclose(mean, g["expected_mean"], rtol=g["rtol"])
+    assert_allclose(error, g["expected_error"], rtol=g["rtol"])
+    # multiple inputs are concatenated (test_functions.py:229-235)
+    mean2, error2 = ufun(test_points[:, [0]], test_points[:, [1]])
+    assert_allclose(mean, mean2)
+    assert_allclose(error, error2)
+
+
+def test_gp_scale_invariance():
+    """GPRCached's internal ``scale`` must not change predictions (functions.py:392-456)."""
+    rng = np.random.default_rng(0)
+    X, Y = rng.uniform(-1, 1, (20, 3)), rng.normal(size=(20, 2))
+    kern = RBF(3, variance=0.3, lengthscales=[0.5, 0.7, 1.1], ARD=True)
+    xs = rng.uniform(-1, 1, (7, 3))
+    m1, v1 = GPRCached(X, Y, kern, likelihood_variance=0.01).build_predict(xs)
+    m2, v2 = GPRCached(X, Y, kern, scale=3.7, likelihood_variance=0.01).build_predict(xs)
+    assert_allclose(m1, m2, rtol=1e-10)
+    assert_allclose(v1, v2, rtol=1e-9)
+
+
+def test_quadratic(golden):
+    g = golden["quadratic"]
+    quad = QuadraticFunction(np.array(g["P"]))
+    assert_allclose(quad(np.array(g["points"], dtype=float)), g["expected"])
+
+
+def test_gridworld(golden):
+    g = golden["gridworld"]
+    grid = GridWorld(g["limits"], g["num_points"])
+    indices = np.arange(grid.nindex)
+    states = grid.index_to_state(indices)
+    assert_equal(indices, grid.state_to_index(states))
+    assert_allclose(states, grid.all_points, rtol=0, atol=0)        # linspace == ijk*unit+offset
+    grid.state_to_index([0, 2.3])
+    grid.index_to_state(1)
+    rectangles = np.arange(grid.nrectangles)
+    states = grid.rectangle_to_state(rectangles)
+    assert_equal(rectangles, grid.state_to_rectangle(states + grid.unit_maxes / 2))
+    assert_equal(grid.state_to_rectangle(100 * np.ones((1, 2))), grid.nrectangles - 1)
+    assert_equal(grid.state_to_rectangle(-100 * np.ones((1, 2))), 0)
+    corners = grid.rectangle_corner_index(rectangles)
+    assert_equal(corners, grid.state_to_index(grid.rectangle_to_state(rectangles)))
+    assert_equal(grid.state_to_index(np.array(g["outside_point"])), g["outside_index"])
+    with pytest.raises(oracle.DimensionError):
+        grid._check_dimensions(np.array([[1, 2, 3]]))
+    with pytest.raises(oracle.DimensionError):
+        GridWorld([[0, 1]], 1)
+    gi = g["integer_numpoints"]
+    assert_equal(GridWorld(gi["limits"], gi["num_points"]).num_points, gi["expected"])
+    g1 = g["one_d"]
+    grid = GridWorld(g1["limits"], g1["num_points"])
+    test = np.array(g1["test"])
+    assert_allclose(grid.state_to_index(test), g1["index"])
+    assert_allclose(grid.state_to_rectangle(test), g1["rectangle"])
+    assert_allclose(grid.rectangle_to_state(np.array(g1["rectangle"])), g1["rectangle_states"])
+
+
+def test_triangulation_find_simplex(golden):
+    g = golden["triangulation_find_simplex"]
+    grid = GridWorld(g["limits"], g["num_points"])
+    tri = Triangulation(grid)
+    assert grid.nrectangles == g["nrectangles"]
+    assert tri.nsimplex == g["nsimplex"]
+    assert_equal(grid.offset, g["offset"])
+    assert_allclose(grid.unit_maxes, g["unit_maxes"])
+    lower = int(np.squeeze(tri.triangulation.find_simplex(np.array([0, 0]))))
+    upper = 1 - lower
+    pts = np.array(g["test_points_minus_lower_limits"], dtype=float) + np.array(g["limits"])[:, 0]
+    rect = np.array(g["expected_rectangles"])
+    expected = rect * 2 + np.array([lower, upper, lower, upper])
+    result = tri.find_simplex(pts)
+    assert_allclose(result, expected)
+    assert_equal(np.sort(tri.simplices(result), axis=1), g["expected_sorted_simplices"])
+    assert_equal(lower, tri.find_simplex(np.array([[-100., -100.]])))
+    assert_equal(tri.nsimplex - 1 - lower, tri.find_simplex(np.array([[100., 100.]])))
+
+
+def _resolve(points, eps):
+    table = {"1-eps": 1 - eps, "0.5-eps": 0.5 - eps}
+    return np.array([[table.get(v, v) if isinstance(v, str) else v for v in row]
+                     for row in points], dtype=float)
+
+
+def test_triangulation_values(golden):
+    g = golden["triangulation_values"]
+    grid = GridWorld(g["limits"], g["num_points"])
+    tri = Triangulation(grid)
+    pts = _resolve(g["test_points"], g["eps"])
+    nodes = grid.state_to_index(np.array(g["node_states"], dtype=float))
+    true_H = np.zeros((len(pts), grid.nindex))
+    for row, w in enumerate(g["weights_on_nodes"]):
+        true_H[row, nodes] = w
+    weights, simplices = tri._get_weights(pts)
+    H = np.zeros_like(true_H)
+    for row in range(len(pts)):
+        np.add.at(H[row], simplices[row], weights[row])
+    assert_allclose(H, true_H, atol=g["atol"])
+    values = np.random.default_rng(0).random(grid.nindex)
+    tri.parameters = values
+    assert_allclose(H.dot(values)[:, None], tri(pts))
+    p = g["projection"]
+    tri.parameters = np.array(p["parameters"], dtype=float)
+    assert_allclose(tri(np.array(p["point"])), p["unprojected"])
+    tri.project = True
+    assert_allclose(tri(np.array(p["point"])), p["projected"])
+
+
+def test_triangulation_3d(golden):
+    g = golden["triangulation_3d"]
+    grid = GridWorld(g["limits"], g["num_points"])
+    tri = Triangulation(grid)
+    assert tri.nsimplex == g["nsimplex"]
+    tri.parameters = np.sum(grid.index_to_state(np.arange(8)), axis=1) / 3
+    result = tri(np.array(g["test_points"], dtype=float))
+    assert_allclose(result, np.array(g["expected"])[:, None], atol=g["atol"])
+
+
+def test_triangulation_gradient(golden):
+    g = golden["triangulation_gradient"]
+    grid = GridWorld(g["limits"], g["num_points"])
+    tri = Triangulation(grid)
+    nodes = grid.state_to_index(np.array(g["node_states"], dtype=float))
+    values = np.zeros(grid.nindex)
+    values[nodes] = g["node_values"]
+    tri.parameters = values
+    assert_allclose(tri.gradient(np.array(g["test_points"])), g["expected_gradient"])
+
+
+def test_triangulation_1d(golden):
+    g = golden["triangulation_1d"]
+    grid = GridWorld(g["limits"], g["num_points"])
+    tri = Triangulation(grid, vertex_values=g["vertex_values"])
+    pts = np.array(g["test_points"], dtype=float)
+    assert_allclose(tri.find_simplex(pts), g["expected_simplices"])
+    assert_allclose(tri.find_simplex(pts[[0], :]), g["expected_simplices"][:1])
+    assert_allclose(tri(pts), g["expected_values"], atol=1e-15)
+    assert_allclose(tri.gradient(pts), g["expected_gradient"])
+
+
+def test_unit_cell_triangulation_frozen():
+    """The Qhull unit-cell tables (incl. the 22-simplex 4-D one) match the frozen fixture."""
+    with open(os.path.join(GOLDEN_DIR, "unit_cell_triangulations.json")) as f:
+        cells = json.load(f)["cells"]
+    for cell in cells:
+        um = np.array(cell["unit_maxes"])
+        d = len(um)
+        grid = GridWorld(np.stack([np.zeros(d), um * 2], axis=1), 3)
+        tri = Triangulation(grid)
+        assert tri.triangulation.nsimplex == cell["nsimplex"]
+        strides = np.array([3 ** (d - 1 - k) for k in range(d)])
+        expected = sorted(sorted(int(np.dot(code, strides)) for code in simplex)
+                          for simplex in cell["simplex_vertex_codes"])
+        got = sorted(sorted(int(v) for v in simplex) for simplex in tri.unit_simplices)
+        assert got == expected
+
+
+def test_future_values_mock(golden):
+    g = golden["future_values_mock"]
+
+    class VF(object):
+        class discretization(object):
+            all_points = np.arange(4, dtype=float)[:, None]
+
+        def __call__(self, x):
+            return np.array(g["values_at_next"])
+
+    calls = {}
+
+    def dynamics(s, a):
+        calls["dyn"] = (s, a)
+        return "next_states"
+
+    def rewards(s, a):
+        calls["rew"] = (s, a)
+        return np.array(g["rewards"])
+
+    rl = PolicyIteration(lambda s: "actions", dynamics, rewards, VF(), gamma=g["gamma"])
+    fv = rl.future_values("states")
+    assert calls["dyn"] == ("states", "actions") and calls["rew"] == ("states", "actions")
+    assert_allclose(fv, np.arange(4, dtype=float)[:, None] * (1 + rl.gamma))
+
+
+def test_dlqr(golden):
+    g = golden["dlqr"]
+    k, p = dlqr(g["a"], g["b"], g["q"], g["r"])
+    assert_allclose(k, g["k"], rtol=g["rtol"])
+    assert_allclose(p, g["p"], rtol=g["rtol"])
+
+
+def test_policy_iteration_integration(golden):
+    """test_rl.py:29-77 - value iteration + gradient ascent on the policy vertices -> DLQR."""
+    g = golden["policy_iteration_integration"]
+    a, b, q, r = (np.array(g[k], dtype=float) for k in "abqr")
+    k, p = dlqr(a, b, q, r)
+    true_value = QuadraticFunction(-p)
+    vgrid = GridWorld(g["value_grid"]["limits"], g["value_grid"]["num_points"])
+    value_function = Triangulation(vgrid, 0. * vgrid.all_points, project=True)
+    dynamics = LinearSystem((a, b))
+    pgrid = GridWorld(g["policy_grid"]["limits"], g["policy_grid"]["num_points"])
+    policy = Triangulation(pgrid, -k / 2 * pgrid.all_points)
+    reward = QuadraticFunction(-scipy.linalg.block_diag(q, r))
+    rl = PolicyIteration(policy, dynamics, reward, value_function)
+
+    def loss_gradient():
+        """d/d(policy vertices) of -sum(future_values): chain rule through the 1-D
+        interpolants (the reference lets TensorFlow differentiate the same graph)."""
+        x = rl.state_space
+        wu, su = policy._get_weights(x)
+        u = np.sum(wu * policy.parameters[su][:, :, 0], axis=1, keepdims=True)
+        nxt = dynamics(x, u)
+        dv_dnext = value_function.gradient(nxt).reshape(-1, 1)
+        dr_du = 2 * (-r[0, 0]) * u
+        dfv_du = dr_du + rl.gamma * dv_dnext * b[0, 0]
+        grad = np.zeros(pgrid.nindex)
+        for row in range(len(x)):
+            np.add.at(grad, su[row], -dfv_du[row, 0] * wu[row])
+        return grad[:, None]
+
+    for _ in range(g["outer_iterations"]):
+        rl.value_iteration()
+        for _ in range(g["gd_steps"]):
+            policy.parameters = policy.parameters - g["learning_rate"] * loss_gradient()
+
+    assert_allclose(value_function.parameters, true_value(rl.state_space), atol=g["atol"])
+    assert_allclose(policy.parameters, -k * pgrid.all_points, atol=g["atol"])
