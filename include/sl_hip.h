@@ -1,0 +1,234 @@
+/*
+ * sl_hip.h - C ABI of libslhip.so, the MI355X (gfx950) engine under safe_learning_amd.
+ *
+ * The reference (befelix/safe_learning) has no FFI: its hot path is a Python loop that
+ * feeds 10 000-cell batches to a TensorFlow graph (safe_learning/lyapunov.py:517-587,
+ * safe_learning/reinforcement_learning.py:65-140, 213-279).  This header is the boundary a
+ * maintainer would bind (ctypes stub in INTEGRATION.md) to replace exactly those loops; each
+ * entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.  Every function returns 0 (SL_OK) or a
+ *    negative error code, never throws, never aborts; sl_last_error() gives the message.
+ *  - "h_" pointers are host memory, copied before the call returns.  "d_" pointers are
+ *    device memory owned by the caller (e.g. a torch tensor's data_ptr()) on the context's
+ *    device and must stay valid until the context's stream has executed the call.
+ *  - All launches go to the stream given at sl_ctx_create (a hipStream_t; NULL = the
+ *    default stream) and are asynchronous unless stated otherwise.
+ *  - All arithmetic is float64 (safe_learning/configuration.py:16); masks are bit masks,
+ *    bit (i % 64) of word (i / 64), cell indices are flat C-order GridWorld indices
+ *    (safe_learning/functions.py:622-638, 714-731).
+ *  - A context is not re-entrant; use one context per GPU / per host thread.
+ */
+#ifndef SL_HIP_H
+#define SL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SL_OK               0
+#define SL_ERR_INVALID     (-1)   /* bad argument / model not set            */
+#define SL_ERR_HIP         (-2)   /* a HIP runtime call failed               */
+#define SL_ERR_UNSUPPORTED (-3)   /* combination not implemented             */
+#define SL_ERR_NOMEM       (-4)
+
+#define SL_MAX_STATE_DIM   6
+#define SL_MAX_ACTION_DIM  2
+#define SL_MAX_INPUT_DIM   8      /* state + action                          */
+#define SL_MAX_GP_HEADS    6
+#define SL_MAX_NN_LAYERS   4
+#define SL_MAX_SIMPLICES   32     /* unit-cell simplices (Qhull gives 22 in 4-D) */
+
+typedef struct sl_ctx sl_ctx;
+
+/* ---- function kinds -------------------------------------------------------------- */
+enum sl_policy_kind {
+    SL_POLICY_LINEAR = 1,   /* u = x K^T            (LinearSystem, functions.py:1567-1583)  */
+    SL_POLICY_CONST  = 2,   /* u = constant row     (reinforcement_learning.py:233-235,268) */
+    SL_POLICY_TABLE  = 3,   /* u = table[i]         (per-vertex policy on the same grid)    */
+    SL_POLICY_TRI    = 4    /* u = Triangulation(x) on the auxiliary grid #1                */
+};
+enum sl_dynamics_kind {
+    SL_DYN_LINEAR   = 1,    /* [x,u] M^T            (functions.py:1567-1583)                */
+    SL_DYN_PENDULUM = 2,    /* examples/utilities.py:242-289, 10 Euler sub-steps            */
+    SL_DYN_CARTPOLE = 3,    /* examples/utilities.py:387-437, 10 Euler sub-steps            */
+    SL_DYN_GP       = 4     /* GP posterior (functions.py:417-458, 507-515, 278-291)        */
+};
+enum sl_value_kind {
+    SL_V_QUADRATIC  = 1,    /* x P x^T              (functions.py:1534-1539)                */
+    SL_V_TRI        = 2,    /* Triangulation on the auxiliary grid #0 (functions.py:1473-1499) */
+    SL_V_NETWORK    = 3     /* LyapunovNetwork      (examples/utilities.py:85-104)          */
+};
+enum sl_lipschitz_kind {
+    SL_LIP_CONST       = 0, /* scalar                                  (lyapunov.py:241-263) */
+    SL_LIP_ABS_LINEAR  = 1, /* |x G^T| per column  (adaptive_safety_verification.ipynb c.17) */
+    SL_LIP_NORM_LINEAR = 2, /* ||x G^T||_1, one column                                       */
+    SL_LIP_ABS_GRAD    = 3  /* |grad V(x)| of the value function (NN or triangulation)       */
+};
+
+/* ---- plain-old-data model description (copied by sl_model_set) ---------------------- */
+typedef struct sl_grid_desc {            /* GridWorld: functions.py:591-620 */
+    int32_t d;                           /* state dimension                 */
+    int32_t reserved;
+    int64_t num_points[SL_MAX_STATE_DIM];
+    double  offset[SL_MAX_STATE_DIM];    /* limits[:,0]                     */
+    double  unit_maxes[SL_MAX_STATE_DIM];
+    double  upper[SL_MAX_STATE_DIM];     /* limits[:,1]                     */
+} sl_grid_desc;
+
+typedef struct sl_policy_desc {
+    int32_t kind, m, saturate, reserved;             /* Saturation: functions.py:349-354 */
+    double  matrix[SL_MAX_ACTION_DIM][SL_MAX_STATE_DIM];   /* rows = outputs            */
+    double  lower[SL_MAX_ACTION_DIM], upper[SL_MAX_ACTION_DIM];
+    double  constant[SL_MAX_ACTION_DIM];
+    const double* d_table;                           /* [nindex][m] when kind == TABLE   */
+} sl_policy_desc;
+
+typedef struct sl_dynamics_desc {
+    int32_t kind, normalize;
+    double  matrix[SL_MAX_STATE_DIM][SL_MAX_INPUT_DIM];    /* LINEAR: rows = outputs; GP: prior mean */
+    double  tx[SL_MAX_STATE_DIM], tx_inv[SL_MAX_STATE_DIM];
+    double  tu[SL_MAX_ACTION_DIM];
+    double  coef[16];                    /* analytic coefficients, see sl_model.h */
+} sl_dynamics_desc;
+
+typedef struct sl_value_desc {
+    int32_t kind, negate;                /* negate: V = -f (functions.py:120-122)           */
+    double  matrix[SL_MAX_INPUT_DIM][SL_MAX_INPUT_DIM];    /* QUADRATIC                     */
+} sl_value_desc;
+
+typedef struct sl_lipschitz_desc {
+    int32_t lv_kind, lv_cols;            /* columns of L_v(x): 1 or d                       */
+    double  lv_const;
+    double  lv_matrix[SL_MAX_STATE_DIM][SL_MAX_STATE_DIM]; /* rows = outputs                */
+    double  lf_const;                    /* L_f (closed loop), scalar                       */
+    double  tau;
+} sl_lipschitz_desc;
+
+typedef struct sl_model_desc {
+    sl_grid_desc      grid;
+    sl_policy_desc    policy;
+    sl_dynamics_desc  dynamics;
+    sl_value_desc     value;             /* Lyapunov function V / value function            */
+    sl_lipschitz_desc lipschitz;
+    sl_value_desc     reward;            /* QUADRATIC on [x,u] (PolicyIteration only)       */
+    double            gamma;             /* discount (reinforcement_learning.py:47)          */
+} sl_model_desc;
+
+/* (V, flat index) ordering key: ascending V, ties by ascending index (oracle/np_lyapunov.py). */
+typedef struct sl_key { uint64_t vbits; int64_t index; } sl_key;
+
+/* Result block of the Lyapunov passes (device memory, 8 x 8 bytes). */
+typedef struct sl_sweep_result {
+    sl_key   fail;          /* lexmin{(V_i,i): not (negative_i or init_i)}; vbits=~0 if none */
+    sl_key   last_safe;     /* lexmax{(V_i,i) < key_star}; index=-1 if none                  */
+    sl_key   max_key;       /* lexmax over all cells of the range                            */
+    int64_t  count_below;   /* #cells with key < key_star                                    */
+    int64_t  count_safe;    /* #bits set in the written safe mask                            */
+} sl_sweep_result;
+
+/* ---- context ------------------------------------------------------------------------- */
+int  sl_version(void);
+int  sl_ctx_create(int device, void* hip_stream, sl_ctx** out);
+int  sl_ctx_destroy(sl_ctx* ctx);
+const char* sl_last_error(const sl_ctx* ctx);      /* ctx may be NULL: last global error */
+int  sl_ctx_synchronize(sl_ctx* ctx);
+
+/* ---- model upload (copies; replaces the TF graph build of lyapunov.py:431-443) --------- */
+int  sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model);
+
+/* GP head `head` of the dynamics (FunctionStack: one head per output column,
+ * functions.py:278-291; a shared-kernel multi-output GPRCached is one head with dout = D).
+ *   h_X      [n][p]   training inputs                     (GPRCached.X,      functions.py:382)
+ *   h_Linv   [n][n]   inverse of the Cholesky factor of K + sigma_n^2 I, lower triangular,
+ *                     so that a = Linv k_x equals tf.matrix_triangular_solve (functions.py:441)
+ *   h_alpha  [n][dout] L^-1 (Y - m(X))                    (GPRCached.alpha,  functions.py:405-409)
+ * RBF (gpflow 0.4.0): k = variance * exp(-0.5 sum_q ((x_q - x'_q) / lengthscales_q)^2). */
+int  sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
+                    const double* h_X, const double* h_Linv, const double* h_alpha,
+                    double variance, const double* h_lengthscales);
+int  sl_gp_configure(sl_ctx* ctx, int nheads, double beta);
+
+/* Auxiliary grid #slot with a per-vertex table (Triangulation: functions.py:1002-1032,
+ * 1064-1101): slot 0 = value function, slot 1 = policy.  h_simplices [nsimplex][d+1] are the
+ * unit-cell vertices as {0,1}^d corner codes (bit k = dimension k), h_hyperplanes
+ * [nsimplex][d][d] = inv(vertices[1:] - vertices[0]); d_table [nindex][ncols] stays caller-owned. */
+int  sl_tri_set(sl_ctx* ctx, int slot, const sl_grid_desc* h_grid, int nsimplex,
+                const int32_t* h_simplices, const double* h_hyperplanes,
+                const double* h_discrete_points, int project, int ncols, const double* d_table);
+int  sl_tri_set_table(sl_ctx* ctx, int slot, const double* d_table);
+
+/* LyapunovNetwork (examples/utilities.py:85-104): h_kernels = per-layer kernel matrices
+ * [out_i][in_i] concatenated; activation codes 0 = linear, 1 = tanh, 2 = relu. */
+int  sl_network_set(sl_ctx* ctx, int nlayers, const int32_t* h_dims /* nlayers+1 */,
+                    const int32_t* h_activations, const double* h_kernels);
+
+/* ---- Lyapunov passes ------------------------------------------------------------------- */
+/* values[i-lo] = V(x_i), i in [lo,hi).  Replaces Lyapunov.update_values (lyapunov.py:305-322). */
+int  sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values);
+
+/* Decrease check of every cell i in [lo,hi) (lo % 64 == 0): policy -> dynamics ->
+ * V(f(x)) - V(x) + L_v.err < -|L_v|_1 (1 + L_f) tau  (lyapunov.py:436-441, 265-288, 324-376).
+ * Replaces the batch loop lyapunov.py:524-587.
+ *   d_init_bits   in  (may be NULL) cells that count as safe without a check
+ *   d_values      out V(x_i)                                  (may be NULL)
+ *   d_neg_bits    out the `negative` mask
+ *   d_result      out ->fail = lexmin over failing cells (other fields untouched)
+ *   d_dbg         out (may be NULL) per cell [decrease, threshold, mean[d], err[d]] */
+int  sl_lyap_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
+                   double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
+                   double* d_dbg);
+
+/* safe_i = init_i | (key_i < key_star) | (prev_i & key_i >= key_keep), the parallel form of
+ * lyapunov.py:513-606.  d_prev_bits may be NULL.  Fills last_safe, max_key,
+ * count_below, count_safe of d_result. */
+int  sl_lyap_finalize(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values,
+                      const uint64_t* d_init_bits, const uint64_t* d_prev_bits,
+                      sl_key key_star, sl_key key_keep, uint64_t* d_safe_bits,
+                      sl_sweep_result* d_result);
+
+/* One radix-select pass over the (V, index) keys of [lo,hi): 256-bin histogram of byte
+ * `byte` (7 = most significant) of the vbits (which = 0) or of the index (which = 1, only cells
+ * with vbits == prefix) among keys whose higher bytes equal `prefix`'s.  d_hist[256] is ADDED to
+ * (zero it first).  Gives the k-th order statistic that lyapunov.py:590-595 reads through argsort. */
+int  sl_select_pass(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values, int which,
+                    int byte, uint64_t prefix, uint64_t vbits_equal, uint64_t* d_hist);
+
+/* Bit mask <-> byte mask helpers for the bool[N] safe_set of the reference (lyapunov.py:187). */
+int  sl_bits_to_bytes(sl_ctx* ctx, int64_t n, const uint64_t* d_bits, uint8_t* d_bytes);
+int  sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uint64_t* d_bits);
+
+/* ---- dynamic programming (reinforcement_learning.py:65-140, 213-279) --------------------- */
+/* One Jacobi sweep over vertices [lo,hi) of the value grid (auxiliary grid #0):
+ *   q(i,a) = r(x_i,u_a) + gamma * V_old(mean f(x_i,u_a))
+ * n_actions == 0: u = policy(x_i) (value_iteration, :135-140).
+ * n_actions  > 0: u_a = h_actions[a] (row-major [n_actions][m]); writes max_a q and the first
+ *                 arg-max (discrete_policy_optimization, :266-279); d_q (may be NULL) gets all q.
+ *   d_v_new [hi-lo], d_argmax [hi-lo] (may be NULL), d_stats[2] = {max|v_new - v_old|, sum (v_new - v_old)^2}. */
+int  sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const double* h_actions,
+                      double* d_v_new, int32_t* d_argmax, double* d_q, double* d_stats);
+
+/* ---- evaluation at arbitrary points (Function.__call__, lyapunov.py:265-288, 324-376) ------ */
+enum sl_eval_what {
+    SL_EVAL_VALUE = 1,      /* V(x)                    out [n][1]                  */
+    SL_EVAL_POLICY = 2,     /* policy(x)               out [n][m]                  */
+    SL_EVAL_DYNAMICS = 3,   /* per-point record        out [n][2+2d] =             */
+    SL_EVAL_DECREASE = 4,   /*   [v_decrease_bound, threshold, mean f[d], error[d]] (both selectors) */
+    SL_EVAL_LV = 5          /* L_v(x)                  out [n][lv_cols]            */
+};
+int  sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_points /* [n][d] */,
+                    double* d_out);
+
+/* ---- diagnostics -------------------------------------------------------------------------- */
+/* D = A(16x4) * B(4x16) through v_mfma_f64_16x16x4_f64 with this library's fragment maps. */
+int  sl_debug_mfma(sl_ctx* ctx, const double* h_a, const double* h_b, double* h_d);
+/* Sustained FP64 rate probes, TFLOP/s: which = 0 MFMA, 1 VALU FMA, 2 both interleaved. */
+int  sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SL_HIP_H */

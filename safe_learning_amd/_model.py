@@ -1,0 +1,187 @@
+"""Translate function specs into the C-ABI model description and upload it.
+
+This is the host-side replacement of the reference's TensorFlow graph construction
+(``safe_learning/lyapunov.py:431-443``, ``reinforcement_learning.py:89-104``): instead of
+composing callables into a graph, the specs are written into ``sl_model_desc`` and the GP /
+table / network payloads are uploaded once (and again only when they change).
+"""
+
+import numpy as np
+
+from . import _hip
+from .functions import (AbsFunction, AbsGradient, CartPole, ConstantFunction, FunctionStack,
+                        GaussianProcess, InvertedPendulum, LinearSystem, LyapunovNetwork,
+                        Norm1Function, QuadraticFunction, Saturation, Triangulation, _gp_heads)
+
+
+class ModelBuilder(object):
+    """Keeps the engine's model in sync with a set of specs."""
+
+    def __init__(self, ctx, grid):
+        self.ctx = ctx
+        self.grid = grid
+        self._gp_signature = None
+        self._tri_signature = [None, None]
+        self._net_signature = None
+        self._policy_table = None
+
+    # ---- pieces --------------------------------------------------------------------------
+    def _write_policy(self, desc, policy):
+        import torch
+        d = self.grid.ndim
+        pd = desc.policy
+        inner = policy
+        pd.saturate = 0
+        if isinstance(policy, Saturation):
+            inner = policy.fun
+        if isinstance(inner, LinearSystem):
+            m = inner.output_dim
+            if inner.input_dim != d:
+                raise ValueError('policy expects %d inputs, the grid has %d dimensions'
+                                 % (inner.input_dim, d))
+            pd.kind = _hip.POLICY_LINEAR
+            for a in range(m):
+                for k in range(d):
+                    pd.matrix[a][k] = float(inner.matrix[a, k])
+        elif isinstance(inner, ConstantFunction):
+            m = inner.output_dim
+            pd.kind = _hip.POLICY_CONST
+            for a in range(m):
+                pd.constant[a] = float(inner.constant[a])
+        elif isinstance(inner, Triangulation):
+            m = inner.output_dim
+            same_grid = (inner.discretization is self.grid or (
+                np.array_equal(inner.discretization.num_points, self.grid.num_points) and
+                np.array_equal(inner.discretization.limits, self.grid.limits)))
+            if same_grid:
+                # a vertex table evaluated at its own vertices is the table itself
+                pd.kind = _hip.POLICY_TABLE
+                self._policy_table = inner._device(self.ctx)
+                pd.d_table = self._policy_table.data_ptr()
+            else:
+                pd.kind = _hip.POLICY_TRI
+                self._upload_tri(1, inner)
+        elif isinstance(inner, np.ndarray):
+            table = np.ascontiguousarray(inner, dtype=np.float64).reshape(self.grid.nindex, -1)
+            m = table.shape[1]
+            pd.kind = _hip.POLICY_TABLE
+            self._policy_table = torch.from_numpy(table).to(self.ctx.torch_device)
+            pd.d_table = self._policy_table.data_ptr()
+        else:
+            raise TypeError('unsupported policy spec %r: use LinearSystem, Saturation(LinearSystem), '
+                            'Triangulation, ConstantFunction or a per-vertex ndarray' % (policy,))
+        if m > _hip.MAX_ACTION_DIM:
+            raise ValueError('at most %d action dimensions are supported' % _hip.MAX_ACTION_DIM)
+        pd.m = m
+        if isinstance(policy, Saturation):
+            pd.saturate = 1
+            lower = np.broadcast_to(np.asarray(policy.lower, dtype=np.float64), (m,))
+            upper = np.broadcast_to(np.asarray(policy.upper, dtype=np.float64), (m,))
+            for a in range(m):
+                pd.lower[a], pd.upper[a] = float(lower[a]), float(upper[a])
+        return m
+
+    def _write_dynamics(self, desc, dynamics, m):
+        d = self.grid.ndim
+        dd = desc.dynamics
+        if isinstance(dynamics, LinearSystem):
+            if dynamics.matrix.shape != (d, d + m):
+                raise ValueError('linear dynamics must be %d x %d' % (d, d + m))
+            dd.kind = _hip.DYN_LINEAR
+            for i in range(d):
+                for j in range(d + m):
+                    dd.matrix[i][j] = float(dynamics.matrix[i, j])
+        elif isinstance(dynamics, (InvertedPendulum, CartPole)):
+            dynamics._write_dynamics(dd)
+        elif isinstance(dynamics, (GaussianProcess, FunctionStack)):
+            dd.kind = _hip.DYN_GP
+            heads, beta = _gp_heads(dynamics)
+            # prior mean rows m(x*) (functions.py:439), one row per output column
+            for gp, _, col0 in heads:
+                if gp.mean_function is not None:
+                    mat = gp.mean_function.matrix
+                    for r in range(mat.shape[0]):
+                        for j in range(d + m):
+                            dd.matrix[col0 + r][j] = float(mat[r, j])
+            self._upload_gp(heads, beta, d + m)
+        else:
+            raise TypeError('unsupported dynamics spec %r' % (dynamics,))
+
+    def _upload_gp(self, heads, beta, p):
+        signature = tuple((id(gp), gp._version, col0) for gp, _, col0 in heads) + (beta,)
+        if signature == self._gp_signature:
+            return
+        for h, (gp, _, col0) in enumerate(heads):
+            if gp.X.shape[1] != p:
+                raise ValueError('GP inputs have %d columns, expected state+action = %d'
+                                 % (gp.X.shape[1], p))
+            self.ctx.gp_set_head(h, gp.X, gp.cholesky_inverse, gp.alpha, col0, gp.kern.variance,
+                                 gp.kern.lengthscales)
+        self.ctx.gp_configure(len(heads), beta)
+        self._gp_signature = signature
+
+    def _upload_tri(self, slot, tri):
+        signature = (id(tri), tri._table_version, tri.project)
+        if signature != self._tri_signature[slot]:
+            tri._upload(self.ctx, slot)
+            self._tri_signature[slot] = signature
+
+    def _write_value(self, vd, fun):
+        if isinstance(fun, QuadraticFunction):
+            fun._write_value(vd)
+        elif isinstance(fun, Triangulation):
+            vd.kind = _hip.V_TRI
+            vd.negate = int(fun.negate)
+            self._upload_tri(0, fun)
+        elif isinstance(fun, LyapunovNetwork):
+            vd.kind = _hip.V_NETWORK
+            vd.negate = int(fun.negate)
+            signature = (id(fun), tuple(w.tobytes() for w in fun.weights))
+            if signature != self._net_signature:
+                fun._upload(self.ctx)
+                self._net_signature = signature
+        else:
+            raise TypeError('unsupported value-function spec %r' % (fun,))
+
+    def _write_lipschitz(self, ld, lipschitz_lyapunov, lipschitz_dynamics, tau):
+        d = self.grid.ndim
+        if isinstance(lipschitz_lyapunov, (AbsFunction, Norm1Function)):
+            inner = lipschitz_lyapunov.fun
+            if not isinstance(inner, LinearSystem) or inner.matrix.shape != (d, d):
+                raise TypeError('AbsFunction / Norm1Function need a %d x %d LinearSystem' % (d, d))
+            ld.lv_kind = (_hip.LIP_ABS_LINEAR if isinstance(lipschitz_lyapunov, AbsFunction)
+                          else _hip.LIP_NORM_LINEAR)
+            for i in range(d):
+                for j in range(d):
+                    ld.lv_matrix[i][j] = float(inner.matrix[i, j])
+        elif isinstance(lipschitz_lyapunov, AbsGradient):
+            ld.lv_kind = _hip.LIP_ABS_GRAD
+        elif np.isscalar(lipschitz_lyapunov):
+            ld.lv_kind = _hip.LIP_CONST
+            ld.lv_const = float(lipschitz_lyapunov)
+        else:
+            raise TypeError('lipschitz_lyapunov must be a float, AbsFunction(LinearSystem), '
+                            'Norm1Function(LinearSystem) or AbsGradient(V); arbitrary Python '
+                            'callables cannot run inside a GPU kernel')
+        if not np.isscalar(lipschitz_dynamics):
+            raise TypeError('lipschitz_dynamics must be a scalar')
+        ld.lf_const = float(lipschitz_dynamics)
+        ld.tau = float(tau)
+
+    # ---- whole model -----------------------------------------------------------------------
+    def upload(self, policy, dynamics, value_function, lipschitz_lyapunov=0.0,
+               lipschitz_dynamics=0.0, tau=0.0, reward=None, gamma=0.0):
+        desc = _hip.ModelDesc()
+        desc.grid = self.grid._desc()
+        m = self._write_policy(desc, policy)
+        self._write_dynamics(desc, dynamics, m)
+        self._write_value(desc.value, value_function)
+        self._write_lipschitz(desc.lipschitz, lipschitz_lyapunov, lipschitz_dynamics, tau)
+        if reward is not None:
+            if not isinstance(reward, QuadraticFunction):
+                raise TypeError('reward_function must be a QuadraticFunction on [x, u]')
+            reward._write_value(desc.reward)
+        desc.gamma = float(gamma)
+        self.ctx.model_set(desc)
+        self._desc = desc
+        return desc

@@ -1,0 +1,340 @@
+// sl_bellman.hip - dynamic-programming sweep (reinforcement_learning.py:65-140, 213-279) and
+// evaluation of the model's functions at explicit points.
+//
+// One thread per grid vertex, consecutive lanes = consecutive flat indices (coalesced V / q /
+// arg-max stores).  For GP dynamics only the posterior MEAN is needed
+// (reinforcement_learning.py:98-99): mean = k_x . alpha' + m(x*), 2 n D flops per (vertex, action).
+// With a finite action set the RBF factorises, k_x[j] = S_j(x) * E_j(u_a): the state factor S_j
+// (one exp per training point) is shared by all actions, the action factors E_j(u_a) are the same
+// for every vertex and are tabulated once per workgroup in LDS.  Training inputs are read with
+// wave-uniform addresses, i.e. scalar loads.
+#include "sl_common.h"
+
+#define SL_MAX_ACTIONS 16
+
+template <bool ACTIONS, int DT, int MT>
+__global__ __launch_bounds__(SL_BLOCK) void k_bellman(
+    const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int n_actions,
+    const double* __restrict__ actions, double* __restrict__ v_new, int32_t* __restrict__ argmax,
+    double* __restrict__ q_out, double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // E table [head][n_pad][A]
+    __shared__ double red_max[SL_BLOCK / 64], red_sum[SL_BLOCK / 64];
+    const SlDims nd = sl_dims<DT, MT>(M);
+    const int d = nd.d, m = nd.m, p = nd.p;
+    const int A = ACTIONS ? n_actions : 1;
+    const bool is_gp = M.m.dynamics.kind == SL_DYN_GP;
+    const SlTri& vt = aux.tri[0];
+
+    // ---- per-workgroup table of action factors E_j(u_a) -------------------------------------
+    int e_off[SL_MAX_GP_HEADS];
+    if (ACTIONS && is_gp) {
+        int off = 0;
+        for (int h = 0; h < gp.nheads; ++h) {
+            const SlGpHeadDev& hd = gp.head[h];
+            e_off[h] = off;
+            for (int t = threadIdx.x; t < hd.n_pad * A; t += SL_BLOCK) {
+                const int j = t / A, a = t - j * A;
+                double z = 0.0;
+                for (int c = 0; c < m; ++c) {
+                    const double dlt = hd.xs[(d + c) * hd.n_pad + j] - actions[a * m + c] * hd.inv_ls[d + c];
+                    z = fma(dlt, dlt, z);
+                }
+                smem[off + t] = exp(-0.5 * z);
+            }
+            off += hd.n_pad * A;
+        }
+        __syncthreads();
+    }
+
+    double lmax = 0.0, lsum = 0.0;
+    for (int64_t idx = lo + (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; idx < hi;
+         idx += (int64_t)gridDim.x * SL_BLOCK) {
+        double x[SL_P];
+        sl_index_to_state(M.m.grid, M.gf, d, idx, x);
+
+        double best_q = 0.0;
+        int best_a = 0;
+        if (!ACTIONS || !is_gp) {
+            // ---- generic path: one (x, u) at a time --------------------------------------------
+            for (int a = 0; a < A; ++a) {
+                double u[SL_M], nxt[SL_D];
+                if (ACTIONS) {
+#pragma unroll
+                    for (int c = 0; c < SL_M; ++c) if (c < m) u[c] = actions[a * m + c];
+                } else {
+                    sl_policy_any<true>(M, nd, aux.tri, idx, x, u);
+                }
+                sl_append_action(nd, u, x);
+                if (is_gp) {
+                    double prior[SL_D];
+                    sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
+#pragma unroll
+                    for (int k = 0; k < SL_D; ++k) if (k < d) nxt[k] = 0.0;
+                    for (int h = 0; h < gp.nheads; ++h) {
+                        const SlGpHeadDev& hd = gp.head[h];
+                        double xg[SL_P];
+#pragma unroll
+                        for (int qd = 0; qd < SL_P; ++qd) xg[qd] = (qd < p) ? x[qd] * hd.inv_ls[qd] : 0.0;
+                        for (int j = 0; j < hd.n; ++j) {
+                            double z = 0.0;
+#pragma unroll
+                            for (int qd = 0; qd < SL_P; ++qd) {
+                                if (qd < p) {
+                                    const double dlt = hd.xs[qd * hd.n_pad + j] - xg[qd];
+                                    z = fma(dlt, dlt, z);
+                                }
+                            }
+                            const double kx = hd.variance * exp(-0.5 * z);
+#pragma unroll
+                            for (int k = 0; k < SL_D; ++k) {
+                                const int dd = k - hd.col0;
+                                if (k < d && dd >= 0 && dd < hd.dout)
+                                    nxt[k] = fma(kx, hd.alpha[j * hd.dout + dd], nxt[k]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < SL_D; ++k) if (k < d) nxt[k] = nxt[k] + prior[k];
+                } else {
+                    sl_dynamics_det(M, nd, x, nxt);
+                }
+                const double r = sl_quadratic(M.m.reward, p, x);
+                double v = sl_tri_eval(vt, nxt, 0, nullptr);
+                if (M.m.value.negate) v = v * -1.0;
+                const double t = M.m.gamma * v;
+                const double q = r + t;                          // reinforcement_learning.py:104
+                if (q_out) q_out[(idx - lo) * A + a] = q;
+                if (a == 0 || q > best_q) { best_q = q; best_a = a; }
+            }
+        } else {
+            // ---- GP + action set: state factors shared by all actions ---------------------------
+            double mean[SL_MAX_ACTIONS][DT > 0 ? DT : SL_D];
+#pragma unroll
+            for (int a = 0; a < SL_MAX_ACTIONS; ++a)
+#pragma unroll
+                for (int k = 0; k < (DT > 0 ? DT : SL_D); ++k) mean[a][k] = 0.0;
+            for (int h = 0; h < gp.nheads; ++h) {
+                const SlGpHeadDev& hd = gp.head[h];
+                double xg[SL_D];
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k) xg[k] = (k < d) ? x[k] * hd.inv_ls[k] : 0.0;
+                const double* etab = smem + e_off[h];
+                for (int j = 0; j < hd.n; ++j) {
+                    double z = 0.0;
+#pragma unroll
+                    for (int k = 0; k < SL_D; ++k) {
+                        if (k < d) {
+                            const double dlt = hd.xs[k * hd.n_pad + j] - xg[k];
+                            z = fma(dlt, dlt, z);
+                        }
+                    }
+                    const double s = hd.variance * exp(-0.5 * z);
+#pragma unroll
+                    for (int a = 0; a < SL_MAX_ACTIONS; ++a) {
+                        if (a < A) {
+                            const double kx = s * etab[j * A + a];
+#pragma unroll
+                            for (int k = 0; k < (DT > 0 ? DT : SL_D); ++k) {
+                                const int dd = k - hd.col0;
+                                if (dd >= 0 && dd < hd.dout)
+                                    mean[a][k] = fma(kx, hd.alpha[j * hd.dout + dd], mean[a][k]);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < SL_MAX_ACTIONS; ++a) {
+                if (a < A) {
+                    double u[SL_M], prior[SL_D], nxt[SL_D];
+#pragma unroll
+                    for (int c = 0; c < SL_M; ++c) if (c < m) u[c] = actions[a * m + c];
+                    sl_append_action(nd, u, x);
+                    sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
+#pragma unroll
+                    for (int k = 0; k < (DT > 0 ? DT : SL_D); ++k) if (k < d) nxt[k] = mean[a][k] + prior[k];
+                    const double r = sl_quadratic(M.m.reward, p, x);
+                    double v = sl_tri_eval(vt, nxt, 0, nullptr);
+                    if (M.m.value.negate) v = v * -1.0;
+                    const double t = M.m.gamma * v;
+                    const double q = r + t;
+                    if (q_out) q_out[(idx - lo) * A + a] = q;
+                    if (a == 0 || q > best_q) { best_q = q; best_a = a; }
+                }
+            }
+        }
+        v_new[idx - lo] = best_q;
+        if (argmax) argmax[idx - lo] = best_a;
+        double v_old = vt.table[idx * vt.ncols];
+        if (M.m.value.negate) v_old = v_old * -1.0;
+        const double diff = best_q - v_old;
+        lmax = fmax(lmax, fabs(diff));
+        lsum = fma(diff, diff, lsum);
+    }
+    // ---- residual statistics ----------------------------------------------------------------------
+    for (int off = 32; off >= 1; off >>= 1) {
+        lmax = fmax(lmax, __shfl_xor(lmax, off, 64));
+        lsum += __shfl_xor(lsum, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red_max[threadIdx.x >> 6] = lmax; red_sum[threadIdx.x >> 6] = lsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < SL_BLOCK / 64; ++w) { lmax = fmax(lmax, red_max[w]); lsum += red_sum[w]; }
+        // non-negative doubles order like their bit patterns
+        atomicMax(reinterpret_cast<unsigned long long*>(&stats[0]),
+                  (unsigned long long)__double_as_longlong(lmax));
+        atomicAdd(&stats[1], lsum);
+    }
+}
+
+extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions,
+                                const double* h_actions, double* d_v_new, int32_t* d_argmax,
+                                double* d_q, double* d_stats) {
+    if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_bellman_sweep: NULL context");
+    if (!ctx->model_set) return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: call sl_model_set first");
+    if (!ctx->h_tri[0].set)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: value table (sl_tri_set slot 0) not set");
+    const SlDevModel& M = ctx->h_model;
+    if (M.m.value.kind != SL_V_TRI)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: the value function must be a Triangulation");
+    if (M.m.reward.kind != SL_V_QUADRATIC)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: reward must be a QuadraticFunction");
+    if (ctx->h_tri[0].grid.d != M.m.grid.d)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: value grid / model grid mismatch");
+    for (int k = 0; k < M.m.grid.d; ++k)
+        if (ctx->h_tri[0].grid.num_points[k] != M.m.grid.num_points[k])
+            return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: value grid / model grid mismatch");
+    if (lo < 0 || hi < lo || hi > M.gf.nindex || !d_v_new || !d_stats)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: bad range or NULL output");
+    if (n_actions < 0 || n_actions > SL_MAX_ACTIONS)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: %d actions (max %d)", n_actions,
+                       SL_MAX_ACTIONS);
+    if (n_actions > 0 && !h_actions)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: NULL action list");
+    if (M.m.policy.kind == SL_POLICY_TRI && !ctx->h_tri[1].set)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: policy table not set");
+    const bool is_gp = M.m.dynamics.kind == SL_DYN_GP;
+    if (is_gp && ctx->h_gp.nheads < 1)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: GP dynamics without heads");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SL_HIP_CHECK(ctx, hipMemsetAsync(d_stats, 0, 2 * sizeof(double), ctx->stream));
+    if (hi == lo) return SL_OK;
+    size_t lds = 0;
+    if (n_actions > 0) {
+        SL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_actions, h_actions,
+                                         sizeof(double) * n_actions * M.m.policy.m,
+                                         hipMemcpyHostToDevice, ctx->stream));
+        SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (is_gp)
+            for (int h = 0; h < ctx->h_gp.nheads; ++h)
+                lds += sizeof(double) * (size_t)ctx->gp_heads[h].n_pad * n_actions;
+        if (lds > 150 * 1024)
+            return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_bellman_sweep: action-factor table needs %zu "
+                                                    "bytes of LDS", lds);
+    }
+    int64_t blocks64 = (hi - lo + SL_BLOCK - 1) / SL_BLOCK;
+    const int cap = ctx->num_cu * 4;
+    const int blocks = (int)(blocks64 < cap ? blocks64 : cap);
+    SlAux aux{ctx->d_tri, ctx->d_net};
+    const int variant = sl_dim_variant_of(M);
+#define SL_BELLMAN(ACT, D_, M_)                                                                  \
+    do {                                                                                         \
+        auto kern = k_bellman<ACT, D_, M_>;                                                      \
+        if (lds > 48 * 1024)                                                                     \
+            SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),           \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                                  (int)lds));                                    \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(SL_BLOCK), lds, ctx->stream, ctx->h_model,   \
+                           ctx->h_gp, aux, lo, hi, n_actions, ctx->d_actions, d_v_new, d_argmax, \
+                           d_q, d_stats);                                                        \
+    } while (0)
+    if (n_actions > 0) {
+        if (variant == 4) SL_BELLMAN(true, 4, 1);
+        else if (variant == 2) SL_BELLMAN(true, 2, 1);
+        else if (variant == 1) SL_BELLMAN(true, 1, 1);
+        else SL_BELLMAN(true, 0, 0);
+    } else {
+        if (variant == 4) SL_BELLMAN(false, 4, 1);
+        else if (variant == 2) SL_BELLMAN(false, 2, 1);
+        else if (variant == 1) SL_BELLMAN(false, 1, 1);
+        else SL_BELLMAN(false, 0, 0);
+    }
+#undef SL_BELLMAN
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+// =============================================================================================
+// evaluation at explicit points
+// =============================================================================================
+__global__ __launch_bounds__(SL_BLOCK) void k_eval_simple(const SlDevModel M, SlAux aux, int what,
+                                                          int64_t n, const double* __restrict__ points,
+                                                          double* __restrict__ out) {
+    const SlDims nd = sl_dims<0, 0>(M);
+    const int d = nd.d;
+    for (int64_t i = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * SL_BLOCK) {
+        double x[SL_P];
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) if (k < d) x[k] = points[i * d + k];
+        if (what == SL_EVAL_VALUE) {
+            out[i] = sl_value_any<true>(M, d, aux, x);
+        } else if (what == SL_EVAL_POLICY) {
+            double u[SL_M];
+            sl_policy_any<true>(M, nd, aux.tri, 0, x, u);
+#pragma unroll
+            for (int a = 0; a < SL_M; ++a) if (a < nd.m) out[i * nd.m + a] = u[a];
+        } else {   // SL_EVAL_LV
+            double lv[SL_D];
+            sl_lv_any<true>(M, d, aux, x, lv);
+            const int cols = M.m.lipschitz.lv_cols;
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) if (k < cols) out[i * cols + k] = lv[k];
+        }
+    }
+}
+
+int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
+                 double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
+                 double* d_dbg, const double* d_points);
+
+extern "C" int sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_points,
+                              double* d_out) {
+    if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_eval_points: NULL context");
+    if (!ctx->model_set) return sl_fail(ctx, SL_ERR_INVALID, "sl_eval_points: call sl_model_set first");
+    if (n < 0 || !d_points || !d_out) return sl_fail(ctx, SL_ERR_INVALID, "sl_eval_points: bad argument");
+    if (n == 0) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const SlDevModel& M = ctx->h_model;
+    if (what == SL_EVAL_VALUE || what == SL_EVAL_POLICY || what == SL_EVAL_LV) {
+        if (what == SL_EVAL_POLICY && M.m.policy.kind == SL_POLICY_TABLE)
+            return sl_fail(ctx, SL_ERR_UNSUPPORTED, "a per-vertex policy table cannot be evaluated "
+                                                    "at arbitrary points");
+        if (M.m.value.kind == SL_V_TRI && !ctx->h_tri[0].set && what != SL_EVAL_POLICY)
+            return sl_fail(ctx, SL_ERR_INVALID, "sl_eval_points: value table not set");
+        if (M.m.value.kind == SL_V_NETWORK && !ctx->h_net.set && what != SL_EVAL_POLICY)
+            return sl_fail(ctx, SL_ERR_INVALID, "sl_eval_points: network not set");
+        int64_t b = (n + SL_BLOCK - 1) / SL_BLOCK;
+        if (b > SL_MAX_GRID) b = SL_MAX_GRID;
+        SlAux aux{ctx->d_tri, ctx->d_net};
+        hipLaunchKernelGGL(k_eval_simple, dim3((unsigned)b), dim3(SL_BLOCK), 0, ctx->stream,
+                           ctx->h_model, aux, what, n, d_points, d_out);
+        SL_HIP_CHECK(ctx, hipGetLastError());
+        return SL_OK;
+    }
+    if (what != SL_EVAL_DYNAMICS && what != SL_EVAL_DECREASE)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_eval_points: unknown selector %d", what);
+    // run the sweep kernels over the point list; d_out receives the per-point record
+    // [decrease, threshold, mean[d], err[d]]
+    const size_t need = sizeof(uint64_t) * (size_t)((n + 63) / 64) + sizeof(sl_sweep_result);
+    if (need > ctx->scratch_bytes) {
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    sl_sweep_result* res = reinterpret_cast<sl_sweep_result*>(ctx->d_scratch);
+    uint64_t* bits = reinterpret_cast<uint64_t*>(res + 1);
+    return sl_sweep_any(ctx, 0, n, nullptr, nullptr, bits, res, d_out, d_points);
+}

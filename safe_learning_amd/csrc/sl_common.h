@@ -1,0 +1,233 @@
+// sl_common.h - context object and device helpers shared by the kernel files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "sl_hip.h"
+#include "sl_model.h"
+
+#define SL_BLOCK 256
+#define SL_MAX_GRID 2048
+
+struct SlGpHeadHost {
+    bool set = false;
+    int n = 0, n_pad = 0, p = 0, dout = 0, col0 = 0, cfg = 0;
+    double* d_xs = nullptr;
+    double* d_mpack = nullptr;
+    double* d_alpha = nullptr;
+};
+
+struct sl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    bool model_set = false;
+
+    SlDevModel h_model;            // host copy
+    SlDevModel* d_model = nullptr; // device copy read by the kernels
+    SlGpDev h_gp;
+    SlGpDev* d_gp = nullptr;
+    SlGpHeadHost gp_heads[SL_MAX_GP_HEADS];
+    int gp_cfg = 0;
+
+    SlTri h_tri[2];
+    SlTri* d_tri = nullptr;        // [2]
+    double* d_tri_points[2] = {nullptr, nullptr};
+    SlNet h_net;
+    SlNet* d_net = nullptr;
+    double* d_net_kernels = nullptr;
+
+    void* d_scratch = nullptr;         // grown on demand (sl_eval_points)
+    size_t scratch_bytes = 0;
+    sl_key* d_partials = nullptr;      // SL_MAX_GRID entries x 4 keys
+    int64_t* d_partial_counts = nullptr;
+    double* d_actions = nullptr;       // bellman action list
+    int num_cu = 256;
+};
+
+extern thread_local std::string g_sl_last_error;
+
+int sl_fail(sl_ctx* ctx, int code, const char* fmt, ...);
+
+#define SL_HIP_CHECK(ctx, call)                                                             \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return sl_fail((ctx), SL_ERR_HIP, "%s failed: %s (%s:%d)", #call,               \
+                           hipGetErrorString(e__), __FILE__, __LINE__);                     \
+    } while (0)
+
+// The model (and the GP head table) travel BY VALUE in the kernel-argument segment: every field
+// is then fetched with scalar loads and used as an SGPR operand.  Only the large tables
+// (triangulation, network) stay behind pointers.
+struct SlAux {
+    const SlTri* __restrict__ tri;  // [2]
+    const SlNet* __restrict__ net;
+};
+static_assert(sizeof(SlDevModel) + sizeof(SlGpDev) < 3900, "kernel arguments must stay below 4 KiB");
+
+// ---- wave / block reductions on (V, index) keys -----------------------------------------
+__device__ __forceinline__ void sl_key_min(uint64_t& v, int64_t& i, uint64_t ov, int64_t oi) {
+    if (sl_key_less(ov, oi, v, i)) { v = ov; i = oi; }
+}
+__device__ __forceinline__ void sl_key_max(uint64_t& v, int64_t& i, uint64_t ov, int64_t oi) {
+    if (sl_key_less(v, i, ov, oi)) { v = ov; i = oi; }
+}
+
+template <bool IS_MIN>
+__device__ __forceinline__ void sl_wave_reduce_key(uint64_t& v, int64_t& i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t ov = __shfl_xor((unsigned long long)v, off, 64);
+        int64_t oi = __shfl_xor((long long)i, off, 64);
+        if (IS_MIN) sl_key_min(v, i, ov, oi); else sl_key_max(v, i, ov, oi);
+    }
+}
+
+// Reduce over the whole block; result valid in thread 0. `sv`/`si` are LDS scratch of nwaves.
+template <bool IS_MIN>
+__device__ __forceinline__ void sl_block_reduce_key(uint64_t& v, int64_t& i, uint64_t* sv,
+                                                    int64_t* si) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    sl_wave_reduce_key<IS_MIN>(v, i);
+    __syncthreads();
+    if (lane == 0) { sv[wave] = v; si[wave] = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) {
+            if (IS_MIN) sl_key_min(v, i, sv[w], si[w]); else sl_key_max(v, i, sv[w], si[w]);
+        }
+    }
+}
+
+// state of cell `idx`: generated from the flat grid index, or read from an explicit point list
+__device__ __forceinline__ void sl_cell_state(const SlDevModel& M, int d, int64_t idx,
+                                              const double* __restrict__ points, double* x) {
+    if (points) {
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) if (k < d) x[k] = points[idx * d + k];
+    } else {
+        sl_index_to_state(M.m.grid, M.gf, d, idx, x);
+    }
+}
+
+// ---- the per-cell Lyapunov check shared by the deterministic and the GP kernels --------------
+struct SlCellCheck {
+    double v_x, decrease, threshold;
+    bool negative;
+};
+
+// policy(x).  GENERAL = false: closed-form and per-vertex table policies only (no scratch).
+template <bool GENERAL>
+__device__ __forceinline__ void sl_policy_any(const SlDevModel& M, SlDims n, const SlTri* tri,
+                                              int64_t idx, const double* x, double* u) {
+    const sl_policy_desc& p = M.m.policy;
+    if (p.kind == SL_POLICY_TABLE) {
+#pragma unroll
+        for (int a = 0; a < SL_M; ++a) if (a < n.m) u[a] = p.d_table[idx * n.m + a];
+        sl_saturate(p, n.m, u);
+    } else if (GENERAL && p.kind == SL_POLICY_TRI) {
+#pragma unroll
+        for (int a = 0; a < SL_M; ++a) if (a < n.m) u[a] = sl_tri_eval(tri[1], x, a, nullptr);
+        sl_saturate(p, n.m, u);
+    } else {
+        sl_policy_closed_form(M, n, x, u);
+    }
+}
+
+// =============================================================================================
+// LyapunovNetwork forward / input gradient (examples/utilities.py:85-104)
+// =============================================================================================
+__device__ inline double sl_network_value(const SlNet& net, const double* z, int d, double* grad) {
+    double act[SL_MAX_NN_LAYERS + 1][SL_NN_MAXW];
+    double pre[SL_MAX_NN_LAYERS][SL_NN_MAXW];
+    for (int k = 0; k < d; ++k) act[0][k] = z[k];
+    for (int l = 0; l < net.nlayers; ++l) {
+        const int in = net.dims[l], out = net.dims[l + 1];
+        const double* K = net.kernels + net.koff[l];
+        for (int o = 0; o < out; ++o) {
+            double s = 0.0;
+            for (int i = 0; i < in; ++i) s = fma(act[l][i], K[o * in + i], s);
+            pre[l][o] = s;
+            act[l + 1][o] = sl_act(net.act[l], s);
+        }
+    }
+    const int last = net.dims[net.nlayers];
+    double value = 0.0;
+    for (int o = 0; o < last; ++o) value = fma(act[net.nlayers][o], act[net.nlayers][o], value);
+    if (grad) {
+        double g[SL_NN_MAXW], gn[SL_NN_MAXW];
+        for (int o = 0; o < last; ++o) g[o] = 2.0 * act[net.nlayers][o];
+        for (int l = net.nlayers - 1; l >= 0; --l) {
+            const int in = net.dims[l], out = net.dims[l + 1];
+            const double* K = net.kernels + net.koff[l];
+            for (int i = 0; i < in; ++i) gn[i] = 0.0;
+            for (int o = 0; o < out; ++o) {
+                double t = g[o] * sl_dact(net.act[l], pre[l][o], act[l + 1][o]);
+                for (int i = 0; i < in; ++i) gn[i] = fma(t, K[o * in + i], gn[i]);
+            }
+            for (int i = 0; i < in; ++i) g[i] = gn[i];
+        }
+        for (int k = 0; k < d; ++k) grad[k] = g[k];
+    }
+    return value;
+}
+
+
+// V(z).  GENERAL = false: quadratic only.
+template <bool GENERAL>
+__device__ __forceinline__ double sl_value_any(const SlDevModel& M, int d, const SlAux& aux,
+                                               const double* z) {
+    if (!GENERAL || M.m.value.kind == SL_V_QUADRATIC) return sl_quadratic(M.m.value, d, z);
+    if (M.m.value.kind == SL_V_TRI) {
+        double v = sl_tri_eval(aux.tri[0], z, 0, nullptr);
+        return M.m.value.negate ? (v * -1.0) : v;
+    }
+    double v = sl_network_value(*aux.net, z, d, nullptr);
+    return M.m.value.negate ? (v * -1.0) : v;
+}
+
+// L_v(z) including |grad V|
+template <bool GENERAL>
+__device__ __forceinline__ void sl_lv_any(const SlDevModel& M, int d, const SlAux& aux,
+                                          const double* z, double* lv) {
+    if (!GENERAL || M.m.lipschitz.lv_kind != SL_LIP_ABS_GRAD) { sl_lv(M, d, z, lv); return; }
+    double g[SL_D];
+    if (M.m.value.kind == SL_V_TRI) sl_tri_eval(aux.tri[0], z, 0, g);
+    else sl_network_value(*aux.net, z, d, g);
+#pragma unroll
+    for (int k = 0; k < SL_D; ++k) if (k < d) lv[k] = fabs(g[k]);
+}
+
+template <bool GENERAL>
+__device__ __forceinline__ SlCellCheck sl_cell_check(const SlDevModel& M, int d, const SlAux& aux,
+                                                     const double* x, const double* next_mean,
+                                                     const double* err) {
+    SlCellCheck r;
+    double lv_x[SL_D], lv_n[SL_D];
+    r.v_x = sl_value_any<GENERAL>(M, d, aux, x);
+    double v_next = sl_value_any<GENERAL>(M, d, aux, next_mean);
+    if (M.uncertain) sl_lv_any<GENERAL>(M, d, aux, next_mean, lv_n);
+    r.decrease = sl_decrease(M, d, r.v_x, v_next, lv_n, err);
+    sl_lv_any<GENERAL>(M, d, aux, x, lv_x);
+    r.threshold = sl_threshold(M, d, lv_x, M.m.lipschitz.tau);
+    r.negative = r.decrease < r.threshold;
+    return r;
+}
+
+// kernel-variant id of a model: 0 = generic, 1..4 = (d, 1)
+static inline int sl_dim_variant_of(const SlDevModel& M) {
+    if (M.m.policy.m == 1 && M.m.grid.d >= 1 && M.m.grid.d <= 4) return M.m.grid.d;
+    return 0;
+}
+
+// true when the model needs the table / network code paths
+static inline bool sl_model_is_general(const SlDevModel& M) {
+    return M.m.value.kind != SL_V_QUADRATIC || M.m.policy.kind == SL_POLICY_TRI ||
+           M.m.lipschitz.lv_kind == SL_LIP_ABS_GRAD;
+}

@@ -1,0 +1,584 @@
+// sl_gp.hip - the GP-dynamics Lyapunov sweep for gfx950 (CDNA4): one fused kernel per sweep.
+//
+// Per cell the reference evaluates (safe_learning/functions.py:438-456, 507-515)
+//     k_x   = variance * exp(-1/2 |(X - x*) / l|^2)            n values
+//     a     = L^-1 k_x                                        n^2 flops  <- 96 % of the work
+//     mean  = a^T alpha + m(x*),   var = k(x*,x*) - |a|^2,   err = beta sqrt(var)
+// and then the decrease check of lyapunov.py:436-441.  Here:
+//
+//  * a = Linv k_x is a lower-triangular GEMM  [n x n] . [n x cells]  on the FP64 matrix cores
+//    (v_mfma_f64_16x16x4_f64, 64-lane wavefronts).  Linv is pre-packed on the host into MFMA
+//    A-fragment order, so every A operand is one coalesced 1 KiB load per wavefront, streamed
+//    from L2 / Infinity Cache (the triangle is 4 MiB at n = 1024).
+//  * A workgroup of W wavefronts owns a tile of C = 16*CB consecutive grid cells and a panel of
+//    16*R*W rows; each wavefront keeps R x CB accumulator tiles (the whole a-panel) in
+//    registers, k_x is produced cooperatively in 64-row chunks straight into B-fragment order
+//    in LDS (double buffered, one barrier per chunk), so k_x never touches HBM.
+//  * only |a|^2 per cell is needed, so the accumulators are squared and reduced in registers
+//    (row order inside a tile is irrelevant); the mean uses alpha' = Linv^T alpha
+//    (mean = k_x . alpha' + m(x*)), accumulated while k_x is generated.
+//  * training inputs (pre-divided by the lengthscales) are staged once per workgroup in LDS.
+//  * the decrease check, the 64-lane ballot for the mask and the (V, index) lexmin of the
+//    failing cells run in the same kernel; HBM traffic is 8 B (V) + 1 bit per cell.
+#include "sl_common.h"
+
+typedef double sl_d4 __attribute__((ext_vector_type(4)));
+typedef double sl_d2 __attribute__((ext_vector_type(2)));
+
+#define SL_GP_SLABS_PER_CHUNK 16          // 64 training points per chunk
+#define SL_GP_DOUT_MAX SL_MAX_STATE_DIM
+
+// configurations: {W wavefronts, R row blocks per wavefront, CB cell blocks}
+//   cfg 0: small n (tests)   W=4 R=1 CB=1   panel   64 rows, 16 cells
+//   cfg 1:                    W=8 R=8 CB=2   panel 1024 rows, 32 cells
+//   cfg 2:                    W=8 R=4 CB=4   panel  512 rows, 64 cells
+static const int kCfgW[3] = {4, 8, 8};
+static const int kCfgR[3] = {1, 8, 4};
+static const int kCfgCB[3] = {1, 2, 4};
+
+static inline int cfg_panel_rows(int cfg) { return 16 * kCfgR[cfg] * kCfgW[cfg]; }
+
+template <int W, int R, int CB, bool GENERAL, int DT, int MT>
+__global__ __launch_bounds__(W * 64) void k_gp_sweep(
+    const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
+    const uint64_t* __restrict__ init_bits, double* __restrict__ values,
+    uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
+    int xs_doubles, const double* __restrict__ points) {
+    constexpr int C = 16 * CB;
+    constexpr int RP = 16 * R * W;                 // rows per panel
+    constexpr int RB = R * W;                      // row blocks per panel
+    constexpr int FRAGS = SL_GP_SLABS_PER_CHUNK * CB / W;   // k_x fragments per wavefront per chunk
+    constexpr int KXBUF = SL_GP_SLABS_PER_CHUNK * CB * 64;  // doubles per k_x buffer
+    static_assert(W % CB == 0, "W must be a multiple of CB");
+    static_assert((SL_GP_SLABS_PER_CHUNK * CB) % W == 0, "fragments must divide evenly");
+
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* xs_l = smem;                           // [p][n_pad]
+    double* kx_l = xs_l + xs_doubles;              // [2][KXBUF]
+    double* part_ss = kx_l + 2 * KXBUF;            // [W][C]
+    double* part_m = part_ss + W * C;              // [W][16][DOUT_MAX]
+    double* cell_mean = part_m + W * 16 * SL_GP_DOUT_MAX;    // [C][SL_D]
+    double* cell_err = cell_mean + C * SL_D;                 // [C][SL_D]
+    uint64_t* sv = reinterpret_cast<uint64_t*>(cell_err + C * SL_D);   // [W]
+    int64_t* si = reinterpret_cast<int64_t*>(sv + W);                  // [W]
+
+    const SlDims nd = sl_dims<DT, MT>(M);
+    const int d = nd.d, p = nd.p;
+    constexpr int DOUT_UNROLL = DT > 0 ? DT : SL_GP_DOUT_MAX;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform
+    const int gcb = wave % CB;                     // cell block this wavefront generates k_x for
+    const int lcol = lane & 15, lk = lane >> 4;
+
+    uint64_t best_v = ~0ull;
+    int64_t best_i = INT64_MAX;
+    int staged_head = -1;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t tile_base = lo + tile * C;
+        if (tile_base >= hi) {                     // padding tile: only clears mask bits
+            if (tid == 0) {
+                if (C == 64) neg_bits[(tile_base - lo) >> 6] = 0ull;
+                else if (C == 32) reinterpret_cast<uint32_t*>(neg_bits)[(tile_base - lo) >> 5] = 0u;
+                else reinterpret_cast<uint16_t*>(neg_bits)[(tile_base - lo) >> 4] = 0;
+            }
+            continue;
+        }
+
+        for (int h = 0; h < gp.nheads; ++h) {
+            const SlGpHeadDev& hd = gp.head[h];
+            const int n_pad = hd.n_pad, dout = hd.dout;
+            const int nslab2 = hd.nslab2;
+            const double variance = hd.variance;
+            const double* __restrict__ alphap = hd.alpha;
+            const double* __restrict__ mpack = hd.mpack;
+            if (staged_head != h) {
+                __syncthreads();
+                for (int k = tid; k < p * n_pad; k += W * 64) xs_l[k] = hd.xs[k];
+                staged_head = h;
+                __syncthreads();
+            }
+            // GP input [x, policy(x)] / lengthscales of the cell this lane generates k_x for
+            double xg[SL_P];
+            {
+                int64_t gidx = tile_base + 16 * gcb + lcol;
+                gidx = gidx < hi ? gidx : hi - 1;
+                double u[SL_M];
+                sl_cell_state(M, d, gidx, points, xg);
+                sl_policy_any<GENERAL>(M, nd, aux.tri, gidx, xg, u);
+                sl_append_action(nd, u, xg);
+#pragma unroll
+                for (int q = 0; q < SL_P; ++q) xg[q] = (q < p) ? xg[q] * hd.inv_ls[q] : 0.0;
+            }
+
+            double ss[CB];
+            double gmean[DOUT_UNROLL];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) ss[cb] = 0.0;
+#pragma unroll
+            for (int dd = 0; dd < DOUT_UNROLL; ++dd) gmean[dd] = 0.0;
+
+            const int npanels = n_pad / RP;
+            for (int pan = 0; pan < npanels; ++pan) {
+                sl_d4 acc[R][CB];
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) acc[r][cb] = (sl_d4){0.0, 0.0, 0.0, 0.0};
+
+                const int nchunks = (pan + 1) * (RP / 64);
+                const int first_new_chunk = pan * (RP / 64);     // chunks not generated before
+
+                // k_x chunk `ch` -> LDS buffer `buf`, B-fragment order [slab pair][cb][lane][2]
+                auto generate = [&](int ch, int buf) {
+                    const bool add_mean = ch >= first_new_chunk;
+#pragma unroll 1
+                    for (int k = 0; k < FRAGS; ++k) {
+                        const int f = wave + k * W;
+                        const int s = f / CB;
+                        const int j = 64 * ch + 4 * s + lk;
+                        double z = 0.0;
+#pragma unroll
+                        for (int q = 0; q < SL_P; ++q) {
+                            if (q < p) {
+                                const double dlt = xs_l[q * n_pad + j] - xg[q];
+                                z = fma(dlt, dlt, z);
+                            }
+                        }
+                        const double kx = variance * exp(-0.5 * z);
+                        if (add_mean) {
+#pragma unroll
+                            for (int dd = 0; dd < DOUT_UNROLL; ++dd)
+                                if (dd < dout) gmean[dd] = fma(kx, alphap[j * dout + dd], gmean[dd]);
+                        }
+                        kx_l[buf * KXBUF + ((((s >> 1) * CB + gcb) * 64 + lane) << 1) + (s & 1)] = kx;
+                    }
+                };
+
+                // A-fragment address: uniform (row block, slab pair) offset + per-lane 16 bytes
+                auto load_a = [&](int I, int s2abs) -> sl_d2 {
+                    const double* base = mpack + ((size_t)I * nslab2 + (size_t)s2abs) * 128;
+                    return *reinterpret_cast<const sl_d2*>(base + lane * 2);
+                };
+
+                generate(0, 0);
+                __syncthreads();
+                for (int ch = 0; ch < nchunks; ++ch) {
+                    const int buf = ch & 1;
+                    // slab pairs of this chunk on or below the diagonal, per owned row block;
+                    // counts are even and non-decreasing in r, inactive row blocks come first
+                    int cnt[R], rowblk[R];
+                    int r0 = R;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int wsel = (r & 1) ? (W - 1 - wave) : wave;    // balance the triangle
+                        rowblk[r] = pan * RB + r * W + wsel;
+                        int c = 2 * rowblk[r] + 2 - 8 * ch;
+                        c = c > 8 ? 8 : c;
+                        cnt[r] = c > 0 ? c : 0;
+                        if (cnt[r] > 0 && r0 == R) r0 = r;
+                    }
+                    // two-deep register queue of A fragments, primed before k_x generation so
+                    // that the first loads fly while the next chunk's exponentials are computed
+                    sl_d2 q0 = {0.0, 0.0}, q1 = {0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (r == r0) {
+                            q0 = load_a(rowblk[r], 8 * ch);
+                            q1 = load_a(rowblk[r], 8 * ch + 1);
+                        }
+                    }
+                    if (ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
+                    const double* kxb = kx_l + buf * KXBUF;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int c = cnt[r];
+                        for (int s2 = 0; s2 < c; ++s2) {
+                            sl_d2 q2 = q1;
+                            const int t = s2 + 2;
+                            if (t < c) {
+                                q2 = load_a(rowblk[r], 8 * ch + t);
+                            } else if (r + 1 < R) {
+                                q2 = load_a(rowblk[r + 1 < R ? r + 1 : r], 8 * ch + (t - c));
+                            }
+                            sl_d2 b2[CB];
+#pragma unroll
+                            for (int cb = 0; cb < CB; ++cb)
+                                b2[cb] = *reinterpret_cast<const sl_d2*>(
+                                    kxb + (((s2 * CB + cb) * 64 + lane) << 1));
+#pragma unroll
+                            for (int cb = 0; cb < CB; ++cb)
+                                acc[r][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                    q0.x, b2[cb].x, acc[r][cb], 0, 0, 0);
+#pragma unroll
+                            for (int cb = 0; cb < CB; ++cb)
+                                acc[r][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                    q0.y, b2[cb].y, acc[r][cb], 0, 0, 0);
+                            q0 = q1;
+                            q1 = q2;
+                        }
+                    }
+                    __syncthreads();
+                }
+                // |a|^2 of this panel's rows (row order inside a tile does not matter)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        const sl_d4 t = acc[r][cb];
+                        ss[cb] = fma(t.x, t.x, ss[cb]);
+                        ss[cb] = fma(t.y, t.y, ss[cb]);
+                        ss[cb] = fma(t.z, t.z, ss[cb]);
+                        ss[cb] = fma(t.w, t.w, ss[cb]);
+                    }
+            }
+            // ---- reduce over the 4 lane groups, then over wavefronts through LDS ---------------
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                ss[cb] += __shfl_xor(ss[cb], 16, 64);
+                ss[cb] += __shfl_xor(ss[cb], 32, 64);
+            }
+#pragma unroll
+            for (int dd = 0; dd < DOUT_UNROLL; ++dd) {
+                gmean[dd] += __shfl_xor(gmean[dd], 16, 64);
+                gmean[dd] += __shfl_xor(gmean[dd], 32, 64);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) part_ss[wave * C + cb * 16 + lane] = ss[cb];
+#pragma unroll
+                for (int dd = 0; dd < DOUT_UNROLL; ++dd)
+                    part_m[(wave * 16 + lane) * SL_GP_DOUT_MAX + dd] = gmean[dd];
+            }
+            __syncthreads();
+            if (tid < C) {
+                double sumsq = 0.0;
+                for (int w = 0; w < W; ++w) sumsq += part_ss[w * C + tid];
+                const double var = variance - sumsq;                       // functions.py:451
+                const double e = gp.beta * sqrt(var);                      // functions.py:514
+                const int cb = tid >> 4, cc = tid & 15;
+                for (int dd = 0; dd < dout; ++dd) {
+                    double mu = 0.0;
+                    for (int w = cb; w < W; w += CB) mu += part_m[(w * 16 + cc) * SL_GP_DOUT_MAX + dd];
+                    cell_mean[tid * SL_D + hd.col0 + dd] = mu;
+                    cell_err[tid * SL_D + hd.col0 + dd] = e;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- per-cell decrease check, mask word, failing-cell key -------------------------------
+        const int64_t idx = tile_base + tid;
+        const bool valid = (tid < C) && (idx < hi);
+        bool negative = false;
+        double v_x = 0.0;
+        if (valid) {
+            double x[SL_P], u[SL_M], prior[SL_D], mean[SL_D], err[SL_D];
+            sl_cell_state(M, d, idx, points, x);
+            sl_policy_any<GENERAL>(M, nd, aux.tri, idx, x, u);
+            sl_append_action(nd, u, x);
+            sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);   // m(x*), functions.py:439
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) {
+                if (k < d) {
+                    mean[k] = cell_mean[tid * SL_D + k] + prior[k];
+                    err[k] = cell_err[tid * SL_D + k];
+                }
+            }
+            SlCellCheck c = sl_cell_check<GENERAL>(M, d, aux, x, mean, err);
+            negative = c.negative;
+            v_x = c.v_x;
+            if (values) values[idx - lo] = v_x;
+            if (dbg) {
+                double* o = dbg + (idx - lo) * (2 + 2 * d);
+                o[0] = c.decrease; o[1] = c.threshold;
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k) if (k < d) { o[2 + k] = mean[k]; o[2 + d + k] = err[k]; }
+            }
+        }
+        if (wave == 0) {
+            const uint64_t word = __ballot(negative);
+            uint64_t init = 0ull;
+            if (init_bits) {
+                const uint64_t iw = init_bits[(tile_base - lo) >> 6];
+                init = iw >> ((tile_base - lo) & 63);
+            }
+            if (lane == 0) {
+                if (C == 64) neg_bits[(tile_base - lo) >> 6] = word;
+                else if (C == 32) reinterpret_cast<uint32_t*>(neg_bits)[(tile_base - lo) >> 5] = (uint32_t)word;
+                else reinterpret_cast<uint16_t*>(neg_bits)[(tile_base - lo) >> 4] = (uint16_t)word;
+            }
+            const bool ok = negative || ((init >> lane) & 1ull);
+            if (valid && !ok) sl_key_min(best_v, best_i, sl_vbits(v_x), idx);
+        }
+        // (cell_mean / cell_err are rewritten only after the next tile's barriers)
+    }
+    __syncthreads();
+    sl_block_reduce_key<true>(best_v, best_i, sv, si);
+    if (tid == 0) { partials[blockIdx.x].vbits = best_v; partials[blockIdx.x].index = best_i; }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static int choose_cfg(int n) {
+    const char* env = getenv("SL_GP_CFG");
+    if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
+    if (n <= 256) return 0;
+    return 1;
+}
+
+extern "C" int sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
+                              const double* h_X, const double* h_Linv, const double* h_alpha,
+                              double variance, const double* h_lengthscales) {
+    if (!ctx || !h_X || !h_Linv || !h_alpha || !h_lengthscales)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head: NULL argument");
+    if (head < 0 || head >= SL_MAX_GP_HEADS)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head: head %d outside [0,%d)", head,
+                       SL_MAX_GP_HEADS);
+    if (n < 1 || p < 1 || p > SL_MAX_INPUT_DIM || dout < 1 || col0 < 0 ||
+        col0 + dout > SL_MAX_STATE_DIM)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head: bad sizes n=%d p=%d dout=%d col0=%d",
+                       n, p, dout, col0);
+    if (!(variance > 0.0)) return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head: variance <= 0");
+    for (int q = 0; q < p; ++q)
+        if (!(h_lengthscales[q] > 0.0))
+            return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head: lengthscale <= 0");
+    const int cfg = choose_cfg(n);
+    const int rp = cfg_panel_rows(cfg);
+    const int n_pad = ((n + rp - 1) / rp) * rp;
+    const int nslab2 = n_pad / 8;
+
+    std::vector<double> xs((size_t)p * n_pad, 0.0), alphap((size_t)n_pad * dout, 0.0);
+    std::vector<double> mpack((size_t)n_pad * n_pad, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int q = 0; q < p; ++q) xs[(size_t)q * n_pad + j] = h_X[(size_t)j * p + q] / h_lengthscales[q];
+    // alpha' = Linv^T alpha  (so that mean = k_x . alpha' = a . alpha, functions.py:442)
+    for (int i = 0; i < n; ++i) {
+        for (int dd = 0; dd < dout; ++dd) {
+            const double ai = h_alpha[(size_t)i * dout + dd];
+            if (ai == 0.0) continue;
+            for (int j = 0; j <= i; ++j) alphap[(size_t)j * dout + dd] += h_Linv[(size_t)i * n + j] * ai;
+        }
+    }
+    // MFMA A fragments: [row block I][slab pair S2][lane][2]; A[i = lane & 15][k = lane >> 4]
+    for (int I = 0; I < n_pad / 16; ++I) {
+        for (int S2 = 0; S2 < nslab2; ++S2) {
+            if (8 * S2 > 16 * I + 15) continue;                      // strictly above the diagonal
+            for (int l = 0; l < 64; ++l) {
+                const int row = 16 * I + (l & 15);
+                for (int e = 0; e < 2; ++e) {
+                    const int col = 4 * (2 * S2 + e) + (l >> 4);
+                    double v = 0.0;
+                    if (row < n && col <= row) v = h_Linv[(size_t)row * n + col];
+                    mpack[(((size_t)I * nslab2 + S2) * 64 + l) * 2 + e] = v;
+                }
+            }
+        }
+    }
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SlGpHeadHost& hh = ctx->gp_heads[head];
+    if (hh.d_xs) (void)hipFree(hh.d_xs);
+    if (hh.d_mpack) (void)hipFree(hh.d_mpack);
+    if (hh.d_alpha) (void)hipFree(hh.d_alpha);
+    hh.d_xs = hh.d_mpack = hh.d_alpha = nullptr;
+    SL_HIP_CHECK(ctx, hipMalloc(&hh.d_xs, xs.size() * sizeof(double)));
+    SL_HIP_CHECK(ctx, hipMalloc(&hh.d_mpack, mpack.size() * sizeof(double)));
+    SL_HIP_CHECK(ctx, hipMalloc(&hh.d_alpha, alphap.size() * sizeof(double)));
+    SL_HIP_CHECK(ctx, hipMemcpy(hh.d_xs, xs.data(), xs.size() * sizeof(double), hipMemcpyHostToDevice));
+    SL_HIP_CHECK(ctx, hipMemcpy(hh.d_mpack, mpack.data(), mpack.size() * sizeof(double), hipMemcpyHostToDevice));
+    SL_HIP_CHECK(ctx, hipMemcpy(hh.d_alpha, alphap.data(), alphap.size() * sizeof(double), hipMemcpyHostToDevice));
+    hh.set = true; hh.n = n; hh.n_pad = n_pad; hh.p = p; hh.dout = dout; hh.col0 = col0; hh.cfg = cfg;
+
+    SlGpHeadDev& dv = ctx->h_gp.head[head];
+    memset(&dv, 0, sizeof(dv));
+    dv.n = n; dv.n_pad = n_pad; dv.p = p; dv.dout = dout; dv.col0 = col0; dv.nslab2 = nslab2;
+    dv.variance = variance;
+    for (int q = 0; q < p; ++q) dv.inv_ls[q] = 1.0 / h_lengthscales[q];
+    dv.xs = hh.d_xs; dv.mpack = hh.d_mpack; dv.alpha = hh.d_alpha;
+    return SL_OK;
+}
+
+extern "C" int sl_gp_configure(sl_ctx* ctx, int nheads, double beta) {
+    if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_gp_configure: NULL context");
+    if (nheads < 1 || nheads > SL_MAX_GP_HEADS)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_configure: %d heads", nheads);
+    int cfg = -1;
+    for (int h = 0; h < nheads; ++h) {
+        if (!ctx->gp_heads[h].set)
+            return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_configure: head %d not set", h);
+        if (cfg < 0) cfg = ctx->gp_heads[h].cfg;
+        if (cfg != ctx->gp_heads[h].cfg)
+            return sl_fail(ctx, SL_ERR_UNSUPPORTED,
+                           "sl_gp_configure: heads need the same kernel configuration "
+                           "(training-set sizes too different)");
+    }
+    ctx->gp_cfg = cfg;
+    ctx->h_gp.nheads = nheads;
+    ctx->h_gp.beta = beta;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_gp, &ctx->h_gp, sizeof(SlGpDev), hipMemcpyHostToDevice));
+    return SL_OK;
+}
+
+template <int W, int R, int CB, bool GENERAL, int DT, int MT>
+static int launch_cfg(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
+                      double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
+                      const double* d_points) {
+    constexpr int C = 16 * CB;
+    const int64_t nwords = (hi - lo + 63) / 64;
+    const int64_t ntiles = nwords * (64 / C);
+    int xs_doubles = 0;
+    const int p = ctx->h_model.in_dim;
+    for (int h = 0; h < ctx->h_gp.nheads; ++h) {
+        if (ctx->gp_heads[h].p != p)
+            return sl_fail(ctx, SL_ERR_INVALID, "GP head %d has input dim %d, model has %d", h,
+                           ctx->gp_heads[h].p, p);
+        const int v = p * ctx->gp_heads[h].n_pad;
+        xs_doubles = v > xs_doubles ? v : xs_doubles;
+    }
+    xs_doubles = (xs_doubles + 1) & ~1;            // keep the k_x buffers 16-byte aligned
+    const size_t lds = sizeof(double) * ((size_t)xs_doubles + 2 * SL_GP_SLABS_PER_CHUNK * CB * 64 +
+                                         W * C + W * 16 * SL_GP_DOUT_MAX + 2 * C * SL_D + 2 * W);
+    if (lds > 160 * 1024)
+        return sl_fail(ctx, SL_ERR_UNSUPPORTED, "GP training set too large for LDS staging "
+                                                "(%zu bytes needed)", lds);
+    auto kern = k_gp_sweep<W, R, CB, GENERAL, DT, MT>;
+    SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t blocks = ntiles < ctx->num_cu ? ntiles : ctx->num_cu;
+    if (blocks > SL_MAX_GRID) blocks = SL_MAX_GRID;
+    *nblocks = (int)blocks;
+    SlAux aux{ctx->d_tri, ctx->d_net};
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, ctx->stream, ctx->h_model,
+                       ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits, ctx->d_partials, d_dbg,
+                       xs_doubles, d_points);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+int sl_gp_sweep_launch(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
+                       double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
+                       const double* d_points) {
+    if (ctx->h_gp.nheads < 1)
+        return sl_fail(ctx, SL_ERR_INVALID, "GP dynamics selected but sl_gp_configure not called");
+    int covered = 0;
+    for (int h = 0; h < ctx->h_gp.nheads; ++h) covered += ctx->gp_heads[h].dout;
+    if (covered != ctx->h_model.m.grid.d)
+        return sl_fail(ctx, SL_ERR_INVALID, "GP heads cover %d outputs, state dimension is %d",
+                       covered, ctx->h_model.m.grid.d);
+    const bool general = sl_model_is_general(ctx->h_model);
+    const int variant = sl_dim_variant_of(ctx->h_model);
+#define SL_GP_LAUNCH(W_, R_, CB_, G, D_, M_)                                                      \
+    return launch_cfg<W_, R_, CB_, G, D_, M_>(ctx, lo, hi, d_init_bits, d_values, d_neg_bits,     \
+                                              nblocks, d_dbg, d_points)
+#define SL_GP_CASE(id, W_, R_, CB_)                                                               \
+    case id:                                                                                      \
+        if (general) {                                                                            \
+            if (variant == 2) { SL_GP_LAUNCH(W_, R_, CB_, true, 2, 1); }                          \
+            SL_GP_LAUNCH(W_, R_, CB_, true, 0, 0);                                                \
+        }                                                                                         \
+        switch (variant) {                                                                        \
+            case 1: SL_GP_LAUNCH(W_, R_, CB_, false, 1, 1);                                       \
+            case 2: SL_GP_LAUNCH(W_, R_, CB_, false, 2, 1);                                       \
+            case 3: SL_GP_LAUNCH(W_, R_, CB_, false, 3, 1);                                       \
+            case 4: SL_GP_LAUNCH(W_, R_, CB_, false, 4, 1);                                       \
+            default: SL_GP_LAUNCH(W_, R_, CB_, false, 0, 0);                                      \
+        }
+    switch (ctx->gp_cfg) {
+        SL_GP_CASE(0, 4, 1, 1)
+        SL_GP_CASE(1, 8, 8, 2)
+        SL_GP_CASE(2, 8, 4, 4)
+    }
+#undef SL_GP_CASE
+#undef SL_GP_LAUNCH
+    return sl_fail(ctx, SL_ERR_INVALID, "bad GP kernel configuration %d", ctx->gp_cfg);
+}
+
+// =============================================================================================
+// diagnostics
+// =============================================================================================
+__global__ void k_debug_mfma(const double* __restrict__ a, const double* __restrict__ b,
+                             double* __restrict__ dout) {
+    const int l = threadIdx.x;
+    sl_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(l & 15) * 4 + (l >> 4)], b[(l >> 4) * 16 + (l & 15)],
+                                               acc, 0, 0, 0);
+    // assumed C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+    dout[((l >> 4) + 0) * 16 + (l & 15)] = acc.x;
+    dout[((l >> 4) + 4) * 16 + (l & 15)] = acc.y;
+    dout[((l >> 4) + 8) * 16 + (l & 15)] = acc.z;
+    dout[((l >> 4) + 12) * 16 + (l & 15)] = acc.w;
+}
+
+extern "C" int sl_debug_mfma(sl_ctx* ctx, const double* h_a, const double* h_b, double* h_d) {
+    if (!ctx || !h_a || !h_b || !h_d) return sl_fail(ctx, SL_ERR_INVALID, "sl_debug_mfma: NULL");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    double *da, *db, *dd;
+    SL_HIP_CHECK(ctx, hipMalloc(&da, 64 * sizeof(double)));
+    SL_HIP_CHECK(ctx, hipMalloc(&db, 64 * sizeof(double)));
+    SL_HIP_CHECK(ctx, hipMalloc(&dd, 256 * sizeof(double)));
+    SL_HIP_CHECK(ctx, hipMemcpy(da, h_a, 64 * sizeof(double), hipMemcpyHostToDevice));
+    SL_HIP_CHECK(ctx, hipMemcpy(db, h_b, 64 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_mfma, dim3(1), dim3(64), 0, ctx->stream, da, db, dd);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SL_HIP_CHECK(ctx, hipMemcpy(h_d, dd, 256 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dd);
+    return SL_OK;
+}
+
+// FP64 rate probes: which = 0 MFMA only, 1 VALU FMA only, 2 both in the same wavefront
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_fp64_rate(int iters, double* sink) {
+    sl_d4 acc[8];
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { acc[k] = (sl_d4){0.0, 0.0, 0.0, 0.0}; v[k] = threadIdx.x * 1e-3 + k; }
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (WHICH != 1) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
+            if (WHICH != 0) {
+#pragma unroll
+                for (int rep = 0; rep < 16; ++rep) v[(k + rep) & 7] = fma(v[(k + rep) & 7], b, a);
+            }
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += acc[k].x + acc[k].y + acc[k].z + acc[k].w + v[k];
+    if (s == 12345.678) sink[0] = s;
+}
+
+extern "C" int sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_tflops) {
+    if (!ctx || !h_tflops || which < 0 || which > 2 || iters < 1)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_debug_fp64_rate: bad argument");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    double* sink;
+    SL_HIP_CHECK(ctx, hipMalloc(&sink, sizeof(double)));
+    hipEvent_t e0, e1;
+    SL_HIP_CHECK(ctx, hipEventCreate(&e0));
+    SL_HIP_CHECK(ctx, hipEventCreate(&e1));
+    const int blocks = ctx->num_cu * 2;          // 8 wavefronts per CU = 2 per SIMD
+    for (int rep = 0; rep < 2; ++rep) {
+        SL_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+        if (which == 0) hipLaunchKernelGGL(k_fp64_rate<0>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink);
+        else if (which == 1) hipLaunchKernelGGL(k_fp64_rate<1>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink);
+        else hipLaunchKernelGGL(k_fp64_rate<2>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink);
+        SL_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+        SL_HIP_CHECK(ctx, hipEventSynchronize(e1));
+    }
+    float ms = 0.f;
+    SL_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    const double waves = (double)blocks * 4.0;
+    double flops = 0.0;
+    if (which != 1) flops += waves * (double)iters * 8.0 * (2.0 * 16 * 16 * 4);
+    if (which != 0) flops += waves * (double)iters * 8.0 * 16.0 * 64.0 * 2.0;
+    *h_tflops = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+    return SL_OK;
+}

@@ -1,0 +1,655 @@
+// sl_kernels.hip - context, model upload and the streaming (HBM-bound) passes of the Lyapunov
+// sweep for gfx950: values, deterministic-dynamics decrease check, safe-set finalisation,
+// radix-select histogram, bit/byte mask conversion.  The GP (MFMA) sweep lives in sl_gp.hip,
+// the dynamic-programming sweep in sl_bellman.hip.
+//
+// Launch geometry: 256-thread workgroups (4 wavefronts of 64), a grid capped at 2048 blocks
+// (= 8 per CU) that walks the cell range in 256-cell strides, so consecutive lanes own
+// consecutive flat indices: value stores are 512 B per wavefront instruction, each wavefront
+// produces exactly one 64-bit mask word with one ballot.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include "sl_common.h"
+
+thread_local std::string g_sl_last_error;
+
+int sl_fail(sl_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_sl_last_error = buf;
+    if (ctx) ctx->error = buf;
+    return code;
+}
+
+// =============================================================================================
+// context
+// =============================================================================================
+extern "C" int sl_version(void) { return 100; }
+
+extern "C" const char* sl_last_error(const sl_ctx* ctx) {
+    return ctx ? ctx->error.c_str() : g_sl_last_error.c_str();
+}
+
+extern "C" int sl_ctx_create(int device, void* hip_stream, sl_ctx** out) {
+    if (!out) return sl_fail(nullptr, SL_ERR_INVALID, "sl_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return sl_fail(nullptr, SL_ERR_HIP, "sl_ctx_create: no HIP device (%s)",
+                       hipGetErrorString(e));
+    if (device < 0 || device >= count)
+        return sl_fail(nullptr, SL_ERR_INVALID, "sl_ctx_create: device %d out of range", device);
+    sl_ctx* ctx = new (std::nothrow) sl_ctx();
+    if (!ctx) return sl_fail(nullptr, SL_ERR_NOMEM, "sl_ctx_create: out of host memory");
+    ctx->device = device;
+    ctx->stream = (hipStream_t)hip_stream;
+    memset(&ctx->h_model, 0, sizeof(ctx->h_model));
+    memset(&ctx->h_gp, 0, sizeof(ctx->h_gp));
+    memset(&ctx->h_tri, 0, sizeof(ctx->h_tri));
+    memset(&ctx->h_net, 0, sizeof(ctx->h_net));
+    SL_HIP_CHECK(ctx, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_model, sizeof(SlDevModel)));
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_gp, sizeof(SlGpDev)));
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_tri, 2 * sizeof(SlTri)));
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_net, sizeof(SlNet)));
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_partials, sizeof(sl_key) * 4 * SL_MAX_GRID));
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_partial_counts, sizeof(int64_t) * 2 * SL_MAX_GRID));
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_actions, sizeof(double) * 1024));
+    SL_HIP_CHECK(ctx, hipMemset(ctx->d_tri, 0, 2 * sizeof(SlTri)));
+    SL_HIP_CHECK(ctx, hipMemset(ctx->d_net, 0, sizeof(SlNet)));
+    SL_HIP_CHECK(ctx, hipMemset(ctx->d_gp, 0, sizeof(SlGpDev)));
+    *out = ctx;
+    return SL_OK;
+}
+
+extern "C" int sl_ctx_destroy(sl_ctx* ctx) {
+    if (!ctx) return SL_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int h = 0; h < SL_MAX_GP_HEADS; ++h) {
+        if (ctx->gp_heads[h].d_xs) (void)hipFree(ctx->gp_heads[h].d_xs);
+        if (ctx->gp_heads[h].d_mpack) (void)hipFree(ctx->gp_heads[h].d_mpack);
+        if (ctx->gp_heads[h].d_alpha) (void)hipFree(ctx->gp_heads[h].d_alpha);
+    }
+    for (int s = 0; s < 2; ++s) if (ctx->d_tri_points[s]) (void)hipFree(ctx->d_tri_points[s]);
+    if (ctx->d_net_kernels) (void)hipFree(ctx->d_net_kernels);
+    (void)hipFree(ctx->d_model);
+    (void)hipFree(ctx->d_gp);
+    (void)hipFree(ctx->d_tri);
+    (void)hipFree(ctx->d_net);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    (void)hipFree(ctx->d_partials);
+    (void)hipFree(ctx->d_partial_counts);
+    (void)hipFree(ctx->d_actions);
+    delete ctx;
+    return SL_OK;
+}
+
+extern "C" int sl_ctx_synchronize(sl_ctx* ctx) {
+    if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "NULL context");
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return SL_OK;
+}
+
+static int sl_check_grid(sl_ctx* ctx, const sl_grid_desc& g, SlGridFast* gf) {
+    if (g.d < 1 || g.d > SL_MAX_STATE_DIM)
+        return sl_fail(ctx, SL_ERR_INVALID, "grid dimension %d outside [1,%d]", g.d,
+                       SL_MAX_STATE_DIM);
+    memset(gf, 0, sizeof(*gf));
+    gf->d = g.d;
+    gf->all_pow2 = 1;
+    gf->nindex = 1;
+    for (int k = 0; k < g.d; ++k) {
+        int64_t n = g.num_points[k];
+        if (n < 2) return sl_fail(ctx, SL_ERR_INVALID, "num_points[%d] = %lld < 2", k, (long long)n);
+        if (gf->nindex > INT64_MAX / n) return sl_fail(ctx, SL_ERR_INVALID, "grid too large");
+        gf->nindex *= n;
+        gf->num32[k] = (uint32_t)n;
+        if ((n & (n - 1)) == 0) {
+            int s = 0;
+            while ((1ll << s) < n) ++s;
+            gf->shift[k] = s;
+        } else {
+            gf->all_pow2 = 0;
+        }
+    }
+    return SL_OK;
+}
+
+extern "C" int sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model) {
+    if (!ctx || !h_model) return sl_fail(ctx, SL_ERR_INVALID, "sl_model_set: NULL argument");
+    SlDevModel M;
+    memset(&M, 0, sizeof(M));
+    M.m = *h_model;
+    int rc = sl_check_grid(ctx, M.m.grid, &M.gf);
+    if (rc) return rc;
+    const sl_policy_desc& p = M.m.policy;
+    if (p.m < 1 || p.m > SL_MAX_ACTION_DIM)
+        return sl_fail(ctx, SL_ERR_INVALID, "action dimension %d outside [1,%d]", p.m,
+                       SL_MAX_ACTION_DIM);
+    if (p.kind < SL_POLICY_LINEAR || p.kind > SL_POLICY_TRI)
+        return sl_fail(ctx, SL_ERR_INVALID, "unknown policy kind %d", p.kind);
+    if (p.kind == SL_POLICY_TABLE && !p.d_table)
+        return sl_fail(ctx, SL_ERR_INVALID, "table policy without a table");
+    M.in_dim = M.m.grid.d + p.m;
+    if (M.in_dim > SL_MAX_INPUT_DIM)
+        return sl_fail(ctx, SL_ERR_INVALID, "state+action dimension %d > %d", M.in_dim,
+                       SL_MAX_INPUT_DIM);
+    const int dk = M.m.dynamics.kind;
+    if (dk < SL_DYN_LINEAR || dk > SL_DYN_GP)
+        return sl_fail(ctx, SL_ERR_INVALID, "unknown dynamics kind %d", dk);
+    if (dk == SL_DYN_PENDULUM && (M.m.grid.d != 2 || p.m != 1))
+        return sl_fail(ctx, SL_ERR_INVALID, "pendulum dynamics need d=2, m=1");
+    if (dk == SL_DYN_CARTPOLE && (M.m.grid.d != 4 || p.m != 1))
+        return sl_fail(ctx, SL_ERR_INVALID, "cart-pole dynamics need d=4, m=1");
+    M.uncertain = (dk == SL_DYN_GP);
+    const int vk = M.m.value.kind;
+    if (vk < SL_V_QUADRATIC || vk > SL_V_NETWORK)
+        return sl_fail(ctx, SL_ERR_INVALID, "unknown value-function kind %d", vk);
+    const int lk = M.m.lipschitz.lv_kind;
+    if (lk < SL_LIP_CONST || lk > SL_LIP_ABS_GRAD)
+        return sl_fail(ctx, SL_ERR_INVALID, "unknown L_v kind %d", lk);
+    if (lk == SL_LIP_CONST || lk == SL_LIP_NORM_LINEAR) M.m.lipschitz.lv_cols = 1;
+    else M.m.lipschitz.lv_cols = M.m.grid.d;
+    if (lk == SL_LIP_ABS_GRAD && vk == SL_V_QUADRATIC)
+        return sl_fail(ctx, SL_ERR_INVALID, "ABS_GRAD L_v needs a table or network V "
+                                             "(use ABS_LINEAR with P + P^T)");
+    ctx->h_model = M;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_model, &ctx->h_model, sizeof(SlDevModel),
+                                     hipMemcpyHostToDevice, ctx->stream));
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // h_model may change right after
+    ctx->model_set = true;
+    return SL_OK;
+}
+
+// =============================================================================================
+// auxiliary grids (Triangulation) and the network
+// =============================================================================================
+extern "C" int sl_tri_set(sl_ctx* ctx, int slot, const sl_grid_desc* h_grid, int nsimplex,
+                          const int32_t* h_simplices, const double* h_hyperplanes,
+                          const double* h_discrete_points, int project, int ncols,
+                          const double* d_table) {
+    if (!ctx || !h_grid || !h_simplices || !h_hyperplanes || !h_discrete_points)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_tri_set: NULL argument");
+    if (slot < 0 || slot > 1) return sl_fail(ctx, SL_ERR_INVALID, "sl_tri_set: slot %d", slot);
+    if (nsimplex < 1 || nsimplex > SL_MAX_SIMPLICES)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_tri_set: %d simplices (max %d)", nsimplex,
+                       SL_MAX_SIMPLICES);
+    SlGridFast gf;
+    int rc = sl_check_grid(ctx, *h_grid, &gf);
+    if (rc) return rc;
+    if (ncols < 1) return sl_fail(ctx, SL_ERR_INVALID, "sl_tri_set: ncols < 1");
+    SlTri& t = ctx->h_tri[slot];
+    memset(&t, 0, sizeof(t));
+    t.grid = *h_grid;
+    t.nsimplex = nsimplex;
+    t.project = project ? 1 : 0;
+    t.ncols = ncols;
+    t.set = 1;
+    const int d = h_grid->d;
+    for (int s = 0; s < nsimplex; ++s) {
+        for (int v = 0; v <= d; ++v) t.simplices[s][v] = h_simplices[s * (d + 1) + v];
+        for (int k = 0; k < d; ++k)
+            for (int j = 0; j < d; ++j) t.hyper[s][k][j] = h_hyperplanes[(s * d + k) * d + j];
+    }
+    int64_t stride = 1, total = 0;
+    for (int k = d - 1; k >= 0; --k) { t.stride[k] = stride; stride *= h_grid->num_points[k]; }
+    for (int k = 0; k < d; ++k) { t.points_off[k] = (int32_t)total; total += h_grid->num_points[k]; }
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (ctx->d_tri_points[slot]) { (void)hipFree(ctx->d_tri_points[slot]); ctx->d_tri_points[slot] = nullptr; }
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_tri_points[slot], sizeof(double) * total));
+    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_tri_points[slot], h_discrete_points, sizeof(double) * total,
+                                hipMemcpyHostToDevice));
+    t.points = ctx->d_tri_points[slot];
+    t.table = d_table;
+    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_tri + slot, &t, sizeof(SlTri), hipMemcpyHostToDevice));
+    return SL_OK;
+}
+
+extern "C" int sl_tri_set_table(sl_ctx* ctx, int slot, const double* d_table) {
+    if (!ctx || slot < 0 || slot > 1 || !ctx->h_tri[slot].set)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_tri_set_table: slot not set");
+    ctx->h_tri[slot].table = d_table;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_tri + slot, &ctx->h_tri[slot], sizeof(SlTri),
+                                hipMemcpyHostToDevice));
+    return SL_OK;
+}
+
+extern "C" int sl_network_set(sl_ctx* ctx, int nlayers, const int32_t* h_dims,
+                              const int32_t* h_activations, const double* h_kernels) {
+    if (!ctx || !h_dims || !h_activations || !h_kernels)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_network_set: NULL argument");
+    if (nlayers < 1 || nlayers > SL_MAX_NN_LAYERS)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_network_set: %d layers (max %d)", nlayers,
+                       SL_MAX_NN_LAYERS);
+    SlNet& n = ctx->h_net;
+    memset(&n, 0, sizeof(n));
+    n.nlayers = nlayers;
+    n.set = 1;
+    int64_t total = 0;
+    for (int l = 0; l <= nlayers; ++l) {
+        if (h_dims[l] < 1 || h_dims[l] > SL_NN_MAXW)
+            return sl_fail(ctx, SL_ERR_INVALID, "sl_network_set: width %d outside [1,%d]",
+                           h_dims[l], SL_NN_MAXW);
+        n.dims[l] = h_dims[l];
+    }
+    for (int l = 0; l < nlayers; ++l) {
+        n.act[l] = h_activations[l];
+        n.koff[l] = (int32_t)total;
+        total += (int64_t)h_dims[l] * h_dims[l + 1];
+    }
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (ctx->d_net_kernels) { (void)hipFree(ctx->d_net_kernels); ctx->d_net_kernels = nullptr; }
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_net_kernels, sizeof(double) * total));
+    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_net_kernels, h_kernels, sizeof(double) * total,
+                                hipMemcpyHostToDevice));
+    n.kernels = ctx->d_net_kernels;
+    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_net, &n, sizeof(SlNet), hipMemcpyHostToDevice));
+    return SL_OK;
+}
+
+static int sl_check_ready(sl_ctx* ctx, const char* who) {
+    if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "%s: NULL context", who);
+    if (!ctx->model_set) return sl_fail(ctx, SL_ERR_INVALID, "%s: call sl_model_set first", who);
+    const SlDevModel& M = ctx->h_model;
+    if (M.m.value.kind == SL_V_TRI && !ctx->h_tri[0].set)
+        return sl_fail(ctx, SL_ERR_INVALID, "%s: value table (sl_tri_set slot 0) not set", who);
+    if (M.m.value.kind == SL_V_NETWORK && !ctx->h_net.set)
+        return sl_fail(ctx, SL_ERR_INVALID, "%s: network not set", who);
+    if (M.m.policy.kind == SL_POLICY_TRI && !ctx->h_tri[1].set)
+        return sl_fail(ctx, SL_ERR_INVALID, "%s: policy table (sl_tri_set slot 1) not set", who);
+    return SL_OK;
+}
+
+static inline int sl_grid_blocks(int64_t ncells) {
+    int64_t b = (ncells + SL_BLOCK - 1) / SL_BLOCK;
+    if (b > SL_MAX_GRID) b = SL_MAX_GRID;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// =============================================================================================
+// kernel-variant dispatch: fixed (state, action) dimensions fold every per-dimension predicate
+// =============================================================================================
+// variant ids: 0 = generic (dimensions read from the model), 1..4 = (d, 1) with d = 1..4
+static inline int sl_dim_variant(const SlDevModel& M) {
+    if (M.m.policy.m == 1 && M.m.grid.d >= 1 && M.m.grid.d <= 4) return M.m.grid.d;
+    return 0;
+}
+#define SL_DISPATCH_DIMS(variant, general, CALL)                                     \
+    do {                                                                             \
+        if (general) {                                                               \
+            if ((variant) == 2) { CALL(true, 2, 1); } else { CALL(true, 0, 0); }     \
+        } else {                                                                     \
+            switch (variant) {                                                       \
+                case 1: CALL(false, 1, 1); break;                                    \
+                case 2: CALL(false, 2, 1); break;                                    \
+                case 3: CALL(false, 3, 1); break;                                    \
+                case 4: CALL(false, 4, 1); break;                                    \
+                default: CALL(false, 0, 0); break;                                   \
+            }                                                                        \
+        }                                                                            \
+    } while (0)
+
+// =============================================================================================
+// values: V(x_i)                                             (lyapunov.py:305-322)
+// =============================================================================================
+template <bool GENERAL, int DT, int MT>
+__global__ __launch_bounds__(SL_BLOCK) void k_values(const SlDevModel M, SlAux aux, int64_t lo,
+                                                     int64_t hi, double* __restrict__ values) {
+    const SlDims n = sl_dims<DT, MT>(M);
+    for (int64_t idx = lo + (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; idx < hi;
+         idx += (int64_t)gridDim.x * SL_BLOCK) {
+        double x[SL_P];
+        sl_index_to_state(M.m.grid, M.gf, n.d, idx, x);
+        values[idx - lo] = sl_value_any<GENERAL>(M, n.d, aux, x);
+    }
+}
+
+extern "C" int sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values) {
+    int rc = sl_check_ready(ctx, "sl_values");
+    if (rc) return rc;
+    if (lo < 0 || hi < lo || hi > ctx->h_model.gf.nindex || !d_values)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_values: bad range or NULL output");
+    if (hi == lo) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SlAux aux{ctx->d_tri, ctx->d_net};
+    const int blocks = sl_grid_blocks(hi - lo);
+#define SL_CALL(G, D_, M_)                                                                    \
+    hipLaunchKernelGGL((k_values<G, D_, M_>), dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream,   \
+                       ctx->h_model, aux, lo, hi, d_values)
+    SL_DISPATCH_DIMS(sl_dim_variant(ctx->h_model), sl_model_is_general(ctx->h_model), SL_CALL);
+#undef SL_CALL
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+// =============================================================================================
+// deterministic-dynamics decrease check                    (lyapunov.py:436-441, 524-535)
+// =============================================================================================
+template <bool GENERAL, int DT, int MT>
+__global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
+    const SlDevModel M, SlAux aux, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
+    double* __restrict__ values, uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials,
+    double* __restrict__ dbg, const double* __restrict__ points) {
+    __shared__ uint64_t sv[SL_BLOCK / 64];
+    __shared__ int64_t si[SL_BLOCK / 64];
+    const SlDims n = sl_dims<DT, MT>(M);
+    const int d = n.d;
+    const int lane = threadIdx.x & 63;
+    uint64_t best_v = ~0ull;
+    int64_t best_i = INT64_MAX;
+    for (int64_t base = lo + (int64_t)blockIdx.x * SL_BLOCK; base < hi;
+         base += (int64_t)gridDim.x * SL_BLOCK) {
+        const int64_t idx = base + threadIdx.x;
+        const bool valid = idx < hi;
+        bool negative = false;
+        double v_x = 0.0;
+        if (valid) {
+            double x[SL_P], u[SL_M], nxt[SL_D], err[SL_D];
+            sl_cell_state(M, d, idx, points, x);
+            sl_policy_any<GENERAL>(M, n, aux.tri, idx, x, u);
+            sl_append_action(n, u, x);
+            sl_dynamics_det(M, n, x, nxt);
+            SlCellCheck c = sl_cell_check<GENERAL>(M, d, aux, x, nxt, err);
+            negative = c.negative;
+            v_x = c.v_x;
+            if (values) values[idx - lo] = v_x;
+            if (dbg) {
+                double* o = dbg + (idx - lo) * (2 + 2 * d);
+                o[0] = c.decrease; o[1] = c.threshold;
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k) if (k < d) { o[2 + k] = nxt[k]; o[2 + d + k] = 0.0; }
+            }
+        }
+        const uint64_t word = __ballot(negative);
+        const int64_t wbase = base + (threadIdx.x & ~63);        // first cell of this wavefront
+        if (wbase < hi) {
+            const int64_t widx = (wbase - lo) >> 6;
+            if (lane == 0) neg_bits[widx] = word;
+            const uint64_t init = init_bits ? init_bits[widx] : 0ull;
+            const bool ok = negative || ((init >> lane) & 1ull);
+            if (valid && !ok) sl_key_min(best_v, best_i, sl_vbits(v_x), idx);
+        }
+    }
+    sl_block_reduce_key<true>(best_v, best_i, sv, si);
+    if (threadIdx.x == 0) { partials[blockIdx.x].vbits = best_v; partials[blockIdx.x].index = best_i; }
+}
+
+// partials[0..n) -> result->fail
+__global__ __launch_bounds__(SL_BLOCK) void k_reduce_fail(const sl_key* __restrict__ partials,
+                                                          int n, sl_sweep_result* result) {
+    __shared__ uint64_t sv[SL_BLOCK / 64];
+    __shared__ int64_t si[SL_BLOCK / 64];
+    uint64_t v = ~0ull;
+    int64_t i = INT64_MAX;
+    for (int k = threadIdx.x; k < n; k += SL_BLOCK) sl_key_min(v, i, partials[k].vbits, partials[k].index);
+    sl_block_reduce_key<true>(v, i, sv, si);
+    if (threadIdx.x == 0) { result->fail.vbits = v; result->fail.index = i; }
+}
+
+int sl_gp_sweep_launch(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
+                       double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
+                       const double* d_points);
+
+// shared by sl_lyap_sweep (grid cells) and sl_eval_points (explicit points)
+int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
+                 double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
+                 double* d_dbg, const double* d_points) {
+    int rc = sl_check_ready(ctx, "sl_lyap_sweep");
+    if (rc) return rc;
+    if (lo < 0 || hi < lo || (!d_points && hi > ctx->h_model.gf.nindex) || (lo & 63))
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_lyap_sweep: bad range (lo must be a multiple of 64)");
+    if (d_points && ctx->h_model.m.policy.kind == SL_POLICY_TABLE)
+        return sl_fail(ctx, SL_ERR_UNSUPPORTED, "a per-vertex policy table cannot be evaluated "
+                                                "at arbitrary points");
+    if (!d_neg_bits || !d_result) return sl_fail(ctx, SL_ERR_INVALID, "sl_lyap_sweep: NULL output");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int blocks = 1;
+    if (hi == lo) {
+        blocks = 0;
+    } else if (ctx->h_model.m.dynamics.kind == SL_DYN_GP) {
+        rc = sl_gp_sweep_launch(ctx, lo, hi, d_init_bits, d_values, d_neg_bits, &blocks, d_dbg,
+                                d_points);
+        if (rc) return rc;
+    } else {
+        blocks = sl_grid_blocks(hi - lo);
+        SlAux aux{ctx->d_tri, ctx->d_net};
+#define SL_CALL(G, D_, M_)                                                                     \
+    hipLaunchKernelGGL((k_det_sweep<G, D_, M_>), dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream, \
+                       ctx->h_model, aux, lo, hi, d_init_bits, d_values, d_neg_bits,           \
+                       ctx->d_partials, d_dbg, d_points)
+        SL_DISPATCH_DIMS(sl_dim_variant(ctx->h_model), sl_model_is_general(ctx->h_model), SL_CALL);
+#undef SL_CALL
+        SL_HIP_CHECK(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_reduce_fail, dim3(1), dim3(SL_BLOCK), 0, ctx->stream, ctx->d_partials,
+                       blocks, d_result);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+extern "C" int sl_lyap_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
+                             double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
+                             double* d_dbg) {
+    return sl_sweep_any(ctx, lo, hi, d_init_bits, d_values, d_neg_bits, d_result, d_dbg, nullptr);
+}
+
+// =============================================================================================
+// finalisation: the prefix rule of lyapunov.py:513-606 in parallel form
+// =============================================================================================
+__global__ __launch_bounds__(SL_BLOCK) void k_finalize(
+    int64_t lo, int64_t hi, const double* __restrict__ values,
+    const uint64_t* __restrict__ init_bits, const uint64_t* __restrict__ prev_bits, sl_key star,
+    sl_key keep, uint64_t* __restrict__ safe_bits, sl_key* __restrict__ partials,
+    int64_t* __restrict__ counts) {
+    __shared__ uint64_t sv[SL_BLOCK / 64];
+    __shared__ int64_t si[SL_BLOCK / 64];
+    __shared__ int64_t sc[2][SL_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t ls_v = 0ull, mx_v = 0ull;
+    int64_t ls_i = -1, mx_i = -1;
+    int64_t n_below = 0, n_safe = 0;
+    for (int64_t base = lo + (int64_t)blockIdx.x * SL_BLOCK; base < hi;
+         base += (int64_t)gridDim.x * SL_BLOCK) {
+        const int64_t idx = base + threadIdx.x;
+        const bool valid = idx < hi;
+        const int64_t wbase = base + (threadIdx.x & ~63);
+        bool safe = false;
+        if (wbase < hi) {
+            const int64_t widx = (wbase - lo) >> 6;
+            const uint64_t init = init_bits ? init_bits[widx] : 0ull;
+            const uint64_t prev = prev_bits ? prev_bits[widx] : 0ull;
+            if (valid) {
+                const uint64_t vb = sl_vbits(values[idx - lo]);
+                const bool below = sl_key_less(vb, idx, star.vbits, star.index);
+                const bool kept = ((prev >> lane) & 1ull) && !sl_key_less(vb, idx, keep.vbits, keep.index);
+                safe = below || kept || ((init >> lane) & 1ull);
+                if (below) { ++n_below; sl_key_max(ls_v, ls_i, vb, idx); }
+                sl_key_max(mx_v, mx_i, vb, idx);
+            }
+            const uint64_t word = __ballot(safe);
+            if (lane == 0) { safe_bits[widx] = word; n_safe += __popcll(word); }
+        }
+    }
+    // block reductions
+    for (int off = 32; off >= 1; off >>= 1) {
+        n_below += __shfl_xor((long long)n_below, off, 64);
+        n_safe += __shfl_xor((long long)n_safe, off, 64);
+    }
+    if (lane == 0) { sc[0][wave] = n_below; sc[1][wave] = n_safe; }
+    sl_block_reduce_key<false>(ls_v, ls_i, sv, si);
+    __syncthreads();
+    sl_block_reduce_key<false>(mx_v, mx_i, sv, si);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x].vbits = ls_v; partials[2 * blockIdx.x].index = ls_i;
+        partials[2 * blockIdx.x + 1].vbits = mx_v; partials[2 * blockIdx.x + 1].index = mx_i;
+        int64_t a = 0, b = 0;
+        for (int w = 0; w < SL_BLOCK / 64; ++w) { a += sc[0][w]; b += sc[1][w]; }
+        counts[2 * blockIdx.x] = a; counts[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ __launch_bounds__(SL_BLOCK) void k_reduce_finalize(const sl_key* __restrict__ partials,
+                                                              const int64_t* __restrict__ counts,
+                                                              int n, sl_sweep_result* result) {
+    __shared__ uint64_t sv[SL_BLOCK / 64];
+    __shared__ int64_t si[SL_BLOCK / 64];
+    __shared__ int64_t sc[2][SL_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t ls_v = 0ull, mx_v = 0ull;
+    int64_t ls_i = -1, mx_i = -1, a = 0, b = 0;
+    for (int k = threadIdx.x; k < n; k += SL_BLOCK) {
+        sl_key_max(ls_v, ls_i, partials[2 * k].vbits, partials[2 * k].index);
+        sl_key_max(mx_v, mx_i, partials[2 * k + 1].vbits, partials[2 * k + 1].index);
+        a += counts[2 * k]; b += counts[2 * k + 1];
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor((long long)a, off, 64);
+        b += __shfl_xor((long long)b, off, 64);
+    }
+    if (lane == 0) { sc[0][wave] = a; sc[1][wave] = b; }
+    sl_block_reduce_key<false>(ls_v, ls_i, sv, si);
+    __syncthreads();
+    sl_block_reduce_key<false>(mx_v, mx_i, sv, si);
+    if (threadIdx.x == 0) {
+        result->last_safe.vbits = ls_v; result->last_safe.index = ls_i;
+        result->max_key.vbits = mx_v; result->max_key.index = mx_i;
+        int64_t ta = 0, tb = 0;
+        for (int w = 0; w < SL_BLOCK / 64; ++w) { ta += sc[0][w]; tb += sc[1][w]; }
+        result->count_below = ta; result->count_safe = tb;
+    }
+}
+
+extern "C" int sl_lyap_finalize(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values,
+                                const uint64_t* d_init_bits, const uint64_t* d_prev_bits,
+                                sl_key key_star, sl_key key_keep, uint64_t* d_safe_bits,
+                                sl_sweep_result* d_result) {
+    if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_lyap_finalize: NULL context");
+    if (lo < 0 || hi < lo || (lo & 63) || !d_values || !d_safe_bits || !d_result)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_lyap_finalize: bad argument");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int blocks = (hi == lo) ? 0 : sl_grid_blocks(hi - lo);
+    if (blocks) {
+        hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream, lo, hi,
+                           d_values, d_init_bits, d_prev_bits, key_star, key_keep, d_safe_bits,
+                           ctx->d_partials, ctx->d_partial_counts);
+        SL_HIP_CHECK(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_reduce_finalize, dim3(1), dim3(SL_BLOCK), 0, ctx->stream, ctx->d_partials,
+                       ctx->d_partial_counts, blocks, d_result);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+// =============================================================================================
+// radix-select histogram pass over (V, index) keys
+// =============================================================================================
+__global__ __launch_bounds__(SL_BLOCK) void k_select_pass(int64_t lo, int64_t hi,
+                                                          const double* __restrict__ values,
+                                                          int which, int byte, uint64_t prefix,
+                                                          uint64_t vbits_equal,
+                                                          uint64_t* __restrict__ hist) {
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = byte * 8;
+    const uint64_t himask = (byte == 7) ? 0ull : (~0ull << (shift + 8));
+    for (int64_t idx = lo + (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; idx < hi;
+         idx += (int64_t)gridDim.x * SL_BLOCK) {
+        const uint64_t vb = sl_vbits(values[idx - lo]);
+        uint64_t key;
+        bool take;
+        if (which == 0) { key = vb; take = true; }
+        else { key = (uint64_t)idx; take = (vb == vbits_equal); }
+        take = take && ((key & himask) == (prefix & himask));
+        if (take) atomicAdd(&lh[(key >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    const unsigned int c = lh[threadIdx.x];
+    if (c) atomicAdd((unsigned long long*)&hist[threadIdx.x], (unsigned long long)c);
+}
+
+extern "C" int sl_select_pass(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values,
+                              int which, int byte, uint64_t prefix, uint64_t vbits_equal,
+                              uint64_t* d_hist) {
+    if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_select_pass: NULL context");
+    if (lo < 0 || hi < lo || !d_values || !d_hist || byte < 0 || byte > 7 || which < 0 || which > 1)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_select_pass: bad argument");
+    if (hi == lo) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // a block must not overflow its 32-bit local counters: <= 2^31 cells per block
+    hipLaunchKernelGGL(k_select_pass, dim3(sl_grid_blocks(hi - lo)), dim3(SL_BLOCK), 0,
+                       ctx->stream, lo, hi, d_values, which, byte, prefix, vbits_equal, d_hist);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+// =============================================================================================
+// bit mask <-> bool[N] byte mask
+// =============================================================================================
+__global__ __launch_bounds__(SL_BLOCK) void k_bits_to_bytes(int64_t n, const uint64_t* __restrict__ bits,
+                                                            uint8_t* __restrict__ bytes) {
+    // one thread per 8 cells: 8-byte store
+    const int64_t ngroups = (n + 7) >> 3;
+    for (int64_t g = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; g < ngroups;
+         g += (int64_t)gridDim.x * SL_BLOCK) {
+        const uint64_t word = bits[g >> 3];
+        const unsigned int b = (unsigned int)((word >> ((g & 7) * 8)) & 0xff);
+        // spread 8 bits into 8 bytes
+        uint64_t x = b;
+        x = (x | (x << 28)) & 0x0000000f0000000full;
+        x = (x | (x << 14)) & 0x0003000300030003ull;
+        x = (x | (x << 7)) & 0x0101010101010101ull;
+        if (g * 8 + 8 <= n) {
+            *reinterpret_cast<uint64_t*>(bytes + g * 8) = x;
+        } else {
+            for (int k = 0; g * 8 + k < n; ++k) bytes[g * 8 + k] = (uint8_t)((x >> (8 * k)) & 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(SL_BLOCK) void k_bytes_to_bits(int64_t n, const uint8_t* __restrict__ bytes,
+                                                            uint64_t* __restrict__ bits) {
+    for (int64_t base = (int64_t)blockIdx.x * SL_BLOCK; base < n; base += (int64_t)gridDim.x * SL_BLOCK) {
+        const int64_t idx = base + threadIdx.x;
+        const bool on = (idx < n) && bytes[idx] != 0;
+        const uint64_t word = __ballot(on);
+        const int64_t wbase = base + (threadIdx.x & ~63);
+        if ((threadIdx.x & 63) == 0 && wbase < n) bits[wbase >> 6] = word;
+    }
+}
+
+extern "C" int sl_bits_to_bytes(sl_ctx* ctx, int64_t n, const uint64_t* d_bits, uint8_t* d_bytes) {
+    if (!ctx || n < 0 || !d_bits || !d_bytes)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bits_to_bytes: bad argument");
+    if (n == 0) return SL_OK;
+    if (((uintptr_t)d_bytes) & 7)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bits_to_bytes: d_bytes must be 8-byte aligned");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_bits_to_bytes, dim3(sl_grid_blocks((n + 7) / 8)), dim3(SL_BLOCK), 0,
+                       ctx->stream, n, d_bits, d_bytes);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+extern "C" int sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uint64_t* d_bits) {
+    if (!ctx || n < 0 || !d_bits || !d_bytes)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_bytes_to_bits: bad argument");
+    if (n == 0) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_bytes_to_bits, dim3(sl_grid_blocks(n)), dim3(SL_BLOCK), 0, ctx->stream, n,
+                       d_bytes, d_bits);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}

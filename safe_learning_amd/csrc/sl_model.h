@@ -1,0 +1,511 @@
+// sl_model.h - per-cell arithmetic of the Lyapunov sweep, shared by every kernel.
+//
+// Everything here is plain C++ on scalars (no HIP builtins), marked __host__ __device__ so
+// that tests/hostsim can compile the very same functions with g++ and check them against
+// the oracle without a GPU.  Arithmetic order is the canonical one defined by the oracle
+// (oracle/np_functions.py: ordered_matmul / ordered_rowsum): left to right, one rounding per
+// multiply and per add.  The translation unit is compiled with -ffp-contract=off, so no
+// multiply-add below is ever fused; where a fused operation is wanted it is written fma().
+//
+// Reference formulas (upstream checkout):
+//   state from index      safe_learning/functions.py:728-731
+//   policy / linear dyn.  safe_learning/functions.py:1567-1583, saturation :349-354
+//   quadratic V           safe_learning/functions.py:1534-1539
+//   pendulum / cart-pole  examples/utilities.py:242-289 / 387-437
+//   threshold             safe_learning/lyapunov.py:265-288
+//   decrease + bound      safe_learning/lyapunov.py:324-376
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+#include "sl_hip.h"
+
+#if defined(__HIPCC__)
+#define SL_HD __host__ __device__ __forceinline__
+#else
+#define SL_HD inline
+#endif
+
+#define SL_D SL_MAX_STATE_DIM
+#define SL_M SL_MAX_ACTION_DIM
+#define SL_P SL_MAX_INPUT_DIM
+
+// Device-side view of one auxiliary grid with a vertex table (Triangulation).
+struct SlTri {
+    sl_grid_desc grid;
+    int32_t nsimplex, project, ncols, set;
+    int32_t simplices[SL_MAX_SIMPLICES][SL_D + 1];   // corner codes, bit k = dimension k
+    double  hyper[SL_MAX_SIMPLICES][SL_D][SL_D];
+    int64_t stride[SL_D];                            // flat-index stride per dimension
+    const double* points;                            // concatenated linspace tables (device)
+    int32_t points_off[SL_D];
+    const double* table;                             // [nindex][ncols] (device)
+};
+
+// Device-side view of the LyapunovNetwork.
+struct SlNet {
+    int32_t nlayers, set;
+    int32_t dims[SL_MAX_NN_LAYERS + 1];
+    int32_t act[SL_MAX_NN_LAYERS];
+    int32_t koff[SL_MAX_NN_LAYERS];                  // offset of layer kernel in `kernels`
+    const double* kernels;                           // device
+};
+
+// ---------------------------------------------------------------------------------------------
+// grid addressing
+// ---------------------------------------------------------------------------------------------
+struct SlGridFast {                 // derived from sl_grid_desc at sl_model_set time
+    int32_t d, all_pow2;
+    int32_t shift[SL_D];            // log2(num_points[k]) when all_pow2
+    uint32_t num32[SL_D];
+    int64_t nindex;
+};
+
+SL_HD void sl_unravel(const sl_grid_desc& g, const SlGridFast& f, int d, int64_t idx, int64_t* ijk) {
+    if (f.all_pow2) {
+        uint64_t r = (uint64_t)idx;
+#pragma unroll
+        for (int k = SL_D - 1; k >= 0; --k) {
+            if (k < d) {
+                ijk[k] = (int64_t)(r & ((1ull << f.shift[k]) - 1ull));
+                r >>= f.shift[k];
+            }
+        }
+    } else if (f.nindex <= 0xffffffffll) {
+        uint32_t r = (uint32_t)idx;
+#pragma unroll
+        for (int k = SL_D - 1; k >= 0; --k) {
+            if (k < d) {
+                uint32_t q = r / f.num32[k];
+                ijk[k] = (int64_t)(r - q * f.num32[k]);
+                r = q;
+            }
+        }
+    } else {
+        int64_t r = idx;
+#pragma unroll
+        for (int k = SL_D - 1; k >= 0; --k) {
+            if (k < d) {
+                int64_t q = r / g.num_points[k];
+                ijk[k] = r - q * g.num_points[k];
+                r = q;
+            }
+        }
+    }
+}
+
+// functions.py:731: ijk * unit_maxes + offset (multiply, then add)
+SL_HD void sl_index_to_state(const sl_grid_desc& g, const SlGridFast& f, int d, int64_t idx,
+                              double* x) {
+    int64_t ijk[SL_D];
+    sl_unravel(g, f, d, idx, ijk);
+#pragma unroll
+    for (int k = 0; k < SL_D; ++k) {
+        if (k < d) {
+            double t = (double)ijk[k] * g.unit_maxes[k];
+            x[k] = t + g.offset[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small ordered linear algebra: out[j] = ((z0*M[j][0] + z1*M[j][1]) + ...) rows = outputs
+// ---------------------------------------------------------------------------------------------
+template <int ROWS, int COLS>
+SL_HD void sl_rows_dot(const double (&mat)[ROWS][COLS], int nrows, int ncols, const double* z,
+                       double* out) {
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        if (j < nrows) {
+            double acc = z[0] * mat[j][0];
+#pragma unroll
+            for (int i = 1; i < COLS; ++i) {
+                if (i < ncols) {
+                    double t = z[i] * mat[j][i];
+                    acc = acc + t;
+                }
+            }
+            out[j] = acc;
+        }
+    }
+}
+
+// functions.py:1537-1539: linear_form = z P ; sum_j linear_form_j * z_j
+SL_HD double sl_quadratic(const sl_value_desc& v, int n, const double* z) {
+    double total = 0.0;
+#pragma unroll
+    for (int j = 0; j < SL_P; ++j) {
+        if (j < n) {
+            double lin = z[0] * v.matrix[0][j];
+#pragma unroll
+            for (int i = 1; i < SL_P; ++i) {
+                if (i < n) {
+                    double t = z[i] * v.matrix[i][j];
+                    lin = lin + t;
+                }
+            }
+            double q = lin * z[j];
+            total = (j == 0) ? q : (total + q);
+        }
+    }
+    return v.negate ? (total * -1.0) : total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// policy
+// ---------------------------------------------------------------------------------------------
+SL_HD void sl_saturate(const sl_policy_desc& p, int m, double* u) {
+    if (p.saturate) {
+#pragma unroll
+        for (int a = 0; a < SL_M; ++a) {
+            if (a < m) {
+                double t = u[a];
+                t = (t > p.lower[a]) ? t : p.lower[a];      // tf.maximum(res, lower)
+                t = (t < p.upper[a]) ? t : p.upper[a];      // tf.minimum(.., upper)
+                u[a] = t;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// analytic dynamics
+// ---------------------------------------------------------------------------------------------
+// coef: [0]=dt/10 [1]=g/l [2]=inertia [3]=friction/inertia [4]=(friction>0)
+SL_HD void sl_pendulum(const sl_dynamics_desc& f, const double* x, const double* u, double* nxt) {
+    double th = x[0], om = x[1], act = u[0];
+    if (f.normalize) { th = th * f.tx[0]; om = om * f.tx[1]; act = act * f.tu[0]; }
+    const double dt = f.coef[0];
+    for (int it = 0; it < 10; ++it) {
+        double acc = f.coef[1] * sin(th);
+        double t2 = act / f.coef[2];
+        acc = acc + t2;
+        if (f.coef[4] != 0.0) {
+            double t3 = f.coef[3] * om;
+            acc = acc - t3;
+        }
+        double dth = dt * om;
+        double dom = dt * acc;
+        th = th + dth;
+        om = om + dom;
+    }
+    if (f.normalize) { th = th * f.tx_inv[0]; om = om * f.tx_inv[1]; }
+    nxt[0] = th; nxt[1] = om;
+}
+
+// coef: [0]=dt/10 [1]=m [2]=M [3]=L [4]=b [5]=m*L [6]=((0.5*m)*g)*L [7]=(0.5*m)*L
+//       [8]=b*(m+M) [9]=(m+M)*g
+SL_HD void sl_cartpole(const sl_dynamics_desc& f, const double* x, const double* u, double* nxt) {
+    double px = x[0], th = x[1], v = x[2], om = x[3], act = u[0];
+    if (f.normalize) {
+        px = px * f.tx[0]; th = th * f.tx[1]; v = v * f.tx[2]; om = om * f.tx[3];
+        act = act * f.tu[0];
+    }
+    const double dt = f.coef[0], m = f.coef[1], M = f.coef[2], L = f.coef[3], b = f.coef[4];
+    for (int it = 0; it < 10; ++it) {
+        double s = sin(th), c = cos(th), s2 = sin(2.0 * th);
+        double om2 = om * om;
+        double det = m * (s * s);
+        det = M + det;
+        det = L * det;
+        double t1 = (f.coef[5] * om2) * s;
+        double t2 = (b * om) * c;
+        double t3 = f.coef[6] * s2;
+        double vd = act - t1;
+        vd = vd - t2;
+        vd = vd + t3;
+        vd = vd * L;
+        vd = vd / det;
+        double w1 = act * c;
+        double w2 = (f.coef[7] * om2) * s2;
+        double w3 = (f.coef[8] * om) / f.coef[5];
+        double w4 = f.coef[9] * s;
+        double wd = w1 - w2;
+        wd = wd - w3;
+        wd = wd + w4;
+        wd = wd / det;
+        double dpx = dt * v, dth = dt * om, dv = dt * vd, dom = dt * wd;
+        px = px + dpx; th = th + dth; v = v + dv; om = om + dom;
+    }
+    if (f.normalize) {
+        px = px * f.tx_inv[0]; th = th * f.tx_inv[1]; v = v * f.tx_inv[2]; om = om * f.tx_inv[3];
+    }
+    nxt[0] = px; nxt[1] = th; nxt[2] = v; nxt[3] = om;
+}
+
+// ---------------------------------------------------------------------------------------------
+// piecewise-linear interpolation on an auxiliary grid (functions.py:1103-1202, 1473-1499)
+// ---------------------------------------------------------------------------------------------
+// numpy.digitize(x, points) - 1 clipped to [0, n-2] (functions.py:771-773)
+SL_HD int64_t sl_rectangle_1d(const double* pts, int64_t n, double offset, double unit, double x) {
+    double g = (x - offset) / unit;
+    int64_t i;
+    if (!(g > 0.0)) i = 0; else if (g >= (double)(n - 1)) i = n - 1; else i = (int64_t)g;
+    // digitize: number of points <= x ; fix the guess with the actual linspace values
+    while (i + 1 < n && pts[i + 1] <= x) ++i;
+    while (i > 0 && pts[i] > x) --i;
+    int64_t cnt = (pts[i] <= x) ? (i + 1) : 0;    // bins[cnt-1] <= x < bins[cnt]
+    if (x != x) cnt = n;                           // NaN sorts last in digitize
+    int64_t r = cnt - 1;
+    if (r < 0) r = 0;
+    if (r > n - 2) r = n - 2;
+    return r;
+}
+
+SL_HD double sl_fmod_pos(double a, double b) {     // numpy `%` for a >= 0, b > 0
+    double r = fmod(a, b);
+    return r;
+}
+
+// Value (column `col`) of the interpolant at x; also returns the simplex gradient if grad != 0.
+SL_HD double sl_tri_eval(const SlTri& t, const double* x, int col, double* grad) {
+    const int d = t.grid.d;
+    const double eps2 = 2.0 * 2.220446049250313e-16;
+    int64_t corner = 0;
+    int64_t rk[SL_D];
+    double unitc[SL_D], xc[SL_D];
+#pragma unroll
+    for (int k = 0; k < SL_D; ++k) {
+        if (k < d) {
+            const double* pts = t.points + t.points_off[k];
+            int64_t r = sl_rectangle_1d(pts, t.grid.num_points[k], t.grid.offset[k],
+                                        t.grid.unit_maxes[k], x[k]);
+            rk[k] = r;
+            corner += r * t.stride[k];
+            // _center_states(clip=True): functions.py:705-712
+            double c = x[k] - t.grid.offset[k];
+            double lo = 0.0 + eps2, hi = (t.grid.upper[k] - t.grid.offset[k]) - eps2;
+            c = (c < lo) ? lo : c;
+            c = (c > hi) ? hi : c;
+            unitc[k] = sl_fmod_pos(c, t.grid.unit_maxes[k]);       // :1123
+            double p = x[k];
+            if (t.project) {                                       // :1190-1191 / :1479-1485
+                p = (p > t.grid.offset[k]) ? p : t.grid.offset[k];
+                p = (p < t.grid.upper[k]) ? p : t.grid.upper[k];
+            }
+            xc[k] = p;
+        }
+    }
+    // point location inside the unit cell: the simplex whose smallest barycentric weight is largest
+    int best = 0;
+    double best_min = -1e300;
+    for (int s = 0; s < t.nsimplex; ++s) {
+        double w0 = 1.0, wmin = 1e300;
+        double org[SL_D];
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k)
+            if (k < d) org[k] = ((t.simplices[s][0] >> k) & 1) ? t.grid.unit_maxes[k] : 0.0;
+#pragma unroll
+        for (int j = 0; j < SL_D; ++j) {
+            if (j < d) {
+                double w = 0.0;
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k)
+                    if (k < d) w += (unitc[k] - org[k]) * t.hyper[s][k][j];
+                w0 -= w;
+                wmin = (w < wmin) ? w : wmin;
+            }
+        }
+        wmin = (w0 < wmin) ? w0 : wmin;
+        if (wmin > best_min) { best_min = wmin; best = s; }
+    }
+    // weights relative to the simplex origin in physical coordinates (:1180-1200)
+    int64_t v0 = corner;
+    double org[SL_D];
+    {
+        // origin = index_to_state(simplices[:,0]) = (ijk)*unit + offset
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) {
+            if (k < d) {
+                int64_t ik = rk[k];
+                int bit = (t.simplices[best][0] >> k) & 1;
+                v0 += bit * t.stride[k];
+                double tt = (double)(ik + bit) * t.grid.unit_maxes[k];
+                org[k] = tt + t.grid.offset[k];
+            }
+        }
+    }
+    double w1[SL_D], wsum = 0.0;
+#pragma unroll
+    for (int j = 0; j < SL_D; ++j) {
+        if (j < d) {
+            double w = 0.0;
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k)
+                if (k < d) w += (xc[k] - org[k]) * t.hyper[best][k][j];
+            w1[j] = w;
+            wsum += w;
+        }
+    }
+    double p0 = t.table[v0 * t.ncols + col];
+    double value = (1.0 - wsum) * p0;
+    if (grad) {
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) if (k < d) grad[k] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < SL_D; ++j) {
+        if (j < d) {
+            int64_t vj = corner;
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k)
+                if (k < d) vj += ((t.simplices[best][j + 1] >> k) & 1) * t.stride[k];
+            double pj = t.table[vj * t.ncols + col];
+            value += w1[j] * pj;
+            if (grad) {
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k)
+                    if (k < d) grad[k] += t.hyper[best][k][j] * (pj - p0);
+            }
+        }
+    }
+    return value;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LyapunovNetwork forward (+ input gradient)   examples/utilities.py:85-104
+// ---------------------------------------------------------------------------------------------
+#define SL_NN_MAXW 64
+SL_HD double sl_act(int a, double x) { return a == 1 ? tanh(x) : (a == 2 ? (x > 0.0 ? x : 0.0) : x); }
+SL_HD double sl_dact(int a, double pre, double post) {
+    return a == 1 ? (1.0 - post * post) : (a == 2 ? (pre > 0.0 ? 1.0 : 0.0) : 1.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the model as the kernels see it
+// ---------------------------------------------------------------------------------------------
+struct SlGpHeadDev {
+    int32_t n, n_pad, p, dout, col0, nslab2, reserved0, reserved1;
+    double  variance;
+    double  inv_ls[SL_P];
+    const double* xs;        // [p][n_pad], inputs already divided by the lengthscales
+    const double* mpack;     // MFMA A-fragments of Linv, see sl_gp.hip
+    const double* alpha;     // [n_pad][dout]  alpha' = Linv^T alpha
+};
+
+struct SlGpDev {
+    int32_t nheads, reserved;
+    double  beta;
+    SlGpHeadDev head[SL_MAX_GP_HEADS];
+};
+
+struct SlDevModel {
+    sl_model_desc m;
+    SlGridFast    gf;
+    int32_t       in_dim;      // d + m
+    int32_t       uncertain;   // dynamics returns (mean, error)
+};
+
+// Dimensions of one kernel instantiation.  Kernels are compiled for fixed (state, action)
+// dimensions (DT, MT > 0) so that every `k < d` below folds at compile time, plus one generic
+// variant (DT = MT = 0) that reads them from the model.
+struct SlDims { int d, m, p; };
+template <int DT, int MT>
+SL_HD SlDims sl_dims(const SlDevModel& M) {
+    SlDims r;
+    r.d = DT > 0 ? DT : M.m.grid.d;
+    r.m = MT > 0 ? MT : M.m.policy.m;
+    r.p = r.d + r.m;
+    return r;
+}
+
+// L_v(z): writes lv_cols values
+SL_HD void sl_lv(const SlDevModel& M, int d, const double* z, double* lv) {
+    const sl_lipschitz_desc& l = M.m.lipschitz;
+    if (l.lv_kind == SL_LIP_CONST) { lv[0] = l.lv_const; return; }
+    double t[SL_D];
+    sl_rows_dot<SL_D, SL_D>(l.lv_matrix, d, d, z, t);
+    if (l.lv_kind == SL_LIP_ABS_LINEAR) {
+#pragma unroll
+        for (int j = 0; j < SL_D; ++j) if (j < d) lv[j] = fabs(t[j]);
+    } else {   // SL_LIP_NORM_LINEAR
+        double acc = fabs(t[0]);
+#pragma unroll
+        for (int j = 1; j < SL_D; ++j) if (j < d) acc = acc + fabs(t[j]);
+        lv[0] = acc;
+    }
+}
+
+// lyapunov.py:282-288
+SL_HD double sl_threshold(const SlDevModel& M, int d, const double* lv_x, double tau) {
+    const sl_lipschitz_desc& l = M.m.lipschitz;
+    double l1 = lv_x[0];
+    if (l.lv_kind != SL_LIP_CONST && l.lv_kind != SL_LIP_NORM_LINEAR && d > 1) {
+        l1 = fabs(lv_x[0]);
+#pragma unroll
+        for (int j = 1; j < SL_D; ++j) if (j < d) l1 = l1 + fabs(lv_x[j]);
+    }
+    double t = (-l1) * (1.0 + l.lf_const);
+    return t * tau;
+}
+
+// lyapunov.py:344-352, 376: (V(next) - V(x)) + sum_j lv_j(next) err_j
+SL_HD double sl_decrease(const SlDevModel& M, int d, double v_x, double v_next,
+                         const double* lv_next, const double* err) {
+    double dv = v_next - v_x;
+    double bound = 0.0;
+    if (M.uncertain) {
+        const sl_lipschitz_desc& l = M.m.lipschitz;
+        const bool bcast = (l.lv_kind == SL_LIP_CONST) || (l.lv_kind == SL_LIP_NORM_LINEAR) || d == 1;
+        bound = lv_next[0] * err[0];
+#pragma unroll
+        for (int j = 1; j < SL_D; ++j) {
+            if (j < d) {
+                double t = (bcast ? lv_next[0] : lv_next[j]) * err[j];
+                bound = bound + t;
+            }
+        }
+    }
+    return dv + bound;
+}
+
+// policy(x) for the closed-form kinds (TABLE / TRI handled by the caller)
+SL_HD void sl_policy_closed_form(const SlDevModel& M, SlDims n, const double* x, double* u) {
+    const sl_policy_desc& p = M.m.policy;
+    if (p.kind == SL_POLICY_LINEAR) {
+        sl_rows_dot<SL_M, SL_D>(p.matrix, n.m, n.d, x, u);
+    } else {
+#pragma unroll
+        for (int a = 0; a < SL_M; ++a) if (a < n.m) u[a] = p.constant[a];
+    }
+    sl_saturate(p, n.m, u);
+}
+
+// z[d + a] = u[a] without run-time register indexing
+SL_HD void sl_append_action(SlDims n, const double* u, double* z) {
+#pragma unroll
+    for (int q = 0; q < SL_P; ++q) {
+#pragma unroll
+        for (int a = 0; a < SL_M; ++a)
+            if (a < n.m && q == n.d + a) z[q] = u[a];
+    }
+}
+
+// deterministic dynamics f(z), z = [x, u] (an SL_P-sized array)
+SL_HD void sl_dynamics_det(const SlDevModel& M, SlDims n, const double* z, double* nxt) {
+    const sl_dynamics_desc& f = M.m.dynamics;
+    double u0 = 0.0;
+#pragma unroll
+    for (int q = 0; q < SL_P; ++q) if (q == n.d) u0 = z[q];
+    if (f.kind == SL_DYN_PENDULUM) { sl_pendulum(f, z, &u0, nxt); return; }
+    if (f.kind == SL_DYN_CARTPOLE) { sl_cartpole(f, z, &u0, nxt); return; }
+    sl_rows_dot<SL_D, SL_P>(f.matrix, n.d, n.p, z, nxt);
+}
+
+// (V, index) key: ascending V, -0 == +0, NaN last (numpy sort order), ties by index
+SL_HD uint64_t sl_vbits(double v) {
+    if (v != v) return 0xffffffffffffffffull;
+    if (v == 0.0) v = 0.0;
+    union { double d; uint64_t u; } c;
+    c.d = v;
+    return (c.u & 0x8000000000000000ull) ? ~c.u : (c.u | 0x8000000000000000ull);
+}
+SL_HD double sl_vbits_to_double(uint64_t b) {
+    union { double d; uint64_t u; } c;
+    if (b == 0xffffffffffffffffull) { c.u = 0x7ff8000000000000ull; return c.d; }
+    c.u = (b & 0x8000000000000000ull) ? (b & 0x7fffffffffffffffull) : ~b;
+    return c.d;
+}
+SL_HD bool sl_key_less(uint64_t va, int64_t ia, uint64_t vb, int64_t ib) {
+    return (va < vb) || (va == vb && ia < ib);
+}

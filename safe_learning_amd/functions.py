@@ -1,0 +1,609 @@
+"""Function objects of the Lyapunov sweep as declarative specs for the HIP engine.
+
+The reference composes TensorFlow callables (``safe_learning/functions.py``); a GPU kernel
+cannot call back into Python, so here every class is a small parameter record with the
+reference's constructor signature that knows how to write itself into the C-ABI model
+description (``include/sl_hip.h``).  All arithmetic happens in the HIP kernels; this module
+only prepares host-side metadata (grids, Cholesky factors, unit-cell triangulations), which
+is also host-side NumPy/SciPy work in the reference.
+
+Reference classes mirrored (constructor arguments keep their names):
+``GridWorld`` (functions.py:579-817), ``QuadraticFunction`` (:1513-1543), ``LinearSystem``
+(:1546-1583), ``Saturation`` (:310-354), ``GPRCached`` (:357-458), ``GaussianProcess``
+(:461-546), ``FunctionStack`` (:254-307), ``Triangulation`` (:981-1510) and, from
+``examples/utilities.py``, ``InvertedPendulum`` (:144-289), ``CartPole`` (:292-437),
+``LyapunovNetwork`` (:48-104).
+"""
+
+from itertools import product as _cartesian
+
+import numpy as np
+import scipy.linalg
+from scipy import signal, spatial
+
+from . import _hip
+from .configuration import config
+
+__all__ = ['GridWorld', 'DimensionError', 'DeterministicFunction', 'UncertainFunction',
+           'QuadraticFunction', 'LinearSystem', 'Saturation', 'AbsFunction', 'Norm1Function',
+           'AbsGradient', 'ConstantFunction', 'RBF', 'GPRCached', 'GaussianProcess',
+           'FunctionStack', 'Triangulation', 'InvertedPendulum', 'CartPole', 'LyapunovNetwork']
+
+
+class DimensionError(Exception):
+    """Same role as ``safe_learning/functions.py:575-576``."""
+
+
+# ----------------------------------------------------------------------------------------------
+# grid
+# ----------------------------------------------------------------------------------------------
+
+class GridWorld(object):
+    """Regular grid over a hyper-rectangle (reference: ``functions.py:591-620``).
+
+    ``limits`` is ``[(lo, hi), ...]``, ``num_points`` an int or one int per dimension.  Flat
+    indices are C-order (last dimension fastest); state ``k`` of index ``ijk`` is
+    ``ijk[k] * unit_maxes[k] + offset[k]`` - the addressing contract of the HIP kernels.
+    """
+
+    def __init__(self, limits, num_points):
+        dtype = config.np_dtype
+        self.limits = np.atleast_2d(limits).astype(dtype)
+        self.ndim = len(self.limits)
+        self.num_points = np.broadcast_to(num_points, self.ndim).astype(np.int64)
+        if np.any(self.num_points < 2):
+            raise DimensionError('There must be at least 2 points in each dimension.')
+        lower, upper = self.limits[:, 0], self.limits[:, 1]
+        self.offset = lower
+        self.unit_maxes = ((upper - lower) / (self.num_points - 1)).astype(dtype)
+        self.offset_limits = np.stack((np.zeros_like(lower), upper - lower), axis=1)
+        self.discrete_points = [np.linspace(lo, hi, n, dtype=dtype)
+                                for (lo, hi), n in zip(self.limits, self.num_points)]
+        self.nrectangles = int(np.prod(self.num_points - 1))
+        self.nindex = int(np.prod(self.num_points))
+        self._all_points = None
+
+    def __len__(self):
+        return self.nindex
+
+    @property
+    def all_points(self):
+        """``[nindex, ndim]`` array of every grid point (``functions.py:622-638``).
+
+        Only for small grids / plotting: the kernels generate states from indices instead."""
+        if self._all_points is None:
+            self._all_points = self.index_to_state(np.arange(self.nindex))
+        return self._all_points
+
+    def sample_continuous(self, num_samples):
+        """Uniform samples from the continuous domain (``functions.py:644-659``)."""
+        rand = np.random.uniform(0, 1, size=(num_samples, self.ndim))
+        return rand * np.diff(self.limits, axis=1).T + self.offset
+
+    def sample_discrete(self, num_samples, replace=False):
+        """Uniform samples from the grid points (``functions.py:661-677``)."""
+        idx = np.random.choice(self.nindex, size=num_samples, replace=replace)
+        return self.index_to_state(idx)
+
+    def _check_dimensions(self, states):
+        if not states.shape[1] == self.ndim:
+            raise DimensionError('the input argument has the wrong dimensions.')
+
+    def _center_states(self, states, clip=True):
+        """States relative to the lower corner, optionally clipped 2 eps inside
+        (``functions.py:691-712``)."""
+        eps = np.finfo(config.np_dtype).eps
+        states = np.atleast_2d(states).astype(config.np_dtype) - self.offset[None, :]
+        if clip:
+            np.clip(states, self.offset_limits[:, 0] + 2 * eps,
+                    self.offset_limits[:, 1] - 2 * eps, out=states)
+        return states
+
+    def index_to_state(self, indices):
+        """Flat indices -> states (``functions.py:714-731``)."""
+        ijk = np.stack(np.unravel_index(np.atleast_1d(indices), self.num_points), axis=1)
+        return ijk.astype(config.np_dtype) * self.unit_maxes + self.offset
+
+    def state_to_index(self, states):
+        """Nearest grid point of each state, clipped to the domain (``functions.py:733-752``)."""
+        states = np.atleast_2d(states)
+        self._check_dimensions(states)
+        clipped = np.clip(states, self.limits[:, 0], self.limits[:, 1])
+        ijk = np.rint((clipped - self.offset) * (1. / self.unit_maxes)).astype(np.int32)
+        return np.ravel_multi_index(ijk.T, self.num_points)
+
+    def state_to_rectangle(self, states):
+        """Index of the grid cell containing each state (``functions.py:754-776``)."""
+        cells = []
+        for k in range(self.ndim):
+            idx = np.digitize(states[:, k], self.discrete_points[k]) - 1
+            cells.append(np.clip(idx, 0, self.num_points[k] - 2))
+        return np.ravel_multi_index(cells, self.num_points - 1)
+
+    def rectangle_to_state(self, rectangles):
+        """Lower-left corner state of each cell (``functions.py:778-798``)."""
+        ijk = np.stack(np.unravel_index(np.atleast_1d(rectangles), self.num_points - 1), axis=1)
+        return ijk.astype(config.np_dtype) * self.unit_maxes + self.offset
+
+    def rectangle_corner_index(self, rectangles):
+        """Flat grid index of each cell's lower-left corner (``functions.py:800-817``)."""
+        ijk = np.unravel_index(rectangles, self.num_points - 1)
+        return np.ravel_multi_index(np.atleast_2d(ijk), self.num_points)
+
+    # ---- C-ABI view ------------------------------------------------------------------------
+    def _desc(self):
+        if self.ndim > _hip.MAX_STATE_DIM:
+            raise DimensionError('the HIP engine supports at most %d state dimensions'
+                                 % _hip.MAX_STATE_DIM)
+        g = _hip.GridDesc()
+        g.d = self.ndim
+        for k in range(self.ndim):
+            g.num_points[k] = int(self.num_points[k])
+            g.offset[k] = float(self.offset[k])
+            g.unit_maxes[k] = float(self.unit_maxes[k])
+            g.upper[k] = float(self.limits[k, 1])
+        return g
+
+
+# ----------------------------------------------------------------------------------------------
+# spec base classes
+# ----------------------------------------------------------------------------------------------
+
+class Function(object):
+    """Base of all specs.  ``-f`` is supported as a sign flag (``functions.py:120-122``)."""
+
+    negate = False
+
+    def __neg__(self):
+        import copy
+        other = copy.copy(self)
+        other.negate = not self.negate
+        return other
+
+    def __call__(self, *points):
+        raise NotImplementedError(
+            '%s is a declarative spec evaluated inside the HIP kernels; evaluate it through '
+            'Lyapunov / PolicyIteration (or their .evaluate helpers).' % type(self).__name__)
+
+
+class DeterministicFunction(Function):
+    """Marker base class (``functions.py:233-238``)."""
+
+
+class UncertainFunction(Function):
+    """Marker base class: evaluation yields ``(mean, error_bound)`` (``functions.py:202-230``)."""
+
+
+def _hstack_matrices(matrices):
+    if isinstance(matrices, np.ndarray):
+        matrices = (matrices,)
+    return np.hstack([np.atleast_2d(m).astype(config.np_dtype) for m in matrices])
+
+
+class QuadraticFunction(DeterministicFunction):
+    """``x P x^T`` (``functions.py:1513-1543``); ``P`` need not be symmetric."""
+
+    def __init__(self, matrix, name='quadratic'):
+        self.matrix = np.atleast_2d(matrix).astype(config.np_dtype)
+        self.ndim = self.matrix.shape[0]
+        self.name = name
+
+    def gradient_function(self):
+        """``LinearSystem`` computing ``x (P + P^T)`` (``functions.py:1541-1543``)."""
+        return LinearSystem((self.matrix + self.matrix.T,))
+
+    def _write_value(self, desc):
+        n = self.ndim
+        if n > _hip.MAX_INPUT_DIM:
+            raise DimensionError('quadratic form too large for the HIP engine')
+        desc.kind = _hip.V_QUADRATIC
+        desc.negate = int(self.negate)
+        for i in range(n):
+            for j in range(n):
+                desc.matrix[i][j] = float(self.matrix[i, j])
+
+
+class LinearSystem(DeterministicFunction):
+    """``[x, u] M^T`` with ``M = hstack(matrices)`` (``functions.py:1546-1583``)."""
+
+    def __init__(self, matrices, name='linear_system'):
+        self.matrix = _hstack_matrices(matrices)
+        self.output_dim, self.input_dim = self.matrix.shape
+        self.name = name
+
+
+class Saturation(DeterministicFunction):
+    """Clamp ``fun`` to ``[lower, upper]`` (``functions.py:310-354``)."""
+
+    def __init__(self, fun, lower, upper, name='saturation'):
+        self.fun, self.lower, self.upper = fun, lower, upper
+        self.input_dim = getattr(fun, 'input_dim', None)
+        self.output_dim = getattr(fun, 'output_dim', None)
+        self.name = name
+
+
+class ConstantFunction(DeterministicFunction):
+    """The same output row for every input (``functions.py:241-251``)."""
+
+    def __init__(self, constant, name='constant_function'):
+        self.constant = np.atleast_1d(np.asarray(constant, dtype=config.np_dtype))
+        self.output_dim = len(self.constant)
+        self.name = name
+
+
+class AbsFunction(DeterministicFunction):
+    """``|fun(x)|`` - replaces ``lambda x: tf.abs(grad(x))`` of the notebooks."""
+
+    def __init__(self, fun):
+        self.fun = fun
+
+
+class Norm1Function(DeterministicFunction):
+    """``||fun(x)||_1`` - replaces ``lambda x: tf.norm(grad(x), ord=1, axis=1, keepdims=True)``."""
+
+    def __init__(self, fun):
+        self.fun = fun
+
+
+class AbsGradient(DeterministicFunction):
+    """``|dV/dx|`` of a table / network value function (``inverted_pendulum.ipynb`` cell 14,
+    ``lyapunov_function_learning.ipynb``: ``tf.gradients``)."""
+
+    def __init__(self, fun):
+        self.fun = fun
+
+
+# ----------------------------------------------------------------------------------------------
+# Gaussian process
+# ----------------------------------------------------------------------------------------------
+
+class RBF(object):
+    """Squared-exponential kernel with the gpflow 0.4.0 ``kernels.RBF`` signature:
+    ``k(x, x') = variance * exp(-0.5 * sum_q ((x_q - x'_q) / lengthscales_q)^2)``."""
+
+    def __init__(self, input_dim, variance=1.0, lengthscales=None, ARD=False):
+        self.input_dim = int(input_dim)
+        self.variance = float(variance)
+        if lengthscales is None:
+            lengthscales = 1.0
+        self.lengthscales = np.broadcast_to(np.asarray(lengthscales, dtype=config.np_dtype),
+                                            (self.input_dim,)).copy()
+        self.ARD = bool(ARD)
+
+    def K(self, X, X2=None):
+        """Gram matrix on the host (training-set side only)."""
+        X = np.asarray(X, dtype=config.np_dtype) / self.lengthscales
+        X2 = X if X2 is None else np.asarray(X2, dtype=config.np_dtype) / self.lengthscales
+        diff = X[:, None, :] - X2[None, :, :]
+        return self.variance * np.exp(-0.5 * np.einsum('ijk,ijk->ij', diff, diff))
+
+
+class GPRCached(object):
+    """GP regression model whose Cholesky data is cached for prediction
+    (``functions.py:357-458``).  ``kern`` is an :class:`RBF`; ``mean_function`` a
+    :class:`LinearSystem` (or ``None`` for zero mean); ``likelihood_variance`` is gpflow's
+    ``likelihood.variance`` (default 1.0, the notebooks overwrite it).  ``scale`` is accepted for
+    signature compatibility; it cancels analytically in ``build_predict`` and is not used."""
+
+    def __init__(self, x, y, kern, mean_function=None, scale=1., name='GPRCached',
+                 likelihood_variance=1.0):
+        self.X = np.atleast_2d(np.asarray(x, dtype=config.np_dtype))
+        self.Y = np.atleast_2d(np.asarray(y, dtype=config.np_dtype))
+        if not isinstance(kern, RBF):
+            raise TypeError('the HIP engine implements the RBF kernel (BASELINE north_star)')
+        if mean_function is not None and not isinstance(mean_function, LinearSystem):
+            raise TypeError('mean_function must be a LinearSystem or None')
+        self.kern = kern
+        self.mean_function = mean_function
+        self._scale = float(scale)
+        self.likelihood_variance = float(likelihood_variance)
+        self.name = name
+        self.update_cache()
+
+    def update_cache(self):
+        """Cholesky factor, its inverse and ``alpha = L^-1 (Y - m(X))`` (``functions.py:395-415``)."""
+        n = len(self.X)
+        gram = self.kern.K(self.X) + self.likelihood_variance * np.eye(n)
+        self.cholesky = scipy.linalg.cholesky(gram, lower=True)
+        resid = self.Y.copy()
+        if self.mean_function is not None:
+            resid = resid - self.X.dot(self.mean_function.matrix.T)
+        self.alpha = scipy.linalg.solve_triangular(self.cholesky, resid, lower=True)
+        self.cholesky_inverse = scipy.linalg.solve_triangular(self.cholesky, np.eye(n), lower=True)
+        self.cholesky_inverse = np.tril(self.cholesky_inverse)
+        self._version = getattr(self, '_version', 0) + 1
+
+
+class GaussianProcess(UncertainFunction):
+    """``(mean, beta * sqrt(var))`` of a GP model (``functions.py:461-546``)."""
+
+    def __init__(self, gaussian_process, beta=2., name='gaussian_process'):
+        self.gaussian_process = gaussian_process
+        self.beta = float(beta)
+        self.input_dim = gaussian_process.X.shape[1]
+        self.output_dim = gaussian_process.Y.shape[1]
+        self.n_dim = self.input_dim
+        self.name = name
+
+    @property
+    def X(self):
+        return self.gaussian_process.X
+
+    @property
+    def Y(self):
+        return self.gaussian_process.Y
+
+    def add_data_point(self, x, y):
+        """Append observations and rebuild the cache (``functions.py:525-546``)."""
+        gp = self.gaussian_process
+        gp.X = np.vstack((gp.X, np.atleast_2d(x)))
+        gp.Y = np.vstack((gp.Y, np.atleast_2d(y)))
+        gp.update_cache()
+
+
+class FunctionStack(UncertainFunction):
+    """One uncertain function per output column (``functions.py:254-307``)."""
+
+    def __init__(self, functions, name='function_stack'):
+        self.functions = list(functions)
+        self.num_fun = len(self.functions)
+        self.input_dim = self.functions[0].input_dim
+        self.output_dim = sum(fun.output_dim for fun in self.functions)
+        self.name = name
+
+    def add_data_point(self, x, y):
+        for fun, yi in zip(self.functions, np.asarray(y).squeeze()):
+            fun.add_data_point(x, yi)
+
+
+def _gp_heads(dynamics):
+    """Flatten a GaussianProcess / FunctionStack into ``[(model, beta, col0)]``."""
+    funs = dynamics.functions if isinstance(dynamics, FunctionStack) else [dynamics]
+    heads, col = [], 0
+    for fun in funs:
+        if not isinstance(fun, GaussianProcess):
+            raise TypeError('FunctionStack members must be GaussianProcess instances')
+        heads.append((fun.gaussian_process, fun.beta, col))
+        col += fun.output_dim
+    betas = {b for _, b, _ in heads}
+    if len(betas) != 1:
+        raise ValueError('all GP heads must share the same beta')
+    return heads, betas.pop()
+
+
+# ----------------------------------------------------------------------------------------------
+# piecewise-linear table on a grid
+# ----------------------------------------------------------------------------------------------
+
+class Triangulation(DeterministicFunction):
+    """Delaunay interpolation of per-vertex values on a ``GridWorld`` (``functions.py:981-1510``).
+
+    As in the reference only ONE unit cell is triangulated (SciPy/Qhull on the cell's corners,
+    ``functions.py:1019-1022``) and reused for every cell.  ``parameters`` is the ``[nindex, k]``
+    vertex table; the device copy is refreshed whenever it is assigned."""
+
+    def __init__(self, discretization, vertex_values=None, project=False, name='triangulation'):
+        self.discretization = disc = discretization
+        self.input_dim = disc.ndim
+        self.project = bool(project)
+        self.name = name
+        self._parameters = None
+        self._device_table = None
+        self._table_version = 0
+        if vertex_values is not None:
+            self.parameters = vertex_values
+        d = disc.ndim
+        if d == 1:
+            simplices = np.array([[0, 1]], dtype=np.int32)            # functions.py:935-958
+        else:
+            corners = np.array(list(_cartesian(*np.diag(disc.unit_maxes))), dtype=config.np_dtype)
+            tri = spatial.Delaunay(corners)
+            codes = ((corners > 0).astype(np.int64) << np.arange(d)).sum(axis=1)
+            simplices = codes[tri.simplices].astype(np.int32)
+        self.unit_simplex_codes = simplices
+        self.nsimplex_unit = len(simplices)
+        self.nsimplex = self.nsimplex_unit * disc.nrectangles
+        if self.nsimplex_unit > _hip.MAX_SIMPLICES:
+            raise DimensionError('unit cell has %d simplices (engine limit %d)'
+                                 % (self.nsimplex_unit, _hip.MAX_SIMPLICES))
+        bits = (simplices[:, :, None] >> np.arange(d)) & 1           # [s, d+1, d]
+        verts = bits.astype(config.np_dtype) * disc.unit_maxes
+        self.hyperplanes = np.stack([np.linalg.inv(v[1:] - v[:1]) for v in verts])   # :1090-1101
+
+    @property
+    def nindex(self):
+        return self.discretization.nindex
+
+    @property
+    def output_dim(self):
+        return None if self._parameters is None else self._parameters.shape[1]
+
+    @property
+    def parameters(self):
+        return self._parameters
+
+    @parameters.setter
+    def parameters(self, values):
+        self._parameters = np.ascontiguousarray(
+            np.asarray(values, dtype=config.np_dtype).reshape(self.nindex, -1))
+        self._device_table = None
+        self._table_version += 1
+
+    def _device(self, ctx):
+        """Device copy of the vertex table (uploaded lazily)."""
+        import torch
+        if self._device_table is None or self._device_table.device != ctx.torch_device:
+            self._device_table = torch.from_numpy(self._parameters).to(ctx.torch_device)
+        return self._device_table
+
+    def _adopt_device_table(self, tensor):
+        """Make a device tensor the truth (value iteration keeps V on the GPU)."""
+        self._device_table = tensor
+        self._parameters = None
+        self._table_version += 1
+
+    def _host_parameters(self):
+        if self._parameters is None and self._device_table is not None:
+            self._parameters = self._device_table.cpu().numpy().reshape(self.nindex, -1)
+        return self._parameters
+
+    def _upload(self, ctx, slot):
+        ctx.tri_set(slot, self.discretization._desc(), self.unit_simplex_codes, self.hyperplanes,
+                    self.discretization.discrete_points, self.project,
+                    self._device(ctx).shape[1], self._device(ctx))
+
+
+# ----------------------------------------------------------------------------------------------
+# analytic dynamics of the examples
+# ----------------------------------------------------------------------------------------------
+
+def _normalization(normalization):
+    if normalization is None:
+        return None, None
+    norm = [np.array(v, dtype=config.np_dtype) for v in normalization]
+    return norm, [v ** -1 for v in norm]
+
+
+class InvertedPendulum(DeterministicFunction):
+    """Pendulum with 10 explicit-Euler sub-steps (``examples/utilities.py:144-289``)."""
+
+    def __init__(self, mass, length, friction=0, dt=1 / 80, normalization=None):
+        self.mass, self.length, self.friction, self.dt = mass, length, friction, dt
+        self.gravity = 9.81
+        self.normalization, self.inv_norm = _normalization(normalization)
+        self.input_dim, self.output_dim = 3, 2
+
+    @property
+    def inertia(self):
+        return self.mass * self.length ** 2
+
+    def linearize(self):
+        """Discretised linearisation around the upright position (``:207-240``)."""
+        A = np.array([[0, 1], [self.gravity / self.length, -self.friction / self.inertia]],
+                     dtype=config.np_dtype)
+        B = np.array([[0], [1 / self.inertia]], dtype=config.np_dtype)
+        if self.normalization is not None:
+            Tx, Tu = map(np.diag, self.normalization)
+            Tx_inv, Tu_inv = map(np.diag, self.inv_norm)
+            A = np.linalg.multi_dot((Tx_inv, A, Tx))
+            B = np.linalg.multi_dot((Tx_inv, B, Tu))
+        sysd = signal.StateSpace(A, B, np.eye(2), np.zeros((2, 1))).to_discrete(self.dt)
+        return sysd.A, sysd.B
+
+    def _write_dynamics(self, desc):
+        desc.kind = _hip.DYN_PENDULUM
+        desc.coef[0] = self.dt / 10
+        desc.coef[1] = self.gravity / self.length
+        desc.coef[2] = self.inertia
+        desc.coef[3] = self.friction / self.inertia
+        desc.coef[4] = 1.0 if self.friction > 0 else 0.0
+        _write_norm(desc, self.normalization, self.inv_norm, 2)
+
+
+class CartPole(DeterministicFunction):
+    """Cart-pole with 10 explicit-Euler sub-steps (``examples/utilities.py:292-437``)."""
+
+    def __init__(self, pendulum_mass, cart_mass, length, rot_friction=0.0, dt=0.01,
+                 normalization=None):
+        self.pendulum_mass, self.cart_mass, self.length = pendulum_mass, cart_mass, length
+        self.rot_friction, self.dt, self.gravity = rot_friction, dt, 9.81
+        self.state_dim, self.action_dim = 4, 1
+        self.input_dim, self.output_dim = 5, 4
+        self.normalization, self.inv_norm = _normalization(normalization)
+
+    def linearize(self):
+        """Discretised (zero-order hold) linearisation (``:352-385``)."""
+        m, M, L, b, g = (self.pendulum_mass, self.cart_mass, self.length, self.rot_friction,
+                         self.gravity)
+        A = np.array([[0, 0, 1, 0],
+                      [0, 0, 0, 1],
+                      [0, g * m / M, 0, -b / (M * L)],
+                      [0, g * (m + M) / (L * M), 0, -b * (m + M) / (m * M * L ** 2)]],
+                     dtype=config.np_dtype)
+        B = np.array([0, 0, 1 / M, 1 / (M * L)]).reshape((-1, self.action_dim))
+        if self.normalization is not None:
+            Tx, Tu = map(np.diag, self.normalization)
+            Tx_inv, Tu_inv = map(np.diag, self.inv_norm)
+            A = np.linalg.multi_dot((Tx_inv, A, Tx))
+            B = np.linalg.multi_dot((Tx_inv, B, Tu))
+        Ad, Bd, _, _, _ = signal.cont2discrete((A, B, 0, 0), self.dt, method='zoh')
+        return Ad, Bd
+
+    def _write_dynamics(self, desc):
+        m, M, L, b, g = (self.pendulum_mass, self.cart_mass, self.length, self.rot_friction,
+                         self.gravity)
+        desc.kind = _hip.DYN_CARTPOLE
+        # the products below are evaluated in the operator order of examples/utilities.py:430-433
+        for k, v in enumerate([self.dt / 10, m, M, L, b, m * L, 0.5 * m * g * L, 0.5 * m * L,
+                               b * (m + M), (m + M) * g]):
+            desc.coef[k] = float(v)
+        _write_norm(desc, self.normalization, self.inv_norm, 4)
+
+
+def _write_norm(desc, normalization, inv_norm, d):
+    desc.normalize = 0 if normalization is None else 1
+    for k in range(d):
+        desc.tx[k] = 1.0 if normalization is None else float(normalization[0][k])
+        desc.tx_inv[k] = 1.0 if normalization is None else float(inv_norm[0][k])
+    desc.tu[0] = 1.0 if normalization is None else float(normalization[1][0])
+
+
+# ----------------------------------------------------------------------------------------------
+# positive-definite network
+# ----------------------------------------------------------------------------------------------
+
+_ACTIVATIONS = {None: 0, 'linear': 0, 'tanh': 1, 'relu': 2}
+
+
+class LyapunovNetwork(DeterministicFunction):
+    """``sum(phi(x)^2)`` with layer kernels ``[W^T W + eps I ; W']``
+    (``examples/utilities.py:48-104``).  ``activations`` are names ('tanh', 'relu', None);
+    ``weights`` the flat variable list in the reference's creation order, or ``None`` for
+    Xavier-uniform initialisation from ``seed``."""
+
+    def __init__(self, input_dim, layer_dims, activations, eps=1e-6, weights=None, seed=0,
+                 name='lyapunov_network'):
+        self.input_dim = int(input_dim)
+        self.num_layers = len(layer_dims)
+        self.activations = list(activations)
+        self.eps = float(eps)
+        self.name = name
+        if layer_dims[0] < input_dim:
+            raise ValueError('The first layer dimension must be at least the input dimension!')
+        if not np.all(np.diff(layer_dims) >= 0):
+            raise ValueError('Each layer must maintain or increase the dimension of its input!')
+        self.output_dims = list(layer_dims)
+        self.hidden_dims = [int(np.ceil(((self.input_dim if i == 0 else layer_dims[i - 1]) + 1) / 2))
+                            for i in range(self.num_layers)]
+        shapes = self.weight_shapes()
+        if weights is None:
+            rng = np.random.default_rng(seed)
+            weights = [rng.uniform(-1, 1, s) * np.sqrt(6. / (s[0] + s[1])) for s in shapes]
+        self.weights = [np.asarray(w, dtype=config.np_dtype) for w in weights]
+        if [w.shape for w in self.weights] != shapes:
+            raise ValueError('weights must have shapes %s' % (shapes,))
+
+    def weight_shapes(self):
+        shapes = []
+        for i in range(self.num_layers):
+            in_dim = self.input_dim if i == 0 else self.output_dims[i - 1]
+            shapes.append((self.hidden_dims[i], in_dim))
+            if self.output_dims[i] > in_dim:
+                shapes.append((self.output_dims[i] - in_dim, in_dim))
+        return shapes
+
+    def kernels(self):
+        """Per-layer ``[out_i, in_i]`` matrices (``examples/utilities.py:95-100``)."""
+        out, it = [], iter(self.weights)
+        for i in range(self.num_layers):
+            in_dim = self.input_dim if i == 0 else self.output_dims[i - 1]
+            W = next(it)
+            kernel = W.T.dot(W) + self.eps * np.eye(in_dim)
+            if self.output_dims[i] > in_dim:
+                kernel = np.concatenate([kernel, next(it)], axis=0)
+            out.append(kernel)
+        return out
+
+    def _upload(self, ctx):
+        dims = [self.input_dim] + self.output_dims
+        ctx.network_set(dims, [_ACTIVATIONS[a] for a in self.activations], self.kernels())

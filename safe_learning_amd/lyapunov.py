@@ -1,0 +1,321 @@
+"""``Lyapunov``: safe-set computation on a GridWorld, executed by the HIP engine.
+
+Drop-in for the constructor / ``update_values`` / ``update_safe_set`` surface of
+``safe_learning/lyapunov.py:142-606``.  What changes underneath:
+
+* the reference sorts all cells by V (``np.argsort``, ``lyapunov.py:512``) and walks them in
+  10 000-cell batches through a TensorFlow graph until the first failing cell
+  (``:524-587``).  Here one fused kernel checks EVERY cell of this rank's grid shard and
+  reduces the lexicographically smallest failing ``(V, index)`` key; a second streaming pass
+  marks ``safe_i = init_i or key_i < key*``.  Both formulations give the same mask (see
+  DESIGN.md, "prefix rule"); ties in V are ordered by flat index (the oracle's definition).
+* ``c_max`` follows the reference's index arithmetic, including its two quirks
+  (``lyapunov.py:590-595``): "first cell fails" reads the largest value, "nothing fails" reads
+  the value just before the last batch - obtained with a device-side radix select.
+* with ``torch.distributed`` initialised, every rank owns a contiguous 64-aligned index range
+  and the reductions become RCCL collectives of a few bytes.
+"""
+
+import numpy as np
+
+from . import _hip
+from . import distributed as dist_utils
+from ._model import ModelBuilder
+from .configuration import config
+
+__all__ = ['Lyapunov', 'smallest_boundary_value']
+
+_U64_MAX = (1 << 64) - 1
+_I64_MAX = (1 << 63) - 1
+_KEY_NONE = (_U64_MAX, _I64_MAX)
+
+
+def vbits_to_float(vbits):
+    """Inverse of the kernels' order-preserving float64 -> uint64 map (``sl_vbits``)."""
+    if vbits == _U64_MAX:
+        return float('nan')
+    raw = (vbits & ((1 << 63) - 1)) if vbits & (1 << 63) else (~vbits) & _U64_MAX
+    return float(np.array([raw], dtype=np.uint64).view(np.float64)[0])
+
+
+def smallest_boundary_value(fun, discretization):
+    """Smallest value of the quadratic / table function ``fun`` on the grid boundary
+    (``lyapunov.py:22-56``), evaluated with the engine's value pass."""
+    lyap = Lyapunov.__new__(Lyapunov)
+    lyap._bare_init(discretization, fun)
+    values = lyap.values.reshape(discretization.num_points)
+    best = np.inf
+    for axis in range(discretization.ndim):
+        face = np.take(values, [0, -1], axis=axis)
+        best = min(best, float(face.min()))
+    return best
+
+
+class Lyapunov(object):
+    """See ``safe_learning/lyapunov.py:142-175`` for the argument meanings.
+
+    ``lyapunov_function``, ``dynamics``, ``policy`` and ``lipschitz_lyapunov`` are specs from
+    :mod:`safe_learning_amd.functions` (arbitrary Python callables cannot run in a kernel).
+    """
+
+    def __init__(self, discretization, lyapunov_function, dynamics, lipschitz_dynamics,
+                 lipschitz_lyapunov, tau, policy, initial_set=None, adaptive=False):
+        self._setup_engine(discretization)
+        self.policy = policy
+        self.tau = tau
+        self.dynamics = dynamics
+        self.lyapunov_function = lyapunov_function
+        self._lipschitz_dynamics = lipschitz_dynamics
+        self._lipschitz_lyapunov = lipschitz_lyapunov
+        self.adaptive = adaptive
+        if adaptive:
+            raise NotImplementedError('adaptive refinement (lyapunov.py:445-487, 540-582) is not '
+                                      'part of the accelerated path yet')
+        self.c_max = 0.
+        self.feed_dict = _CMaxView(self)
+        self.initial_safe_set = initial_set
+        # safe_set starts as the initial set (lyapunov.py:187-192)
+        self._safe_host = np.zeros(self.discretization.nindex, dtype=bool)
+        if initial_set is not None:
+            self._safe_host[initial_set] = True
+        self._safe_host_valid = True
+        self._safe_dev_valid = False
+        self.update_values()
+
+    # ---- engine plumbing -----------------------------------------------------------------
+    def _setup_engine(self, discretization):
+        import torch
+        self.discretization = discretization
+        self._ctx = _hip.Context()
+        self._builder = ModelBuilder(self._ctx, discretization)
+        n = discretization.nindex
+        self._rank, self._world = dist_utils.rank_and_world()
+        self._bounds = dist_utils.shard_bounds(n, self._world)
+        self._lo, self._hi = self._bounds[self._rank], self._bounds[self._rank + 1]
+        dev = self._ctx.torch_device
+        count = self._hi - self._lo
+        self._nwords = (count + 63) // 64
+        self._d_values = torch.empty(max(count, 1), dtype=torch.float64, device=dev)
+        self._d_init = torch.zeros(max(self._nwords, 1), dtype=torch.int64, device=dev)
+        self._d_neg = torch.zeros(max(self._nwords, 1), dtype=torch.int64, device=dev)
+        self._d_safe = torch.zeros(max(self._nwords, 1), dtype=torch.int64, device=dev)
+        self._d_result = torch.zeros(_hip.RESULT_WORDS, dtype=torch.int64, device=dev)
+        self._d_hist = torch.zeros(256, dtype=torch.int64, device=dev)
+        self._values_host = None
+        self._init_version = None
+
+    def _bare_init(self, discretization, fun):
+        """Value-only instance used by ``smallest_boundary_value``."""
+        from .functions import ConstantFunction, LinearSystem
+        self._setup_engine(discretization)
+        d = discretization.ndim
+        self.lyapunov_function = fun
+        self.policy = ConstantFunction(np.zeros(1))
+        self.dynamics = LinearSystem((np.eye(d), np.zeros((d, 1))))
+        self._lipschitz_dynamics = 0.
+        self._lipschitz_lyapunov = 0.
+        self.tau = 0.
+        self.update_values()
+
+    def _upload_model(self):
+        self._builder.upload(self.policy, self.dynamics, self.lyapunov_function,
+                             self._lipschitz_lyapunov, self._lipschitz_dynamics, self.tau)
+
+    # ---- reference attribute surface -----------------------------------------------------
+    @property
+    def initial_safe_set(self):
+        return self._initial_safe_set
+
+    @initial_safe_set.setter
+    def initial_safe_set(self, value):
+        self._initial_safe_set = value
+        self._init_version = None
+
+    def lipschitz_dynamics(self, states):
+        """The (scalar) Lipschitz constant of the dynamics (``lyapunov.py:227-244``)."""
+        return self._lipschitz_dynamics
+
+    @property
+    def values(self):
+        """V at every grid point, ``float64[nindex]`` (``lyapunov.py:305-322``); gathered from all
+        ranks and copied to the host on first access after ``update_values``."""
+        if self._values_host is None:
+            sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
+            full = dist_utils.allgather_concat(self._d_values[:self._hi - self._lo], sizes)
+            self._values_host = full.cpu().numpy()
+        return self._values_host
+
+    @property
+    def safe_set(self):
+        """``bool[nindex]`` mask, the same array object across calls (``lyapunov.py:187, 598-606``)."""
+        if not self._safe_host_valid:
+            import torch
+            count = self._hi - self._lo
+            d_bytes = torch.empty(max(-(-count // 8) * 8, 8), dtype=torch.uint8,
+                                  device=self._ctx.torch_device)
+            self._ctx.bits_to_bytes(count, self._d_safe, d_bytes)
+            sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
+            full = dist_utils.allgather_concat(d_bytes[:count], sizes)
+            self._safe_host[:] = full.cpu().numpy().astype(bool)
+            self._safe_host_valid = True
+            # the host array may now be edited by the caller: it becomes the truth again
+            self._safe_dev_valid = False
+        return self._safe_host
+
+    @safe_set.setter
+    def safe_set(self, value):
+        self._safe_host[:] = value
+        self._safe_host_valid = True
+        self._safe_dev_valid = False
+
+    @property
+    def _refinement(self):
+        """Refinement N(x) of the non-adaptive case: 1 on safe cells, 0 elsewhere
+        (``lyapunov.py:220-225, 531, 586, 601-606``)."""
+        return self.safe_set.astype(int)
+
+    def is_safe(self, state):
+        """``lyapunov.py:290-303``."""
+        return self.safe_set[self.discretization.state_to_index(state)]
+
+    # ---- device helpers ------------------------------------------------------------------
+    def _upload_mask(self, host_mask, d_bits):
+        """bool[nindex] host mask -> this rank's bit words."""
+        import torch
+        count = self._hi - self._lo
+        if count == 0:
+            return
+        chunk = np.ascontiguousarray(host_mask[self._lo:self._hi]).view(np.uint8)
+        d_bytes = torch.from_numpy(chunk).to(self._ctx.torch_device)
+        self._ctx.bytes_to_bits(count, d_bytes, d_bits)
+
+    def _refresh_init_bits(self):
+        init = self._initial_safe_set
+        if init is None:
+            version = 'none'
+        else:
+            arr = np.asarray(init)
+            version = (id(init), arr.shape, arr.dtype.str, int(np.count_nonzero(arr)))
+        if version == self._init_version:
+            return
+        if init is None:
+            self._d_init.zero_()
+        else:
+            arr = np.asarray(init)
+            if arr.dtype == bool and arr.shape == (self.discretization.nindex,):
+                mask = arr
+            else:
+                mask = np.zeros(self.discretization.nindex, dtype=bool)
+                mask[init] = True
+            self._upload_mask(mask, self._d_init)
+        self._init_version = version
+
+    def _read_result(self):
+        return [int(v) for v in self._d_result.cpu().numpy().view(np.int64)]
+
+    @staticmethod
+    def _u64(v):
+        return v & _U64_MAX
+
+    def _select_kth(self, k):
+        """``(vbits, index)`` of the k-th smallest key (0-based) over the whole grid: two 8-pass
+        radix selects (value bytes, then index bytes among equal values)."""
+        lo, hi = self._lo, self._hi
+
+        def run(which, vbits_equal, rank_in):
+            prefix, remaining = 0, rank_in
+            for byte in range(7, -1, -1):
+                self._d_hist.zero_()
+                self._ctx.select_pass(lo, hi, self._d_values, which, byte, prefix, vbits_equal,
+                                      self._d_hist)
+                dist_utils.allreduce_sum_(self._d_hist)
+                hist = self._d_hist.cpu().numpy()
+                cum = np.cumsum(hist)
+                digit = int(np.searchsorted(cum, remaining, side='right'))
+                if digit > 0:
+                    remaining -= int(cum[digit - 1])
+                prefix |= digit << (8 * byte)
+            return prefix, remaining
+
+        vbits, rank_among_equal = run(0, 0, k)
+        index, _ = run(1, vbits, rank_among_equal)
+        return vbits, index
+
+    # ---- reference methods ---------------------------------------------------------------
+    def update_values(self):
+        """Recompute V on the grid (``lyapunov.py:305-322``)."""
+        self._upload_model()
+        self._ctx.values(self._lo, self._hi, self._d_values)
+        self._values_host = None
+
+    def update_safe_set(self, can_shrink=True, max_refinement=1, safety_factor=1.,
+                        parallel_iterations=1):
+        """Recompute the safe set (``lyapunov.py:407-606``, non-adaptive branch)."""
+        ctx, lo, hi = self._ctx, self._lo, self._hi
+        n = self.discretization.nindex
+        batch = int(config.gp_batch_size)
+        self._upload_model()
+        self._refresh_init_bits()
+
+        if can_shrink:
+            d_prior = self._d_init                     # lyapunov.py:500-506
+        else:                                          # lyapunov.py:507-510
+            if not self._safe_dev_valid:
+                self._upload_mask(self._safe_host, self._d_safe)
+            d_prior = self._d_safe.clone()
+
+        # decrease check of every cell + lexmin of the failing (V, index) keys
+        ctx.lyap_sweep(lo, hi, d_prior, self._d_values, self._d_neg, self._d_result)
+        self._values_host = None
+        res = self._read_result()
+        star = dist_utils.allreduce_key(self._u64(res[_hip.R_FAIL_V]), res[_hip.R_FAIL_I], 'min',
+                                        ctx.torch_device)
+
+        # first pass of the prefix rule: everything below key* is safe
+        ctx.lyap_finalize(lo, hi, self._d_values, self._d_init, None, star, _KEY_NONE,
+                          self._d_safe, self._d_result)
+        res = self._read_result()
+        below = self._allreduce_int(res[_hip.R_BELOW])
+        last_safe = dist_utils.allreduce_key(self._u64(res[_hip.R_LAST_V]), res[_hip.R_LAST_I],
+                                             'max', ctx.torch_device)
+        max_key = dist_utils.allreduce_key(self._u64(res[_hip.R_MAX_V]), res[_hip.R_MAX_I], 'max',
+                                           ctx.torch_device)
+        failed = star != _KEY_NONE
+
+        if failed and not can_shrink:
+            # cells after the batch that contains the first failure keep their previous state
+            # (lyapunov.py:585-587 never touches later batches)
+            end = (below // batch + 1) * batch
+            keep = self._select_kth(end) if end < n else _KEY_NONE
+            ctx.lyap_finalize(lo, hi, self._d_values, self._d_init, d_prior, star, keep,
+                              self._d_safe, self._d_result)
+
+        # c_max = values[order[max_index]], max_index as in lyapunov.py:590
+        if failed:
+            c_key = last_safe if below > 0 else max_key
+        else:
+            last_batch_start = ((n - 1) // batch) * batch
+            c_key = self._select_kth(last_batch_start - 1) if last_batch_start > 0 else max_key
+        self.c_max = vbits_to_float(c_key[0])
+
+        self._safe_host_valid = False
+        self._safe_dev_valid = True
+
+    def _allreduce_int(self, value):
+        if self._world == 1:
+            return value
+        import torch
+        t = torch.tensor([value], dtype=torch.int64, device=self._ctx.torch_device)
+        dist_utils.allreduce_sum_(t)
+        return int(t[0])
+
+
+class _CMaxView(dict):
+    """``lyapunov.feed_dict[lyapunov.c_max]`` of the notebooks keeps working: any key reads c_max."""
+
+    def __init__(self, owner):
+        super(_CMaxView, self).__init__()
+        self._owner = owner
+
+    def __getitem__(self, key):
+        return self._owner.c_max

@@ -1,0 +1,126 @@
+"""``PolicyIteration``: dynamic programming on a GridWorld, executed by the HIP engine.
+
+Drop-in for ``safe_learning/reinforcement_learning.py:26-140, 213-279`` (``future_values``,
+``value_iteration``, ``bellmann_error``, ``discrete_policy_optimization``).  The reference
+returns TensorFlow ops that the caller runs; here the calls perform the sweep on the GPU.
+
+The value function is a :class:`~safe_learning_amd.functions.Triangulation` whose vertex table
+lives on the device; one Jacobi sweep reads the old table (replicated on every GPU) and writes
+this rank's shard of the new one, followed by an all-gather.
+"""
+
+import numpy as np
+
+from . import _hip
+from . import distributed as dist_utils
+from ._model import ModelBuilder
+from .functions import ConstantFunction, Triangulation
+
+__all__ = ['PolicyIteration', 'OptimizationError']
+
+
+class OptimizationError(Exception):
+    """``reinforcement_learning.py:22-23``."""
+
+
+class PolicyIteration(object):
+    """See ``reinforcement_learning.py:26-63`` for the argument meanings."""
+
+    def __init__(self, policy, dynamics, reward_function, value_function, gamma=0.98):
+        if not isinstance(value_function, Triangulation):
+            raise TypeError('value_function must be a Triangulation')
+        self.policy = policy
+        self.dynamics = dynamics
+        self.reward_function = reward_function
+        self.value_function = value_function
+        self.gamma = gamma
+        self.discretization = value_function.discretization
+        self._ctx = _hip.Context()
+        self._builder = ModelBuilder(self._ctx, self.discretization)
+        n = self.discretization.nindex
+        self._rank, self._world = dist_utils.rank_and_world()
+        self._bounds = dist_utils.shard_bounds(n, self._world)
+        self._lo, self._hi = self._bounds[self._rank], self._bounds[self._rank + 1]
+        self.last_residual = None
+
+    @property
+    def state_space(self):
+        """All grid vertices (``reinforcement_learning.py:58-59``)."""
+        return self.discretization.all_points
+
+    def _upload(self, policy):
+        self._builder.upload(policy, self.dynamics, self.value_function, reward=self.reward_function,
+                             gamma=self.gamma)
+
+    def _sweep(self, policy, actions):
+        """One pass over this rank's vertices; returns device tensors (v_new, argmax, q, stats)."""
+        import torch
+        ctx, lo, hi = self._ctx, self._lo, self._hi
+        dev = ctx.torch_device
+        count = max(hi - lo, 1)
+        self._upload(policy)
+        v_new = torch.empty(count, dtype=torch.float64, device=dev)
+        stats = torch.zeros(2, dtype=torch.float64, device=dev)
+        argmax = q = None
+        if actions is not None:
+            actions = np.atleast_2d(np.asarray(actions, dtype=np.float64))
+            argmax = torch.empty(count, dtype=torch.int32, device=dev)
+            q = torch.empty((count, actions.shape[0]), dtype=torch.float64, device=dev)
+        ctx.bellman_sweep(lo, hi, actions, v_new, argmax, q, stats)
+        return v_new[:hi - lo], argmax, q, stats
+
+    def _gather(self, shard):
+        sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
+        return dist_utils.allgather_concat(shard, sizes)
+
+    def future_values(self, states=None, policy=None, actions=None, lyapunov=None,
+                      lagrange_multiplier=1.):
+        """``r(x,u) + gamma V(f(x,u))`` at every grid vertex (``:65-114``).  ``states`` must be the
+        grid itself (``None`` or ``state_space``); ``actions`` may be one constant action row."""
+        if lyapunov is not None:
+            raise NotImplementedError('the Lyapunov penalty term (:107-112) is not accelerated')
+        if states is not None and states is not self.state_space:
+            if np.shape(states) != (self.discretization.nindex, self.discretization.ndim):
+                raise NotImplementedError('future_values is evaluated on the grid vertices')
+        if actions is not None:
+            policy = ConstantFunction(np.asarray(actions, dtype=np.float64).reshape(-1)[
+                :np.shape(actions)[-1]])
+        elif policy is None:
+            policy = self.policy
+        v_new, _, _, _ = self._sweep(policy, None)
+        return self._gather(v_new).cpu().numpy()[:, None]
+
+    def value_iteration(self):
+        """One Jacobi sweep ``V <- r + gamma V(f)`` (``:135-140``); returns ``max |dV|``."""
+        v_new, _, _, stats = self._sweep(self.policy, None)
+        full = self._gather(v_new)
+        dist_utils.allreduce_max_(stats[:1])
+        self.value_function._adopt_device_table(full.reshape(-1, 1).contiguous())
+        self.last_residual = float(stats[0])
+        return self.last_residual
+
+    def bellmann_error(self, states=None):
+        """``sum (future_values - V)^2`` over the grid (``:116-133``)."""
+        _, _, _, stats = self._sweep(self.policy, None)
+        dist_utils.allreduce_sum_(stats[1:])
+        return float(stats[1])
+
+    def discrete_policy_optimization(self, action_space, constraint=None):
+        """Greedy policy over a finite action set (``:213-279``); the first maximiser wins."""
+        import torch
+        if constraint is not None:
+            raise NotImplementedError('constraint callbacks are not accelerated')
+        action_space = np.atleast_2d(np.asarray(action_space, dtype=np.float64))
+        _, argmax, q, _ = self._sweep(self.policy, action_space)
+        best = self._gather(argmax[:self._hi - self._lo].to(torch.int64))
+        table = torch.from_numpy(action_space).to(best.device)[best]
+        if isinstance(self.policy, Triangulation):
+            self.policy._adopt_device_table(table.contiguous())
+        else:
+            self.policy = Triangulation(self.discretization, table.cpu().numpy())
+        return self._gather(q.reshape(-1)[:(self._hi - self._lo) * action_space.shape[0]]
+                            ).reshape(-1, action_space.shape[0]) if self._world == 1 else None
+
+    def optimize_value_function(self, **solver_options):
+        """The cvxpy linear program of ``:142-211`` is outside the accelerated path."""
+        raise NotImplementedError('optimize_value_function (cvxpy LP) is out of scope')
