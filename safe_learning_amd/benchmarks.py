@@ -1,0 +1,204 @@
+"""Synthetic problem definitions of BASELINE.json's configs.
+
+``make_case`` returns a plain dict of NumPy parameters (no engine objects) so that the very same
+numbers can be fed to the HIP engine (``build_lyapunov`` below) and, in tests / the CPU baseline,
+to the oracle (``tests/cases.py``).  Provenance of the constants: the pendulum and its
+normalisation are ``examples/adaptive_safety_verification.ipynb`` cells 7-17, the cart-pole is
+``examples/reinforcement_learning_cartpole.ipynb`` cell 7; grid sizes, GP sizes and the RBF kernel
+are BASELINE.json's.
+"""
+
+import numpy as np
+from scipy import signal
+
+from .utilities import dlqr
+
+GRAVITY = 9.81
+
+
+def _pendulum_linearize(mass, length, friction, dt, norm):
+    inertia = mass * length ** 2
+    A = np.array([[0, 1], [GRAVITY / length, -friction / inertia]])
+    B = np.array([[0], [1 / inertia]])
+    Tx, Tu = np.diag(norm[0]), np.diag(norm[1])
+    A = np.linalg.multi_dot((np.linalg.inv(Tx), A, Tx))
+    B = np.linalg.multi_dot((np.linalg.inv(Tx), B, Tu))
+    sysd = signal.StateSpace(A, B, np.eye(2), np.zeros((2, 1))).to_discrete(dt)
+    return sysd.A, sysd.B
+
+
+def _cartpole_linearize(m, M, L, b, dt, norm):
+    g = GRAVITY
+    A = np.array([[0, 0, 1, 0], [0, 0, 0, 1], [0, g * m / M, 0, -b / (M * L)],
+                  [0, g * (m + M) / (L * M), 0, -b * (m + M) / (m * M * L ** 2)]])
+    B = np.array([0, 0, 1 / M, 1 / (M * L)]).reshape(-1, 1)
+    Tx, Tu = np.diag(norm[0]), np.diag(norm[1])
+    A = np.linalg.multi_dot((np.linalg.inv(Tx), A, Tx))
+    B = np.linalg.multi_dot((np.linalg.inv(Tx), B, Tu))
+    Ad, Bd, _, _, _ = signal.cont2discrete((A, B, 0, 0), dt, method='zoh')
+    return Ad, Bd
+
+
+def _true_dynamics_numpy(case, X):
+    """True system used to generate GP targets (host NumPy; data generation only)."""
+    dyn = case['true_dynamics']
+    x, u = X[:, :case['d']].copy(), X[:, case['d']:].copy()
+    norm = dyn['normalization']
+    x, u = x * np.asarray(norm[0]), u * np.asarray(norm[1])
+    dt = dyn['dt'] / 10
+    if dyn['kind'] == 'pendulum':
+        inertia = dyn['mass'] * dyn['length'] ** 2
+        for _ in range(10):
+            acc = GRAVITY / dyn['length'] * np.sin(x[:, [0]]) + u / inertia
+            acc = acc - dyn['friction'] / inertia * x[:, [1]]
+            x = x + dt * np.concatenate((x[:, [1]], acc), axis=1)
+    else:
+        m, M, L, b = dyn['pendulum_mass'], dyn['cart_mass'], dyn['length'], dyn['rot_friction']
+        for _ in range(10):
+            th, v, om = x[:, [1]], x[:, [2]], x[:, [3]]
+            s, c = np.sin(th), np.cos(th)
+            det = L * (M + m * s * s)
+            vd = (u - m * L * om * om * s - b * om * c + 0.5 * m * GRAVITY * L * np.sin(2 * th)) * L / det
+            wd = (u * c - 0.5 * m * L * om * om * np.sin(2 * th) - b * (m + M) * om / (m * L)
+                  + (m + M) * GRAVITY * s) / det
+            x = x + dt * np.concatenate((v, om, vd, wd), axis=1)
+    return x / np.asarray(norm[0])
+
+
+def make_case(name, num_points=None, n_gp=None, dynamics=None, seed=0, stack=False,
+              tau_scale=1.0, noise_std=0.01, signal_std=0.05, lengthscale=0.5):
+    """Parameters of one synthetic configuration.
+
+    name: '1d' (C1), 'pendulum' (C2/C3 family, d=2) or 'cartpole' (C4/C5 family, d=4).
+    dynamics: 'linear', 'analytic' (Euler pendulum / cart-pole) or 'gp' (default per family).
+    """
+    case = {'name': name, 'stack': bool(stack)}
+    if name == '1d':
+        # safe_learning/tests/test_lyapunov.py:48-74 scaled to 1001 cells
+        n = 1001 if num_points is None else num_points
+        case.update(d=1, m=1, limits=[[-1., 1.]], num_points=[n],
+                    K=np.array([[-0.1]]), saturate=None,
+                    dynamics={'kind': 'linear', 'matrix': np.array([[1., 1.]])},
+                    P=np.array([[1.]]), lv=('const', 0.3), lf=0.4, tau=0.5 * tau_scale,
+                    initial_set=np.array([n // 2]))
+        return case
+
+    if name == 'pendulum':
+        d, dt = 2, 0.01
+        theta_max, omega_max = np.deg2rad(30), np.sqrt(GRAVITY / 0.5)
+        u_max = GRAVITY * 0.15 * 0.5 * np.sin(theta_max)
+        norm = [(theta_max, omega_max), (u_max,)]
+        true = {'kind': 'pendulum', 'mass': 0.15, 'length': 0.5, 'friction': 0.1, 'dt': dt,
+                'normalization': norm}
+        A_true, B_true = _pendulum_linearize(0.15, 0.5, 0.1, dt, norm)
+        A_prior, B_prior = _pendulum_linearize(0.1, 0.4, 0.0, dt, norm)
+        Q, R = np.diag([1., 2.]), 1.2 * np.eye(1)
+        default_points = 256
+    elif name == 'cartpole':
+        d, dt = 4, 0.01
+        m_p, m_c, length, fric = 0.175, 1.732, 0.28, 0.01
+        norm = [(0.5, np.deg2rad(30), 2., np.deg2rad(30)), ((m_p + m_c) * 4 / 0.5,)]
+        true = {'kind': 'cartpole', 'pendulum_mass': m_p, 'cart_mass': m_c, 'length': length,
+                'rot_friction': fric, 'dt': dt, 'normalization': norm}
+        A_true, B_true = _cartpole_linearize(m_p, m_c, length, fric, dt, norm)
+        A_prior, B_prior = A_true, B_true
+        Q, R = 0.1 * np.eye(4), 0.1 * np.eye(1)
+        default_points = 128
+    else:
+        raise ValueError(name)
+
+    n = default_points if num_points is None else num_points
+    num_points = np.broadcast_to(n, (d,)).astype(int)
+    K, P = dlqr(A_true, B_true, Q, R)
+    P = P / np.abs(P).max()
+    unit = 2.0 / (num_points - 1)
+    case.update(d=d, m=1, limits=[[-1., 1.]] * d, num_points=list(int(v) for v in num_points),
+                K=-K, saturate=(-1., 1.), P=P, lv=('abs_linear', 2 * P),
+                lf=float(np.linalg.norm(A_true, 1) + np.linalg.norm(B_true, 1) * np.linalg.norm(-K, 1)),
+                tau=float(np.sum(unit) / 2) * tau_scale, initial_radius=0.2,
+                true_dynamics=true, A_true=A_true, B_true=B_true)
+    kind = dynamics or 'gp'
+    if kind == 'linear':
+        case['dynamics'] = {'kind': 'linear', 'matrix': np.hstack((A_true, B_true))}
+    elif kind == 'analytic':
+        case['dynamics'] = dict(true)
+    elif kind == 'gp':
+        n_gp = (512 if name == 'pendulum' else 1024) if n_gp is None else n_gp
+        p = d + 1
+        X = np.random.default_rng(seed).uniform(-1, 1, (n_gp, p))
+        Y = _true_dynamics_numpy(case, X) + np.random.default_rng(seed + 1).normal(
+            0, noise_std, (n_gp, d))
+        ls = np.full(p, lengthscale)
+        if stack:
+            # notebook style: one GP per output with its own lengthscales (functions.py:278-291)
+            ls = np.stack([np.full(p, lengthscale * (1 + 0.25 * k)) for k in range(d)])
+        case['dynamics'] = {'kind': 'gp', 'X': X, 'Y': Y, 'variance': signal_std ** 2,
+                            'lengthscales': ls, 'noise_variance': noise_std ** 2,
+                            'prior': np.hstack((A_prior, B_prior)), 'beta': 2.0}
+    else:
+        raise ValueError(kind)
+    return case
+
+
+def initial_safe_mask(case):
+    """``||x||_2 <= radius`` on the grid without materialising all points
+    (``adaptive_safety_verification.ipynb`` cell 11)."""
+    if 'initial_set' in case:
+        return case['initial_set']
+    axes = [np.linspace(lo, hi, n) ** 2 for (lo, hi), n in zip(case['limits'], case['num_points'])]
+    total = axes[0]
+    for ax in axes[1:]:
+        total = np.add.outer(total, ax)
+    return (np.sqrt(total) <= case['initial_radius']).ravel()
+
+
+def build_specs(case):
+    """Engine specs (policy, dynamics, V, L_v) of a case."""
+    from . import functions as F
+    policy = F.LinearSystem((case['K'],))
+    if case['saturate'] is not None:
+        policy = F.Saturation(policy, *case['saturate'])
+    dyn = case['dynamics']
+    if dyn['kind'] == 'linear':
+        dynamics = F.LinearSystem((dyn['matrix'],))
+    elif dyn['kind'] == 'pendulum':
+        dynamics = F.InvertedPendulum(dyn['mass'], dyn['length'], dyn['friction'], dyn['dt'],
+                                      dyn['normalization'])
+    elif dyn['kind'] == 'cartpole':
+        dynamics = F.CartPole(dyn['pendulum_mass'], dyn['cart_mass'], dyn['length'],
+                              dyn['rot_friction'], dyn['dt'], dyn['normalization'])
+    else:
+        d = case['d']
+        if case['stack']:
+            heads = []
+            for k in range(d):
+                kern = F.RBF(d + 1, dyn['variance'], dyn['lengthscales'][k], ARD=True)
+                gp = F.GPRCached(dyn['X'], dyn['Y'][:, [k]], kern,
+                                 F.LinearSystem((dyn['prior'][[k], :],)),
+                                 likelihood_variance=dyn['noise_variance'])
+                heads.append(F.GaussianProcess(gp, dyn['beta']))
+            dynamics = F.FunctionStack(heads)
+        else:
+            kern = F.RBF(d + 1, dyn['variance'], dyn['lengthscales'], ARD=True)
+            gp = F.GPRCached(dyn['X'], dyn['Y'], kern, F.LinearSystem((dyn['prior'],)),
+                             likelihood_variance=dyn['noise_variance'])
+            dynamics = F.GaussianProcess(gp, dyn['beta'])
+    value = F.QuadraticFunction(case['P'])
+    kind, arg = case['lv']
+    if kind == 'const':
+        lv = arg
+    elif kind == 'abs_linear':
+        lv = F.AbsFunction(F.LinearSystem((arg,)))
+    else:
+        lv = F.Norm1Function(F.LinearSystem((arg,)))
+    return policy, dynamics, value, lv
+
+
+def build_lyapunov(case):
+    """``safe_learning_amd.Lyapunov`` of a case (runs ``update_values`` like the reference)."""
+    from .functions import GridWorld
+    from .lyapunov import Lyapunov
+    grid = GridWorld(case['limits'], case['num_points'])
+    policy, dynamics, value, lv = build_specs(case)
+    return Lyapunov(grid, value, dynamics, case['lf'], lv, case['tau'], policy,
+                    initial_set=initial_safe_mask(case))

@@ -265,7 +265,15 @@ class Lyapunov(object):
             d_prior = self._d_safe.clone()
 
         # decrease check of every cell + lexmin of the failing (V, index) keys
+        events = getattr(self, 'sweep_events', None)
+        if events is not None:                      # bench.py: HIP events on the kernel's stream
+            import torch
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
         ctx.lyap_sweep(lo, hi, d_prior, self._d_values, self._d_neg, self._d_result)
+        if events is not None:
+            stop.record()
+            events.append((start, stop))
         self._values_host = None
         res = self._read_result()
         star = dist_utils.allreduce_key(self._u64(res[_hip.R_FAIL_V]), res[_hip.R_FAIL_I], 'min',

@@ -1,0 +1,78 @@
+"""Build ORACLE objects (test infrastructure) from the parameter dicts of
+``safe_learning_amd.benchmarks.make_case`` - the same numbers the HIP engine gets."""
+
+import numpy as np
+
+import oracle
+from safe_learning_amd.benchmarks import initial_safe_mask, make_case  # noqa: F401
+
+
+def oracle_specs(case):
+    policy = oracle.LinearSystem((case['K'],))
+    if case['saturate'] is not None:
+        policy = oracle.Saturation(policy, *case['saturate'])
+    dyn = case['dynamics']
+    if dyn['kind'] == 'linear':
+        dynamics = oracle.LinearSystem((dyn['matrix'],))
+    elif dyn['kind'] == 'pendulum':
+        dynamics = oracle.InvertedPendulum(dyn['mass'], dyn['length'], dyn['friction'], dyn['dt'],
+                                           dyn['normalization'])
+    elif dyn['kind'] == 'cartpole':
+        dynamics = oracle.CartPole(dyn['pendulum_mass'], dyn['cart_mass'], dyn['length'],
+                                   dyn['rot_friction'], dyn['dt'], dyn['normalization'])
+    else:
+        d = case['d']
+        if case['stack']:
+            heads = []
+            for k in range(d):
+                kern = oracle.RBF(d + 1, dyn['variance'], dyn['lengthscales'][k], ARD=True)
+                gp = oracle.GPRCached(dyn['X'], dyn['Y'][:, [k]], kern,
+                                      oracle.LinearSystem((dyn['prior'][[k], :],)),
+                                      likelihood_variance=dyn['noise_variance'])
+                heads.append(oracle.GaussianProcess(gp, dyn['beta']))
+            dynamics = oracle.FunctionStack(heads)
+        else:
+            kern = oracle.RBF(d + 1, dyn['variance'], dyn['lengthscales'], ARD=True)
+            gp = oracle.GPRCached(dyn['X'], dyn['Y'], kern, oracle.LinearSystem((dyn['prior'],)),
+                                  likelihood_variance=dyn['noise_variance'])
+            dynamics = oracle.GaussianProcess(gp, dyn['beta'])
+    value = oracle.QuadraticFunction(case['P'])
+    kind, arg = case['lv']
+    if kind == 'const':
+        lv = arg
+    elif kind == 'abs_linear':
+        lv = oracle.AbsFunction(oracle.LinearSystem((arg,)))
+    else:
+        lv = oracle.Norm1Function(oracle.LinearSystem((arg,)))
+    return policy, dynamics, value, lv
+
+
+class _LyapunovWithoutValues(oracle.Lyapunov):
+    """For timing samples of huge grids: skip the all_points value table (8.6 GB at 128^4)."""
+
+    def update_values(self):
+        self.values = None
+
+
+def oracle_lyapunov(case, compute_values=True):
+    grid = oracle.GridWorld(case['limits'], case['num_points'])
+    policy, dynamics, value, lv = oracle_specs(case)
+    cls = oracle.Lyapunov if compute_values else _LyapunovWithoutValues
+    return cls(grid, value, dynamics, case['lf'], lv, case['tau'], policy,
+               initial_set=initial_safe_mask(case) if compute_values else None)
+
+
+def oracle_cell_records(lyap, indices):
+    """Per-cell [decrease, threshold, mean[d], err[d]] of the oracle (same layout as the
+    engine's debug records)."""
+    states = lyap.discretization.index_to_state(indices)
+    actions = lyap.policy(states)
+    nxt = lyap.dynamics(states, actions)
+    decrease = lyap.v_decrease_bound(states, nxt)
+    threshold = lyap.threshold(states, lyap.tau)
+    if isinstance(nxt, tuple):
+        mean, err = nxt
+    else:
+        mean, err = nxt, np.zeros_like(nxt)
+    threshold = np.broadcast_to(threshold, decrease.shape)
+    return np.hstack((decrease, threshold, mean, err))

@@ -1,0 +1,88 @@
+// hostsim.cpp - TEST-ONLY host build of the per-cell arithmetic in safe_learning_amd/csrc/sl_model.h.
+//
+// The HIP kernels and this file include the very same header; compiling it with g++ lets the CPU
+// test-suite check index->state, policy, dynamics, V, L_v, threshold and decrease bit-for-bit
+// against the oracle without a GPU.  It is never imported by the product package.
+#include <cstring>
+#include "sl_model.h"
+
+static void make_model(const sl_model_desc* desc, SlDevModel* M) {
+    std::memset(M, 0, sizeof(*M));
+    M->m = *desc;
+    SlGridFast& gf = M->gf;
+    gf.d = desc->grid.d;
+    gf.all_pow2 = 1;
+    gf.nindex = 1;
+    for (int k = 0; k < gf.d; ++k) {
+        int64_t n = desc->grid.num_points[k];
+        gf.nindex *= n;
+        gf.num32[k] = (uint32_t)n;
+        if ((n & (n - 1)) == 0) { int s = 0; while ((1ll << s) < n) ++s; gf.shift[k] = s; }
+        else gf.all_pow2 = 0;
+    }
+    M->in_dim = desc->grid.d + desc->policy.m;
+    M->uncertain = 0;
+    const int lk = desc->lipschitz.lv_kind;
+    M->m.lipschitz.lv_cols = (lk == SL_LIP_CONST || lk == SL_LIP_NORM_LINEAR) ? 1 : desc->grid.d;
+}
+
+extern "C" {
+
+// deterministic-dynamics decrease check of cells [lo, hi): quadratic V, closed-form policy
+int hs_det_cells(const sl_model_desc* desc, int64_t lo, int64_t hi, double* values,
+                 uint8_t* negative, double* dbg) {
+    SlDevModel M;
+    make_model(desc, &M);
+    const SlDims n = sl_dims<0, 0>(M);
+    const int d = n.d;
+    for (int64_t idx = lo; idx < hi; ++idx) {
+        double x[SL_P], u[SL_M], nxt[SL_D], lv_x[SL_D], lv_n[SL_D], err[SL_D];
+        sl_index_to_state(M.m.grid, M.gf, d, idx, x);
+        sl_policy_closed_form(M, n, x, u);
+        sl_append_action(n, u, x);
+        sl_dynamics_det(M, n, x, nxt);
+        const double v_x = sl_quadratic(M.m.value, d, x);
+        const double v_n = sl_quadratic(M.m.value, d, nxt);
+        const double dec = sl_decrease(M, d, v_x, v_n, lv_n, err);
+        sl_lv(M, d, x, lv_x);
+        const double thr = sl_threshold(M, d, lv_x, M.m.lipschitz.tau);
+        values[idx - lo] = v_x;
+        negative[idx - lo] = dec < thr ? 1 : 0;
+        if (dbg) {
+            double* o = dbg + (idx - lo) * (2 + 2 * d);
+            o[0] = dec; o[1] = thr;
+            for (int k = 0; k < d; ++k) { o[2 + k] = nxt[k]; o[2 + d + k] = 0.0; }
+        }
+    }
+    return 0;
+}
+
+// piecewise-linear interpolation at explicit points
+int hs_tri_eval(const sl_grid_desc* grid, int nsimplex, const int32_t* simplices,
+                const double* hyper, const double* discrete_points, int project, int ncols,
+                const double* table, int64_t npts, const double* pts, int col, double* out,
+                double* grad) {
+    static SlTri t;
+    std::memset(&t, 0, sizeof(t));
+    t.grid = *grid;
+    t.nsimplex = nsimplex; t.project = project; t.ncols = ncols; t.set = 1;
+    const int d = grid->d;
+    for (int s = 0; s < nsimplex; ++s) {
+        for (int v = 0; v <= d; ++v) t.simplices[s][v] = simplices[s * (d + 1) + v];
+        for (int k = 0; k < d; ++k)
+            for (int j = 0; j < d; ++j) t.hyper[s][k][j] = hyper[(s * d + k) * d + j];
+    }
+    int64_t stride = 1, total = 0;
+    for (int k = d - 1; k >= 0; --k) { t.stride[k] = stride; stride *= grid->num_points[k]; }
+    for (int k = 0; k < d; ++k) { t.points_off[k] = (int32_t)total; total += grid->num_points[k]; }
+    t.points = discrete_points;
+    t.table = table;
+    for (int64_t i = 0; i < npts; ++i)
+        out[i] = sl_tri_eval(t, pts + i * d, col, grad ? grad + i * d : nullptr);
+    return 0;
+}
+
+uint64_t hs_vbits(double v) { return sl_vbits(v); }
+double hs_vbits_to_double(uint64_t b) { return sl_vbits_to_double(b); }
+
+}  // extern "C"

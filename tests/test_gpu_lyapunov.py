@@ -1,0 +1,348 @@
+"""Parity of the HIP engine with the oracle - the tests proper (need an MI355X).
+
+Everything goes through the C ABI (libslhip.so) via safe_learning_amd.  Bars:
+ * deterministic linear / quadratic pipeline: values, per-cell records and masks bit-exact;
+ * Euler dynamics (device sin/cos) and GP dynamics: records within RTOL_GP = 1e-9 relative
+   (requirement: 1e-5), masks equal except cells within rounding of the threshold;
+ * safe_set and c_max equal to the oracle's sequential prefix rule.
+"""
+
+import os
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+import cases
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+RTOL_GP = 1e-9      # north_star asks for 1e-5 relative on V and GP mean / var
+
+
+@pytest.fixture(scope="module")
+def sl():
+    import safe_learning_amd
+    return safe_learning_amd
+
+
+def _engine_records(lyap):
+    """Run the sweep with the debug record buffer: values, negative mask, [dec, thr, mean, err]."""
+    import torch
+    d = lyap.discretization.ndim
+    n = lyap._hi - lyap._lo
+    dbg = torch.zeros((n, 2 + 2 * d), dtype=torch.float64, device=lyap._ctx.torch_device)
+    lyap._upload_model()
+    lyap._refresh_init_bits()
+    lyap._ctx.lyap_sweep(lyap._lo, lyap._hi, lyap._d_init, lyap._d_values, lyap._d_neg,
+                         lyap._d_result, dbg)
+    bits = lyap._d_neg.cpu().numpy().view(np.uint8)
+    neg = np.unpackbits(bits, bitorder="little")[:n].astype(bool)
+    return lyap._d_values[:n].cpu().numpy(), neg, dbg.cpu().numpy()
+
+
+def _oracle_all(olyap, chunk=20000):
+    n = olyap.discretization.nindex
+    recs, negs = [], []
+    for s in range(0, n, chunk):
+        idx = np.arange(s, min(n, s + chunk))
+        recs.append(cases.oracle_cell_records(olyap, idx))
+        negs.append(olyap.negative(olyap.discretization.index_to_state(idx)))
+    return np.vstack(recs), np.concatenate(negs)
+
+
+def _check_masks(neg, ref_neg, rec, ref_rec, allowed=2):
+    differs = neg != ref_neg
+    margin = np.abs(ref_rec[:, 0] - ref_rec[:, 1])
+    scale = np.maximum(np.abs(ref_rec[:, 0]), np.abs(ref_rec[:, 1]))
+    assert not np.any(differs & (margin > 1e-9 * np.maximum(scale, 1e-300))), \
+        "negative mask differs away from the threshold"
+    assert differs.sum() <= allowed
+    return int(differs.sum()), float(np.min(margin / np.maximum(scale, 1e-300)))
+
+
+def _compare_safe_sets(lyap, olyap, flips):
+    lyap.update_safe_set()
+    olyap.update_safe_set()
+    if flips == 0:
+        assert_array_equal(lyap.safe_set, olyap.safe_set)
+        assert lyap.c_max == olyap.c_max or (np.isnan(lyap.c_max) and np.isnan(olyap.c_max))
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own known answers through the engine
+# ---------------------------------------------------------------------------------------------
+def test_reference_known_answers(sl, golden):
+    g = golden["lyapunov_update_safe_set"]
+    for case in g["cases"]:
+        grid = sl.GridWorld(g["limits"], g["num_points"])
+        lyap = sl.Lyapunov(grid, sl.QuadraticFunction([[1.0]]),
+                           sl.LinearSystem((np.array(g["dynamics_matrix"]),)), g["lf"], g["lv"],
+                           case["tau"], sl.LinearSystem((np.array([[g["policy_gain"]]]),)),
+                           initial_set=g["initial_set"])
+        lyap.update_safe_set()
+        assert_array_equal(lyap.safe_set, np.array(case["expected_safe_set"]))
+    g = golden["lyapunov_safe_set_init"]
+    grid = sl.GridWorld(g["limits"], g["num_points"])
+    lyap = sl.Lyapunov(grid, sl.QuadraticFunction(np.eye(2)),
+                       sl.LinearSystem((np.array(g["dynamics_matrix"]), np.zeros((2, 1)))),
+                       g["lf"], g["lv"], g["tau"], sl.LinearSystem((np.zeros((1, 2)),)),
+                       initial_set=g["initial_set"])
+    assert_array_equal(lyap.safe_set, np.array(g["expected_safe_set"]))
+    lyap0 = sl.Lyapunov(grid, sl.QuadraticFunction(np.eye(2)),
+                        sl.LinearSystem((np.array(g["dynamics_matrix"]), np.zeros((2, 1)))),
+                        g["lf"], g["lv"], g["tau"], sl.LinearSystem((np.zeros((1, 2)),)))
+    assert not lyap0.safe_set.any()
+
+
+def test_mfma_fragment_layout(sl):
+    """A(16x4) B(4x16) through v_mfma_f64_16x16x4_f64 with asymmetric operands."""
+    from safe_learning_amd import _hip
+    ctx = _hip.Context()
+    rng = np.random.default_rng(0)
+    a, b = rng.normal(size=(16, 4)), rng.normal(size=(4, 16))
+    assert_allclose(ctx.debug_mfma(a, b), a.dot(b), rtol=1e-14, atol=1e-14)
+    eye = np.zeros((16, 4)); eye[:4, :4] = np.eye(4)
+    assert_allclose(ctx.debug_mfma(eye, b)[:4], b, rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# deterministic dynamics
+# ---------------------------------------------------------------------------------------------
+DET_EXACT = [
+    ("1d", dict()),
+    ("1d", dict(tau_scale=0.0)),
+    ("1d", dict(num_points=64)),
+    ("1d", dict(num_points=65)),
+    ("pendulum", dict(num_points=33, dynamics="linear", tau_scale=0.0)),
+    ("pendulum", dict(num_points=[17, 40], dynamics="linear", tau_scale=0.02)),
+    ("pendulum", dict(num_points=128, dynamics="linear", tau_scale=0.0)),     # power-of-two path
+    ("cartpole", dict(num_points=8, dynamics="linear", tau_scale=0.0)),
+    ("cartpole", dict(num_points=[5, 6, 7, 9], dynamics="linear", tau_scale=0.01)),
+]
+
+
+@pytest.mark.parametrize("name,kw", DET_EXACT)
+def test_deterministic_bit_exact(sl, name, kw):
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case(name, **kw)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    assert_array_equal(lyap.values, olyap.values)
+    values, neg, rec = _engine_records(lyap)
+    ref_rec, ref_neg = _oracle_all(olyap)
+    assert_array_equal(values, olyap.values)
+    assert_array_equal(rec, ref_rec)
+    assert_array_equal(neg, ref_neg)                      # bit-exact mask (north_star)
+    _compare_safe_sets(lyap, olyap, 0)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("pendulum", dict(num_points=100, dynamics="analytic", tau_scale=0.0)),
+    ("pendulum", dict(num_points=100, dynamics="analytic", tau_scale=0.02)),
+    ("cartpole", dict(num_points=12, dynamics="analytic", tau_scale=0.0)),
+])
+def test_euler_dynamics(sl, name, kw):
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case(name, **kw)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    values, neg, rec = _engine_records(lyap)
+    ref_rec, ref_neg = _oracle_all(olyap)
+    assert_array_equal(values, olyap.values)
+    assert_allclose(rec, ref_rec, rtol=1e-11, atol=1e-14)
+    flips, _ = _check_masks(neg, ref_neg, rec, ref_rec)
+    _compare_safe_sets(lyap, olyap, flips)
+
+
+# ---------------------------------------------------------------------------------------------
+# GP dynamics (FP64 MFMA kernel), every kernel configuration
+# ---------------------------------------------------------------------------------------------
+GP_CASES = [
+    # (name, kwargs, SL_GP_CFG)                                  n_pad / panels exercised
+    ("pendulum", dict(num_points=40, n_gp=3, tau_scale=0.0), None),          # tiny n, cfg 0
+    ("pendulum", dict(num_points=64, n_gp=128, tau_scale=0.0), None),        # cfg 0, 2 panels
+    ("pendulum", dict(num_points=[33, 50], n_gp=200, tau_scale=0.02, noise_std=0.001), None),
+    ("cartpole", dict(num_points=8, n_gp=150, tau_scale=0.0), None),
+    ("cartpole", dict(num_points=6, n_gp=100, tau_scale=0.0, stack=True), None),   # FunctionStack
+    ("pendulum", dict(num_points=48, n_gp=600, tau_scale=0.0), "1"),        # cfg 1, 1 panel
+    ("pendulum", dict(num_points=48, n_gp=600, tau_scale=0.0), "2"),        # cfg 2, 2 panels
+    ("cartpole", dict(num_points=7, n_gp=1100, tau_scale=0.0), "1"),        # cfg 1, 2 panels
+    ("cartpole", dict(num_points=7, n_gp=520, tau_scale=0.0), "2"),         # cfg 2, 2 panels
+]
+
+
+@pytest.mark.parametrize("name,kw,cfg", GP_CASES)
+def test_gp_dynamics(sl, name, kw, cfg, monkeypatch):
+    from safe_learning_amd.benchmarks import build_lyapunov
+    if cfg is None:
+        monkeypatch.delenv("SL_GP_CFG", raising=False)
+    else:
+        monkeypatch.setenv("SL_GP_CFG", cfg)
+    case = cases.make_case(name, **kw)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    values, neg, rec = _engine_records(lyap)
+    ref_rec, ref_neg = _oracle_all(olyap)
+    d = case["d"]
+    assert_array_equal(values, olyap.values)
+    assert_allclose(rec[:, 2:2 + d], ref_rec[:, 2:2 + d], rtol=RTOL_GP, atol=1e-13)   # mean
+    assert_allclose(rec[:, 2 + d:], ref_rec[:, 2 + d:], rtol=1e-7, atol=1e-12)        # beta*sigma
+    var, ref_var = (rec[:, 2 + d:] / 2.0) ** 2, (ref_rec[:, 2 + d:] / 2.0) ** 2
+    assert_allclose(var, ref_var, rtol=1e-6, atol=1e-16)                              # variance
+    assert_allclose(rec[:, :2], ref_rec[:, :2], rtol=1e-7, atol=1e-12)
+    flips, _ = _check_masks(neg, ref_neg, rec, ref_rec)
+    _compare_safe_sets(lyap, olyap, flips)
+
+
+def test_gp_known_answer_through_engine(sl, golden):
+    """tests/test_functions.py:237-261 evaluated by the MFMA kernel (explicit points)."""
+    import torch
+    g = golden["gp_known_answer"]
+    grid = sl.GridWorld([[-4, 4], [-4, 4]], 5)
+    X, Y = np.array(g["X"], dtype=float), np.array(g["Y"], dtype=float)
+    # GP over (x0, x1): model it as 1 state + 1 action so that the engine's input is [x, u]
+    grid1 = sl.GridWorld([[-4, 4]], 5)
+    gp = sl.GPRCached(X, Y, sl.RBF(2), None)
+    dyn = sl.GaussianProcess(gp, g["beta"])
+    pts = np.array(g["test_points"], dtype=float)
+    for row, (mean_ref, err_ref) in enumerate(zip(g["expected_mean"], g["expected_error"])):
+        policy = sl.ConstantFunction([pts[row, 1]])
+        lyap = sl.Lyapunov(grid1, sl.QuadraticFunction([[1.0]]), dyn, 0.0, 1.0, 0.0, policy)
+        lyap._upload_model()
+        d_pts = torch.tensor([[pts[row, 0]]], dtype=torch.float64, device=lyap._ctx.torch_device)
+        out = torch.zeros((1, 4), dtype=torch.float64, device=lyap._ctx.torch_device)
+        lyap._ctx.eval_points(3, 1, d_pts, out)
+        rec = out.cpu().numpy()[0]
+        assert_allclose(rec[2], mean_ref[0], rtol=g["rtol"])
+        assert_allclose(rec[3], err_ref[0], rtol=g["rtol"])
+
+
+# ---------------------------------------------------------------------------------------------
+# prefix-rule semantics: batches, can_shrink=False, c_max quirks, ties
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture
+def small_batches(sl):
+    old = (sl.config.gp_batch_size, oracle.config.gp_batch_size)
+    sl.config.gp_batch_size = oracle.config.gp_batch_size = 100
+    yield 100
+    sl.config.gp_batch_size, oracle.config.gp_batch_size = old
+
+
+def test_can_shrink_false_and_batches(sl, small_batches):
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case("pendulum", num_points=50, dynamics="linear", tau_scale=0.02)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    rng = np.random.default_rng(3)
+    for step in range(4):
+        if step == 1:        # pretend earlier verification marked scattered far-away cells safe
+            extra = rng.choice(lyap.discretization.nindex, 300, replace=False)
+            lyap.safe_set[extra] = True
+            olyap.safe_set[extra] = True
+        if step == 2:        # a stricter threshold: the safe set may not shrink
+            lyap.tau = olyap.tau = case["tau"] * 4
+        if step == 3:
+            lyap.tau = olyap.tau = 0.0
+        lyap.update_safe_set(can_shrink=(step == 0))
+        olyap.update_safe_set(can_shrink=(step == 0))
+        assert_array_equal(lyap.safe_set, olyap.safe_set)
+        assert lyap.c_max == olyap.c_max
+
+
+def test_c_max_quirks(sl, small_batches):
+    from safe_learning_amd.benchmarks import build_lyapunov
+    # (a) nothing fails, several batches: c_max = value just before the last batch (lyapunov.py:590)
+    case = cases.make_case("pendulum", num_points=30, dynamics="linear", tau_scale=0.0)
+    case["K"] = case["K"] * 0.0
+    case["saturate"] = None
+    case["dynamics"] = {"kind": "linear", "matrix": np.hstack((0.5 * np.eye(2), np.zeros((2, 1))))}
+    case["initial_radius"] = 0.05          # the origin cell must be initial (decrease == 0 there)
+    num = case["num_points"]
+    case["num_points"] = [31, 31]          # odd: the origin is a grid point
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    lyap.update_safe_set(); olyap.update_safe_set()
+    assert olyap.safe_set.all()
+    assert_array_equal(lyap.safe_set, olyap.safe_set)
+    assert lyap.c_max == olyap.c_max
+    # (b) the very first cell fails: c_max = max(values)
+    case = cases.make_case("pendulum", num_points=20, dynamics="linear", tau_scale=50.0)
+    case["initial_radius"] = -1.0          # empty initial set
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    lyap.update_safe_set(); olyap.update_safe_set()
+    assert not olyap.safe_set.any()
+    assert_array_equal(lyap.safe_set, olyap.safe_set)
+    assert lyap.c_max == olyap.c_max == olyap.values.max()
+
+
+def test_ties_in_values(sl, small_batches):
+    """P = 0 in one direction: whole grid lines share a value; ties resolve by flat index."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case("pendulum", num_points=24, dynamics="linear", tau_scale=0.01)
+    case["P"] = np.array([[1.0, 0.0], [0.0, 0.0]])
+    case["lv"] = ("const", 0.05)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    for shrink in (True, False, False):
+        lyap.update_safe_set(can_shrink=shrink); olyap.update_safe_set(can_shrink=shrink)
+        assert_array_equal(lyap.safe_set, olyap.safe_set)
+        assert lyap.c_max == olyap.c_max
+        olyap.tau = lyap.tau = lyap.tau * 3
+
+
+def test_select_kth(sl):
+    import torch
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case("pendulum", num_points=37, dynamics="linear")
+    lyap = build_lyapunov(case)
+    rng = np.random.default_rng(5)
+    vals = rng.normal(size=lyap.discretization.nindex).round(1)          # many ties
+    vals[rng.choice(len(vals), 10)] = np.nan
+    vals[rng.choice(len(vals), 10)] = -0.0
+    lyap._d_values.copy_(torch.from_numpy(vals))
+    order = np.argsort(vals, kind="stable")
+    from safe_learning_amd.lyapunov import vbits_to_float
+    for k in [0, 1, 17, 500, len(vals) // 2, len(vals) - 11, len(vals) - 1]:
+        vbits, index = lyap._select_kth(k)
+        assert index == order[k]
+        got, ref = vbits_to_float(vbits), vals[order[k]]
+        assert (np.isnan(got) and np.isnan(ref)) or got == ref
+
+
+def test_bits_bytes_roundtrip(sl):
+    import torch
+    from safe_learning_amd import _hip
+    ctx = _hip.Context()
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 8, 63, 64, 65, 1000, 4099):
+        mask = rng.random(n) < 0.4
+        d_bytes = torch.from_numpy(mask.view(np.uint8)).to(ctx.torch_device)
+        d_bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=ctx.torch_device)
+        ctx.bytes_to_bits(n, d_bytes, d_bits)
+        ref = np.packbits(mask, bitorder="little")
+        got = d_bits.cpu().numpy().view(np.uint8)[:len(ref)]
+        assert_array_equal(got, ref)
+        out = torch.zeros(((n + 7) // 8) * 8, dtype=torch.uint8, device=ctx.torch_device)
+        ctx.bits_to_bytes(n, d_bits, out)
+        assert_array_equal(out.cpu().numpy()[:n].astype(bool), mask)
+
+
+def test_smallest_boundary_value(sl, golden):
+    g = golden["smallest_boundary_value"]
+    # the reference's literal uses 2*sum|x| (not representable as a spec); use a quadratic with
+    # the oracle as the checker on the same grid
+    grid = sl.GridWorld(g["limits"], g["num_points"])
+    P = np.array([[2.0, 0.3], [0.1, 1.0]])
+    got = sl.smallest_boundary_value(sl.QuadraticFunction(P), grid)
+    ref = oracle.smallest_boundary_value(oracle.QuadraticFunction(P),
+                                         oracle.GridWorld(g["limits"], g["num_points"]))
+    assert got == ref
+
+
+def test_errors_are_loud(sl):
+    from safe_learning_amd import _hip
+    grid = sl.GridWorld([[-1, 1]], 5)
+    with pytest.raises(TypeError):
+        sl.Lyapunov(grid, sl.QuadraticFunction([[1.0]]), sl.LinearSystem((np.array([[1., 1.]]),)),
+                    0.4, lambda x: x, 0.1, sl.LinearSystem((np.array([[-0.1]]),)))
+    with pytest.raises(sl.DimensionError):
+        sl.GridWorld([[0, 1]], 1)
+    ctx = _hip.Context()
+    with pytest.raises(_hip.HipEngineError):
+        ctx.values(0, 10, None)                        # model not set

@@ -1,0 +1,208 @@
+"""CPU check of the kernels' per-cell arithmetic (safe_learning_amd/csrc/sl_model.h).
+
+The header is compiled with g++ into a test-only shim (tests/hostsim) and compared with the
+oracle: bit-for-bit for the linear / quadratic pipeline (canonical arithmetic), to rounding for
+the Euler dynamics (libm sin/cos differ from NumPy's by an ulp).  The GPU tests repeat the same
+comparisons through the real kernels.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+import cases
+import oracle
+from conftest import ROOT, GOLDEN_DIR
+from safe_learning_amd import _hip
+from safe_learning_amd import functions as F
+from safe_learning_amd._model import ModelBuilder
+from safe_learning_amd.benchmarks import build_specs
+
+
+class _RecordingCtx(object):
+    """Captures the model description instead of uploading it (no GPU needed)."""
+    torch_device = None
+
+    def model_set(self, desc):
+        self.desc = desc
+
+
+@pytest.fixture(scope="module")
+def hostsim():
+    src = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
+    lib = os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
+    deps = [src, os.path.join(ROOT, "safe_learning_amd", "csrc", "sl_model.h"),
+            os.path.join(ROOT, "include", "sl_hip.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                               "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "safe_learning_amd", "csrc"),
+                               "-o", lib, src])
+    h = C.CDLL(lib)
+    h.hs_vbits.restype = C.c_uint64
+    h.hs_vbits.argtypes = [C.c_double]
+    h.hs_vbits_to_double.restype = C.c_double
+    h.hs_vbits_to_double.argtypes = [C.c_uint64]
+    return h
+
+
+def _describe(case):
+    grid = F.GridWorld(case['limits'], case['num_points'])
+    policy, dynamics, value, lv = build_specs(case)
+    ctx = _RecordingCtx()
+    ModelBuilder(ctx, grid).upload(policy, dynamics, value, lv, case['lf'], case['tau'])
+    return grid, ctx.desc
+
+
+def _run(hostsim, case):
+    grid, desc = _describe(case)
+    n, d = grid.nindex, grid.ndim
+    values = np.zeros(n)
+    negative = np.zeros(n, dtype=np.uint8)
+    dbg = np.zeros((n, 2 + 2 * d))
+    rc = hostsim.hs_det_cells(C.byref(desc), C.c_int64(0), C.c_int64(n),
+                              values.ctypes.data_as(C.c_void_p), negative.ctypes.data_as(C.c_void_p),
+                              dbg.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return values, negative.astype(bool), dbg
+
+
+CASES_EXACT = [
+    ("1d", dict()),
+    ("1d", dict(tau_scale=0.0)),
+    ("1d", dict(num_points=3)),
+    ("pendulum", dict(num_points=33, dynamics="linear", tau_scale=0.0)),
+    ("pendulum", dict(num_points=[17, 40], dynamics="linear", tau_scale=0.02)),
+    ("cartpole", dict(num_points=8, dynamics="linear", tau_scale=0.0)),
+    ("cartpole", dict(num_points=[5, 6, 7, 9], dynamics="linear", tau_scale=0.01)),
+]
+
+
+@pytest.mark.parametrize("name,kw", CASES_EXACT)
+def test_linear_pipeline_bit_exact(hostsim, name, kw):
+    case = cases.make_case(name, **kw)
+    values, negative, dbg = _run(hostsim, case)
+    lyap = cases.oracle_lyapunov(case)
+    idx = np.arange(lyap.discretization.nindex)
+    rec = cases.oracle_cell_records(lyap, idx)
+    assert_array_equal(values, lyap.values)                       # V(x) bit for bit
+    assert_array_equal(dbg, rec)                                  # decrease, threshold, f(x)
+    assert_array_equal(negative, lyap.negative(lyap.discretization.index_to_state(idx)))
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("pendulum", dict(num_points=40, dynamics="analytic", tau_scale=0.0)),
+    ("pendulum", dict(num_points=40, dynamics="analytic", tau_scale=0.02)),
+    ("cartpole", dict(num_points=9, dynamics="analytic", tau_scale=0.0)),
+])
+def test_euler_dynamics(hostsim, name, kw):
+    case = cases.make_case(name, **kw)
+    values, negative, dbg = _run(hostsim, case)
+    lyap = cases.oracle_lyapunov(case)
+    idx = np.arange(lyap.discretization.nindex)
+    rec = cases.oracle_cell_records(lyap, idx)
+    assert_array_equal(values, lyap.values)
+    assert_allclose(dbg, rec, rtol=1e-12, atol=1e-15)
+    ref_neg = lyap.negative(lyap.discretization.index_to_state(idx))
+    margin = np.abs(rec[:, 0] - rec[:, 1])
+    differs = negative != ref_neg
+    # a flipped bit is only acceptable if the cell sits within rounding of the threshold
+    assert not np.any(differs & (margin > 1e-12 * np.maximum(1.0, np.abs(rec[:, 1]))))
+    assert differs.sum() <= 2
+
+
+def test_vbits_order(hostsim):
+    rng = np.random.default_rng(0)
+    v = np.concatenate([rng.normal(size=200), [0.0, -0.0, np.inf, -np.inf, 1e-310, -1e-310, np.nan]])
+    bits = np.array([hostsim.hs_vbits(float(x)) for x in v], dtype=np.uint64)
+    order_bits = np.argsort(bits, kind="stable")
+    order_val = np.argsort(v, kind="stable")          # NaN last, -0 == +0
+    assert_array_equal(order_bits, order_val)
+    back = np.array([hostsim.hs_vbits_to_double(int(b)) for b in bits])
+    assert_array_equal(np.isnan(back), np.isnan(v))
+    assert_array_equal(back[~np.isnan(v)], np.where(v[~np.isnan(v)] == 0, 0.0, v[~np.isnan(v)]))
+
+
+def _tri_eval(hostsim, tri, points, col=0, want_grad=False):
+    grid = tri.discretization
+    desc = grid._desc()
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    out = np.zeros(len(pts))
+    grad = np.zeros((len(pts), grid.ndim)) if want_grad else None
+    simp = np.ascontiguousarray(tri.unit_simplex_codes, dtype=np.int32)
+    hyper = np.ascontiguousarray(tri.hyperplanes)
+    dp = np.ascontiguousarray(np.concatenate(grid.discrete_points))
+    table = np.ascontiguousarray(tri.parameters)
+    rc = hostsim.hs_tri_eval(C.byref(desc), len(simp), simp.ctypes.data_as(C.c_void_p),
+                             hyper.ctypes.data_as(C.c_void_p), dp.ctypes.data_as(C.c_void_p),
+                             int(tri.project), table.shape[1], table.ctypes.data_as(C.c_void_p),
+                             C.c_int64(len(pts)), pts.ctypes.data_as(C.c_void_p), col,
+                             out.ctypes.data_as(C.c_void_p),
+                             grad.ctypes.data_as(C.c_void_p) if want_grad else None)
+    assert rc == 0
+    return (out, grad) if want_grad else out
+
+
+@pytest.mark.parametrize("limits,num,project", [
+    ([[0, 1]], [3], False),
+    ([[-1, 1], [-1, 2]], [3, 7], False),
+    ([[-1, 1], [-1, 2]], [3, 7], True),
+    ([[0, 1]] * 3, [4, 3, 5], True),
+    ([[-1, 1]] * 4, [4, 5, 3, 4], True),
+    ([[-1, 1]] * 4, [4, 5, 3, 4], False),
+])
+def test_triangulation_matches_oracle(hostsim, limits, num, project):
+    rng = np.random.default_rng(1)
+    grid = F.GridWorld(limits, num)
+    values = rng.normal(size=(grid.nindex, 1))
+    tri = F.Triangulation(grid, values, project=project)
+    ogrid = oracle.GridWorld(limits, num)
+    otri = oracle.Triangulation(ogrid, values, project=project)
+    span = np.diff(grid.limits, axis=1).T
+    pts = [grid.all_points,                                          # vertices
+           rng.uniform(0, 1, (400, grid.ndim)) * span + grid.offset]
+    if project:
+        # outside points: only with projection - without it the reference extrapolates with
+        # whichever unit-cell simplex Qhull's walk returns for a point on a shared vertex
+        pts.append(rng.uniform(-0.3, 1.3, (100, grid.ndim)) * span + grid.offset)
+    pts = np.vstack(pts)
+    got = _tri_eval(hostsim, tri, pts)
+    assert_allclose(got[:, None], otri(pts), rtol=1e-10, atol=1e-12)
+
+
+def test_triangulation_golden_cases(hostsim, golden):
+    """The reference's own literal cases through the kernel code path."""
+    g = golden["triangulation_1d"]
+    tri = F.Triangulation(F.GridWorld(g["limits"], g["num_points"]), g["vertex_values"])
+    pts = np.array(g["test_points"], dtype=float)
+    val, grad = _tri_eval(hostsim, tri, pts, want_grad=True)
+    assert_allclose(val[:, None], g["expected_values"], atol=1e-15)
+    interior = [1, 3, 4]                                             # away from the kinks
+    assert_allclose(grad[interior], np.array(g["expected_gradient"])[interior])
+
+    g = golden["triangulation_values"]
+    p = g["projection"]
+    grid = F.GridWorld(g["limits"], g["num_points"])
+    tri = F.Triangulation(grid, p["parameters"])
+    assert_allclose(_tri_eval(hostsim, tri, np.array(p["point"])), np.ravel(p["unprojected"]))
+    tri.project = True
+    assert_allclose(_tri_eval(hostsim, tri, np.array(p["point"])), np.ravel(p["projected"]))
+
+    g = golden["triangulation_3d"]
+    grid = F.GridWorld(g["limits"], g["num_points"])
+    tri = F.Triangulation(grid, np.sum(grid.index_to_state(np.arange(8)), axis=1) / 3)
+    assert tri.nsimplex == g["nsimplex"]
+    assert_allclose(_tri_eval(hostsim, tri, np.array(g["test_points"], dtype=float)),
+                    g["expected"], atol=g["atol"])
+
+    g = golden["triangulation_gradient"]
+    grid = F.GridWorld(g["limits"], g["num_points"])
+    values = np.zeros(grid.nindex)
+    values[grid.state_to_index(np.array(g["node_states"], dtype=float))] = g["node_values"]
+    tri = F.Triangulation(grid, values)
+    _, grad = _tri_eval(hostsim, tri, np.array(g["test_points"]), want_grad=True)
+    assert_allclose(grad, g["expected_gradient"])
