@@ -167,19 +167,22 @@ int  sl_network_set(sl_ctx* ctx, int nlayers, const int32_t* h_dims /* nlayers+1
                     const int32_t* h_activations, const double* h_kernels);
 
 /* ---- Lyapunov passes ------------------------------------------------------------------- */
-/* values[i-lo] = V(x_i), i in [lo,hi).  Replaces Lyapunov.update_values (lyapunov.py:305-322). */
+/* values[i-lo] = V(all_points[i]), i in [lo,hi): the points of functions.py:622-638 (np.linspace:
+ * the last point of each dimension is exactly the upper limit).  Replaces
+ * Lyapunov.update_values (lyapunov.py:305-322). */
 int  sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values);
 
 /* Decrease check of every cell i in [lo,hi) (lo % 64 == 0): policy -> dynamics ->
  * V(f(x)) - V(x) + L_v.err < -|L_v|_1 (1 + L_f) tau  (lyapunov.py:436-441, 265-288, 324-376).
  * Replaces the batch loop lyapunov.py:524-587.
  *   d_init_bits   in  (may be NULL) cells that count as safe without a check
- *   d_values      out V(x_i)                                  (may be NULL)
+ *   d_values      in  V on the grid from sl_values: the ordering keys of lyapunov.py:512
+ *                     (may be NULL: the V(x_i) computed for the decrease is used instead)
  *   d_neg_bits    out the `negative` mask
  *   d_result      out ->fail = lexmin over failing cells (other fields untouched)
  *   d_dbg         out (may be NULL) per cell [decrease, threshold, mean[d], err[d]] */
 int  sl_lyap_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
-                   double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
+                   const double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
                    double* d_dbg);
 
 /* safe_i = init_i | (key_i < key_star) | (prev_i & key_i >= key_keep), the parallel form of
@@ -207,7 +210,8 @@ int  sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uint64_t* 
  * n_actions == 0: u = policy(x_i) (value_iteration, :135-140).
  * n_actions  > 0: u_a = h_actions[a] (row-major [n_actions][m]); writes max_a q and the first
  *                 arg-max (discrete_policy_optimization, :266-279); d_q (may be NULL) gets all q.
- *   d_v_new [hi-lo], d_argmax [hi-lo] (may be NULL), d_stats[2] = {max|v_new - v_old|, sum (v_new - v_old)^2}. */
+ *   d_v_new [hi-lo], d_argmax [hi-lo] (may be NULL), d_stats[2] = {max_i |v_new_i - table_i|,
+ *   sum_i (v_new_i - V(x_i))^2} with V(x_i) interpolated as in reinforcement_learning.py:130-133. */
 int  sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const double* h_actions,
                       double* d_v_new, int32_t* d_argmax, double* d_q, double* d_stats);
 
@@ -225,8 +229,9 @@ int  sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_points /* 
 /* ---- diagnostics -------------------------------------------------------------------------- */
 /* D = A(16x4) * B(4x16) through v_mfma_f64_16x16x4_f64 with this library's fragment maps. */
 int  sl_debug_mfma(sl_ctx* ctx, const double* h_a, const double* h_b, double* h_d);
-/* Sustained FP64 rate probes, TFLOP/s: which = 0 MFMA, 1 VALU FMA, 2 both interleaved. */
-int  sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_tflops);
+/* Sustained FP64 rate probes: which = 0 MFMA, 1 VALU FMA, 2 both interleaved.
+ * h_out[3] = {TFLOP/s, sustained shader clock in MHz, shader cycles per MFMA slot per SIMD}. */
+int  sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_out);
 
 #ifdef __cplusplus
 }

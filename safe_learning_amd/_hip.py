@@ -286,10 +286,10 @@ class Context(object):
         return out
 
     def debug_fp64_rate(self, which, iters=20000):
-        out = C.c_double(0.0)
-        self.check(self.lib.sl_debug_fp64_rate(self.handle, which, iters, C.byref(out)),
+        out = (C.c_double * 3)()
+        self.check(self.lib.sl_debug_fp64_rate(self.handle, which, iters, out),
                    "sl_debug_fp64_rate")
-        return out.value
+        return {"tflops": out[0], "shader_mhz": out[1], "cycles_per_slot": out[2]}
 
 
 _default_context = None

@@ -50,17 +50,10 @@ class ModelBuilder(object):
                 pd.constant[a] = float(inner.constant[a])
         elif isinstance(inner, Triangulation):
             m = inner.output_dim
-            same_grid = (inner.discretization is self.grid or (
-                np.array_equal(inner.discretization.num_points, self.grid.num_points) and
-                np.array_equal(inner.discretization.limits, self.grid.limits)))
-            if same_grid:
-                # a vertex table evaluated at its own vertices is the table itself
-                pd.kind = _hip.POLICY_TABLE
-                self._policy_table = inner._device(self.ctx)
-                pd.d_table = self._policy_table.data_ptr()
-            else:
-                pd.kind = _hip.POLICY_TRI
-                self._upload_tri(1, inner)
+            # evaluated by interpolation even on its own grid, exactly like the reference
+            # (policy(states) in reinforcement_learning.py:92 / lyapunov.py:436)
+            pd.kind = _hip.POLICY_TRI
+            self._upload_tri(1, inner)
         elif isinstance(inner, np.ndarray):
             table = np.ascontiguousarray(inner, dtype=np.float64).reshape(self.grid.nindex, -1)
             m = table.shape[1]

@@ -165,10 +165,14 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
         }
         v_new[idx - lo] = best_q;
         if (argmax) argmax[idx - lo] = best_a;
+        // stats[0]: max |V_new - V_old| on the vertex table (convergence test of the examples);
+        // stats[1]: sum (target - V(x))^2 with V(x) interpolated like the reference does
+        //           (reinforcement_learning.py:130-133)
         double v_old = vt.table[idx * vt.ncols];
-        if (M.m.value.negate) v_old = v_old * -1.0;
-        const double diff = best_q - v_old;
-        lmax = fmax(lmax, fabs(diff));
+        double v_int = sl_tri_eval(vt, x, 0, nullptr);
+        if (M.m.value.negate) { v_old = v_old * -1.0; v_int = v_int * -1.0; }
+        lmax = fmax(lmax, fabs(best_q - v_old));
+        const double diff = best_q - v_int;
         lsum = fma(diff, diff, lsum);
     }
     // ---- residual statistics ----------------------------------------------------------------------
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_eval_simple(const SlDevModel M, Sl
 }
 
 int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
-                 double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
+                 const double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
                  double* d_dbg, const double* d_points);
 
 extern "C" int sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_points,

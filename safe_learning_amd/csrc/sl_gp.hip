@@ -41,7 +41,7 @@ static inline int cfg_panel_rows(int cfg) { return 16 * kCfgR[cfg] * kCfgW[cfg];
 template <int W, int R, int CB, bool GENERAL, int DT, int MT>
 __global__ __launch_bounds__(W * 64) void k_gp_sweep(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
-    const uint64_t* __restrict__ init_bits, double* __restrict__ values,
+    const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
     int xs_doubles, const double* __restrict__ points) {
     constexpr int C = 16 * CB;
@@ -287,8 +287,7 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
             }
             SlCellCheck c = sl_cell_check<GENERAL>(M, d, aux, x, mean, err);
             negative = c.negative;
-            v_x = c.v_x;
-            if (values) values[idx - lo] = v_x;
+            v_x = values ? values[idx - lo] : c.v_x;       // ordering key: lyapunov.py:512
             if (dbg) {
                 double* o = dbg + (idx - lo) * (2 + 2 * d);
                 o[0] = c.decrease; o[1] = c.threshold;
@@ -325,7 +324,7 @@ static int choose_cfg(int n) {
     const char* env = getenv("SL_GP_CFG");
     if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
     if (n <= 256) return 0;
-    return 1;
+    return 2;        // 64-cell tiles: half the Linv traffic per MFMA of cfg 1, measured fastest
 }
 
 extern "C" int sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
@@ -425,7 +424,7 @@ extern "C" int sl_gp_configure(sl_ctx* ctx, int nheads, double beta) {
 
 template <int W, int R, int CB, bool GENERAL, int DT, int MT>
 static int launch_cfg(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
-                      double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
+                      const double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
                       const double* d_points) {
     constexpr int C = 16 * CB;
     const int64_t nwords = (hi - lo + 63) / 64;
@@ -460,7 +459,7 @@ static int launch_cfg(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_ini
 }
 
 int sl_gp_sweep_launch(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
-                       double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
+                       const double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
                        const double* d_points) {
     if (ctx->h_gp.nheads < 1)
         return sl_fail(ctx, SL_ERR_INVALID, "GP dynamics selected but sl_gp_configure not called");
@@ -530,14 +529,16 @@ extern "C" int sl_debug_mfma(sl_ctx* ctx, const double* h_a, const double* h_b, 
     return SL_OK;
 }
 
-// FP64 rate probes: which = 0 MFMA only, 1 VALU FMA only, 2 both in the same wavefront
+// FP64 rate probes: which = 0 MFMA only, 1 VALU FMA only, 2 both in the same wavefront.
+// Also reports the shader clock actually sustained (s_memtime ticks / s_memrealtime ticks).
 template <int WHICH>
-__global__ __launch_bounds__(256) void k_fp64_rate(int iters, double* sink) {
+__global__ __launch_bounds__(256) void k_fp64_rate(int iters, double* sink, long long* clocks) {
     sl_d4 acc[8];
     double v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { acc[k] = (sl_d4){0.0, 0.0, 0.0, 0.0}; v[k] = threadIdx.x * 1e-3 + k; }
     const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    const long long c0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -551,34 +552,44 @@ __global__ __launch_bounds__(256) void k_fp64_rate(int iters, double* sink) {
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += acc[k].x + acc[k].y + acc[k].z + acc[k].w + v[k];
+    const long long c1 = clock64(), w1 = wall_clock64();
     if (s == 12345.678) sink[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
 }
 
-extern "C" int sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_tflops) {
-    if (!ctx || !h_tflops || which < 0 || which > 2 || iters < 1)
+extern "C" int sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_out) {
+    if (!ctx || !h_out || which < 0 || which > 2 || iters < 1)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_debug_fp64_rate: bad argument");
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const char* env = getenv("SL_PROBE_BLOCKS_PER_CU");
+    const int per_cu = (env && env[0] >= '1' && env[0] <= '8') ? env[0] - '0' : 2;
     double* sink;
+    long long* clocks;
     SL_HIP_CHECK(ctx, hipMalloc(&sink, sizeof(double)));
+    SL_HIP_CHECK(ctx, hipMalloc(&clocks, 2 * sizeof(long long)));
     hipEvent_t e0, e1;
     SL_HIP_CHECK(ctx, hipEventCreate(&e0));
     SL_HIP_CHECK(ctx, hipEventCreate(&e1));
-    const int blocks = ctx->num_cu * 2;          // 8 wavefronts per CU = 2 per SIMD
+    const int blocks = ctx->num_cu * per_cu;     // per_cu blocks of 4 wavefronts per CU
     for (int rep = 0; rep < 2; ++rep) {
         SL_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
-        if (which == 0) hipLaunchKernelGGL(k_fp64_rate<0>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink);
-        else if (which == 1) hipLaunchKernelGGL(k_fp64_rate<1>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink);
-        else hipLaunchKernelGGL(k_fp64_rate<2>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink);
+        if (which == 0) hipLaunchKernelGGL(k_fp64_rate<0>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
+        else if (which == 1) hipLaunchKernelGGL(k_fp64_rate<1>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
+        else hipLaunchKernelGGL(k_fp64_rate<2>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
         SL_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
         SL_HIP_CHECK(ctx, hipEventSynchronize(e1));
     }
     float ms = 0.f;
     SL_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    long long hc[2] = {0, 0};
+    SL_HIP_CHECK(ctx, hipMemcpy(hc, clocks, sizeof(hc), hipMemcpyDeviceToHost));
     const double waves = (double)blocks * 4.0;
     double flops = 0.0;
     if (which != 1) flops += waves * (double)iters * 8.0 * (2.0 * 16 * 16 * 4);
     if (which != 0) flops += waves * (double)iters * 8.0 * 16.0 * 64.0 * 2.0;
-    *h_tflops = flops / (ms * 1e-3) / 1e12;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+    h_out[0] = flops / (ms * 1e-3) / 1e12;                       // TFLOP/s
+    h_out[1] = hc[1] > 0 ? 100.0 * (double)hc[0] / (double)hc[1] : 0.0;   // shader MHz (100 MHz ref)
+    h_out[2] = (double)hc[0] / ((double)iters * 8.0 * per_cu);   // shader cycles per MFMA (or per 16 FMA) slot per SIMD
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink); (void)hipFree(clocks);
     return SL_OK;
 }

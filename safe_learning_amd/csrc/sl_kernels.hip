@@ -311,7 +311,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_values(const SlDevModel M, SlAux a
     for (int64_t idx = lo + (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; idx < hi;
          idx += (int64_t)gridDim.x * SL_BLOCK) {
         double x[SL_P];
-        sl_index_to_state(M.m.grid, M.gf, n.d, idx, x);
+        sl_index_to_grid_point(M.m.grid, M.gf, n.d, idx, x);
         values[idx - lo] = sl_value_any<GENERAL>(M, n.d, aux, x);
     }
 }
@@ -340,8 +340,8 @@ extern "C" int sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values) 
 template <bool GENERAL, int DT, int MT>
 __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
     const SlDevModel M, SlAux aux, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
-    double* __restrict__ values, uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials,
-    double* __restrict__ dbg, const double* __restrict__ points) {
+    const double* __restrict__ values, uint64_t* __restrict__ neg_bits,
+    sl_key* __restrict__ partials, double* __restrict__ dbg, const double* __restrict__ points) {
     __shared__ uint64_t sv[SL_BLOCK / 64];
     __shared__ int64_t si[SL_BLOCK / 64];
     const SlDims n = sl_dims<DT, MT>(M);
@@ -363,8 +363,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
             sl_dynamics_det(M, n, x, nxt);
             SlCellCheck c = sl_cell_check<GENERAL>(M, d, aux, x, nxt, err);
             negative = c.negative;
-            v_x = c.v_x;
-            if (values) values[idx - lo] = v_x;
+            v_x = values ? values[idx - lo] : c.v_x;       // ordering key: lyapunov.py:512
             if (dbg) {
                 double* o = dbg + (idx - lo) * (2 + 2 * d);
                 o[0] = c.decrease; o[1] = c.threshold;
@@ -399,12 +398,12 @@ __global__ __launch_bounds__(SL_BLOCK) void k_reduce_fail(const sl_key* __restri
 }
 
 int sl_gp_sweep_launch(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
-                       double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
+                       const double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
                        const double* d_points);
 
 // shared by sl_lyap_sweep (grid cells) and sl_eval_points (explicit points)
 int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
-                 double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
+                 const double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
                  double* d_dbg, const double* d_points) {
     int rc = sl_check_ready(ctx, "sl_lyap_sweep");
     if (rc) return rc;
@@ -440,8 +439,8 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
 }
 
 extern "C" int sl_lyap_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
-                             double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
-                             double* d_dbg) {
+                             const double* d_values, uint64_t* d_neg_bits,
+                             sl_sweep_result* d_result, double* d_dbg) {
     return sl_sweep_any(ctx, lo, hi, d_init_bits, d_values, d_neg_bits, d_result, d_dbg, nullptr);
 }
 

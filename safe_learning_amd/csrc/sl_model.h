@@ -108,6 +108,23 @@ SL_HD void sl_index_to_state(const sl_grid_desc& g, const SlGridFast& f, int d, 
     }
 }
 
+// functions.py:612-638 (all_points): np.linspace makes the last point of every dimension exactly
+// `upper`; the other points equal ijk * unit_maxes + offset.  Lyapunov.update_values evaluates V on
+// these points (lyapunov.py:321), the verification loop on index_to_state (lyapunov.py:525).
+SL_HD void sl_index_to_grid_point(const sl_grid_desc& g, const SlGridFast& f, int d, int64_t idx,
+                                  double* x) {
+    int64_t ijk[SL_D];
+    sl_unravel(g, f, d, idx, ijk);
+#pragma unroll
+    for (int k = 0; k < SL_D; ++k) {
+        if (k < d) {
+            double t = (double)ijk[k] * g.unit_maxes[k];
+            t = t + g.offset[k];
+            x[k] = (ijk[k] == g.num_points[k] - 1) ? g.upper[k] : t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // small ordered linear algebra: out[j] = ((z0*M[j][0] + z1*M[j][1]) + ...) rows = outputs
 // ---------------------------------------------------------------------------------------------

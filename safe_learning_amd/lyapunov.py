@@ -274,7 +274,6 @@ class Lyapunov(object):
         if events is not None:
             stop.record()
             events.append((start, stop))
-        self._values_host = None
         res = self._read_result()
         star = dist_utils.allreduce_key(self._u64(res[_hip.R_FAIL_V]), res[_hip.R_FAIL_I], 'min',
                                         ctx.torch_device)

@@ -11,8 +11,10 @@ from safe_learning_amd.benchmarks import build_lyapunov, make_case
 
 out = {}
 ctx = _hip.Context()
-for which, name in ((0, "mfma_f64"), (1, "valu_fma_f64"), (2, "both")):
-    out["rate_" + name] = ctx.debug_fp64_rate(which, 20000)
+for per_cu in ("1", "2", "4"):
+    os.environ["SL_PROBE_BLOCKS_PER_CU"] = per_cu
+    for which, name in ((0, "mfma_f64"), (1, "valu_fma_f64"), (2, "both")):
+        out["rate_%s_x%s" % (name, per_cu)] = ctx.debug_fp64_rate(which, 20000)
 print(out, flush=True)
 
 def time_sweep(family, num_points, n_gp, cfg, reps=3):
