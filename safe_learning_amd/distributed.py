@@ -64,6 +64,16 @@ def allreduce_key(vbits, index, op, device):
     return min(keys) if op == 'min' else max(keys)
 
 
+def allreduce_int(value, device):
+    """SUM of one Python int across ranks."""
+    if not is_distributed():
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    allreduce_sum_(t)
+    return int(t[0])
+
+
 def allreduce_sum_(tensor):
     """In-place SUM all-reduce of an integer / float tensor."""
     if is_distributed():

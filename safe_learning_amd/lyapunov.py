@@ -213,34 +213,6 @@ class Lyapunov(object):
     def _read_result(self):
         return [int(v) for v in self._d_result.cpu().numpy().view(np.int64)]
 
-    @staticmethod
-    def _u64(v):
-        return v & _U64_MAX
-
-    def _select_kth(self, k):
-        """``(vbits, index)`` of the k-th smallest key (0-based) over the whole grid: two 8-pass
-        radix selects (value bytes, then index bytes among equal values)."""
-        lo, hi = self._lo, self._hi
-
-        def run(which, vbits_equal, rank_in):
-            prefix, remaining = 0, rank_in
-            for byte in range(7, -1, -1):
-                self._d_hist.zero_()
-                self._ctx.select_pass(lo, hi, self._d_values, which, byte, prefix, vbits_equal,
-                                      self._d_hist)
-                dist_utils.allreduce_sum_(self._d_hist)
-                hist = self._d_hist.cpu().numpy()
-                cum = np.cumsum(hist)
-                digit = int(np.searchsorted(cum, remaining, side='right'))
-                if digit > 0:
-                    remaining -= int(cum[digit - 1])
-                prefix |= digit << (8 * byte)
-            return prefix, remaining
-
-        vbits, rank_among_equal = run(0, 0, k)
-        index, _ = run(1, vbits, rank_among_equal)
-        return vbits, index
-
     # ---- reference methods ---------------------------------------------------------------
     def update_values(self):
         """Recompute V on the grid (``lyapunov.py:305-322``)."""
@@ -251,70 +223,110 @@ class Lyapunov(object):
     def update_safe_set(self, can_shrink=True, max_refinement=1, safety_factor=1.,
                         parallel_iterations=1):
         """Recompute the safe set (``lyapunov.py:407-606``, non-adaptive branch)."""
-        ctx, lo, hi = self._ctx, self._lo, self._hi
-        n = self.discretization.nindex
-        batch = int(config.gp_batch_size)
         self._upload_model()
         self._refresh_init_bits()
+        if not can_shrink and not self._safe_dev_valid:          # lyapunov.py:507-510
+            self._upload_mask(self._safe_host, self._d_safe)
+        engine = _HipShardEngine(self)
+        self.c_max = prefix_rule(engine, self.discretization.nindex, int(config.gp_batch_size),
+                                 can_shrink, self._ctx.torch_device)
+        self._safe_host_valid = False
+        self._safe_dev_valid = True
 
-        if can_shrink:
-            d_prior = self._d_init                     # lyapunov.py:500-506
-        else:                                          # lyapunov.py:507-510
-            if not self._safe_dev_valid:
-                self._upload_mask(self._safe_host, self._d_safe)
-            d_prior = self._d_safe.clone()
 
-        # decrease check of every cell + lexmin of the failing (V, index) keys
-        events = getattr(self, 'sweep_events', None)
+class _HipShardEngine(object):
+    """This rank's shard of the grid as the prefix rule sees it (all work in HIP kernels)."""
+
+    def __init__(self, lyap):
+        self.lyap = lyap
+        self.prior = None
+
+    def sweep(self, can_shrink):
+        """Decrease check of every cell; returns the local lexmin failing ``(vbits, index)``."""
+        ly = self.lyap
+        self.prior = ly._d_init if can_shrink else ly._d_safe.clone()     # lyapunov.py:500-510
+        events = getattr(ly, 'sweep_events', None)
         if events is not None:                      # bench.py: HIP events on the kernel's stream
             import torch
             start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
-        ctx.lyap_sweep(lo, hi, d_prior, self._d_values, self._d_neg, self._d_result)
+        ly._ctx.lyap_sweep(ly._lo, ly._hi, self.prior, ly._d_values, ly._d_neg, ly._d_result)
         if events is not None:
             stop.record()
             events.append((start, stop))
-        res = self._read_result()
-        star = dist_utils.allreduce_key(self._u64(res[_hip.R_FAIL_V]), res[_hip.R_FAIL_I], 'min',
-                                        ctx.torch_device)
+        res = ly._read_result()
+        return res[_hip.R_FAIL_V] & _U64_MAX, res[_hip.R_FAIL_I]
 
-        # first pass of the prefix rule: everything below key* is safe
-        ctx.lyap_finalize(lo, hi, self._d_values, self._d_init, None, star, _KEY_NONE,
-                          self._d_safe, self._d_result)
-        res = self._read_result()
-        below = self._allreduce_int(res[_hip.R_BELOW])
-        last_safe = dist_utils.allreduce_key(self._u64(res[_hip.R_LAST_V]), res[_hip.R_LAST_I],
-                                             'max', ctx.torch_device)
-        max_key = dist_utils.allreduce_key(self._u64(res[_hip.R_MAX_V]), res[_hip.R_MAX_I], 'max',
-                                           ctx.torch_device)
-        failed = star != _KEY_NONE
+    def finalize(self, star, keep, use_prior):
+        """``safe = init | key < star | (prior & key >= keep)``; returns local statistics."""
+        ly = self.lyap
+        ly._ctx.lyap_finalize(ly._lo, ly._hi, ly._d_values, ly._d_init,
+                              self.prior if use_prior else None, star, keep, ly._d_safe,
+                              ly._d_result)
+        res = ly._read_result()
+        return {'below': res[_hip.R_BELOW],
+                'last_safe': (res[_hip.R_LAST_V] & _U64_MAX, res[_hip.R_LAST_I]),
+                'max_key': (res[_hip.R_MAX_V] & _U64_MAX, res[_hip.R_MAX_I])}
 
-        if failed and not can_shrink:
-            # cells after the batch that contains the first failure keep their previous state
-            # (lyapunov.py:585-587 never touches later batches)
-            end = (below // batch + 1) * batch
-            keep = self._select_kth(end) if end < n else _KEY_NONE
-            ctx.lyap_finalize(lo, hi, self._d_values, self._d_init, d_prior, star, keep,
-                              self._d_safe, self._d_result)
+    def select_hist(self, which, byte, prefix, vbits_equal):
+        """Local 256-bin histogram of one radix-select pass (int64[256])."""
+        ly = self.lyap
+        ly._d_hist.zero_()
+        ly._ctx.select_pass(ly._lo, ly._hi, ly._d_values, which, byte, prefix, vbits_equal,
+                            ly._d_hist)
+        return ly._d_hist
 
-        # c_max = values[order[max_index]], max_index as in lyapunov.py:590
-        if failed:
-            c_key = last_safe if below > 0 else max_key
-        else:
-            last_batch_start = ((n - 1) // batch) * batch
-            c_key = self._select_kth(last_batch_start - 1) if last_batch_start > 0 else max_key
-        self.c_max = vbits_to_float(c_key[0])
 
-        self._safe_host_valid = False
-        self._safe_dev_valid = True
+def select_kth(engine, k, device):
+    """``(vbits, index)`` of the k-th smallest key (0-based) over all shards: two 8-pass radix
+    selects (value bytes, then index bytes among equal values), one 2 KiB SUM all-reduce each."""
+    def run(which, vbits_equal, rank_in):
+        prefix, remaining = 0, rank_in
+        for byte in range(7, -1, -1):
+            hist = engine.select_hist(which, byte, prefix, vbits_equal)
+            hist = dist_utils.allreduce_sum_(hist)
+            hist = hist.cpu().numpy() if hasattr(hist, 'cpu') else np.asarray(hist)
+            cum = np.cumsum(hist)
+            digit = int(np.searchsorted(cum, remaining, side='right'))
+            if digit > 0:
+                remaining -= int(cum[digit - 1])
+            prefix |= digit << (8 * byte)
+        return prefix, remaining
 
-    def _allreduce_int(self, value):
-        if self._world == 1:
-            return value
-        import torch
-        t = torch.tensor([value], dtype=torch.int64, device=self._ctx.torch_device)
-        dist_utils.allreduce_sum_(t)
-        return int(t[0])
+    vbits, rank_among_equal = run(0, 0, k)
+    index, _ = run(1, vbits, rank_among_equal)
+    return vbits, index
+
+
+def prefix_rule(engine, n, batch, can_shrink, device):
+    """The safe-set rule of ``lyapunov.py:512-606`` over sharded cells; returns ``c_max``.
+
+    ``engine`` owns one contiguous shard (the HIP engine in production, a NumPy stand-in in the
+    CPU tests of the multi-rank path).  Collectives: one 24-byte all-gather per key reduction,
+    one 8-byte SUM, and - only for ``can_shrink=False`` or the no-failure ``c_max`` quirk - sixteen
+    2 KiB SUM all-reduces of radix-select histograms.
+    """
+    star = dist_utils.allreduce_key(*engine.sweep(can_shrink), op='min', device=device)
+    stats = engine.finalize(star, _KEY_NONE, use_prior=False)
+    below = dist_utils.allreduce_int(stats['below'], device)
+    last_safe = dist_utils.allreduce_key(*stats['last_safe'], op='max', device=device)
+    max_key = dist_utils.allreduce_key(*stats['max_key'], op='max', device=device)
+    failed = star != _KEY_NONE
+
+    if failed and not can_shrink:
+        # cells after the batch that contains the first failure keep their previous state
+        # (lyapunov.py:585-587 never touches later batches)
+        end = (below // batch + 1) * batch
+        keep = select_kth(engine, end, device) if end < n else _KEY_NONE
+        engine.finalize(star, keep, use_prior=True)
+
+    # c_max = values[order[max_index]], max_index as in lyapunov.py:590
+    if failed:
+        c_key = last_safe if below > 0 else max_key
+    else:
+        last_batch_start = ((n - 1) // batch) * batch
+        c_key = select_kth(engine, last_batch_start - 1, device) if last_batch_start > 0 else max_key
+    return vbits_to_float(c_key[0])
 
 
 class _CMaxView(dict):

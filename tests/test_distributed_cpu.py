@@ -1,0 +1,136 @@
+"""The N > 1 path on CPU: world_size 2 and 3 over gloo (127.0.0.1).
+
+Every rank owns a contiguous 64-aligned shard, runs ``prefix_rule`` (the production
+orchestration of safe_learning_amd.lyapunov) with the NumPy shard engine standing in for the HIP
+kernels, and the assembled mask / c_max must equal the oracle's sequential result."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+import oracle
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _scenarios():
+    out = []
+    c = cases.make_case("pendulum", num_points=50, dynamics="linear", tau_scale=0.02)
+    out.append(("shrink", c, [dict(can_shrink=True)]))
+    out.append(("no_shrink", c, [dict(can_shrink=True), dict(can_shrink=False, extra=300, tau=4.0),
+                                 dict(can_shrink=False, tau=0.0)]))
+    c = cases.make_case("pendulum", num_points=24, dynamics="linear", tau_scale=0.01)
+    c["P"] = np.array([[1.0, 0.0], [0.0, 0.0]])
+    c["lv"] = ("const", 0.05)
+    out.append(("ties", c, [dict(can_shrink=True), dict(can_shrink=False, tau=3.0)]))
+    c = cases.make_case("pendulum", num_points=31, dynamics="linear", tau_scale=0.0)
+    c["K"] = c["K"] * 0.0
+    c["saturate"] = None
+    c["dynamics"] = {"kind": "linear", "matrix": np.hstack((0.5 * np.eye(2), np.zeros((2, 1))))}
+    c["initial_radius"] = 0.05
+    out.append(("all_safe", c, [dict(can_shrink=True)]))
+    c = cases.make_case("pendulum", num_points=20, dynamics="linear", tau_scale=50.0)
+    c["initial_radius"] = -1.0
+    out.append(("first_fails", c, [dict(can_shrink=True)]))
+    c = cases.make_case("cartpole", num_points=7, dynamics="analytic", tau_scale=0.0)
+    out.append(("cartpole", c, [dict(can_shrink=True), dict(can_shrink=False, extra=50)]))
+    return out
+
+
+def _worker(rank, world, port, results):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from np_shard_engine import NumpyShardEngine
+    from safe_learning_amd import distributed as du
+    from safe_learning_amd.lyapunov import prefix_rule
+    oracle.config.gp_batch_size = 100
+    device = torch.device("cpu")
+    failures = []
+    for name, case, steps in _scenarios():
+        olyap = cases.oracle_lyapunov(case)
+        n = olyap.discretization.nindex
+        init = np.zeros(n, dtype=bool)
+        init[cases.initial_safe_mask(case)] = True
+        lo, hi = du.shard_range(n)
+        assert lo % 64 == 0 or lo == n
+        prev = init.copy()
+        rng = np.random.default_rng(7)
+        for step in steps:
+            if "tau" in step:
+                olyap.tau = case["tau"] * step["tau"]
+            if "extra" in step:
+                extra = rng.choice(n, step["extra"], replace=False)
+                olyap.safe_set[extra] = True
+                prev[extra] = True
+            negative = olyap.negative(olyap.discretization.index_to_state(np.arange(n)))
+            engine = NumpyShardEngine(lo, hi, olyap.values, negative, init, prev)
+            c_max = prefix_rule(engine, n, 100, step["can_shrink"], device)
+            sizes = [b - a for a, b in zip(du.shard_bounds(n, world)[:-1], du.shard_bounds(n, world)[1:])]
+            full = du.allgather_concat(torch.from_numpy(engine.safe.astype(np.uint8)), sizes)
+            safe = full.numpy().astype(bool)
+            olyap.update_safe_set(can_shrink=step["can_shrink"])
+            same_c = (c_max == olyap.c_max) or (np.isnan(c_max) and np.isnan(olyap.c_max))
+            if not np.array_equal(safe, olyap.safe_set) or not same_c:
+                failures.append((name, step, int((safe != olyap.safe_set).sum()), c_max, olyap.c_max))
+            prev = olyap.safe_set.copy()
+    results[rank] = failures
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_prefix_rule_gloo(world):
+    port = _free_port()
+    manager = mp.Manager()
+    results = manager.dict()
+    mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
+    assert len(results) == world
+    for rank in range(world):
+        assert results[rank] == [], results[rank]
+
+
+def test_shard_bounds():
+    from safe_learning_amd.distributed import shard_bounds
+    for n in (1, 63, 64, 65, 1000, 128 ** 4):
+        for world in (1, 2, 3, 8):
+            b = shard_bounds(n, world)
+            assert b[0] == 0 and b[-1] == n and len(b) == world + 1
+            assert all(x <= y for x, y in zip(b, b[1:]))
+            assert all(x % 64 == 0 for x in b[1:-1] if x != n)
+
+
+def test_single_process_matches_oracle_semantics():
+    """world = 1 without torch.distributed: same engine, same result."""
+    from np_shard_engine import NumpyShardEngine
+    from safe_learning_amd.lyapunov import prefix_rule
+    old = oracle.config.gp_batch_size
+    oracle.config.gp_batch_size = 100
+    try:
+        for name, case, steps in _scenarios():
+            olyap = cases.oracle_lyapunov(case)
+            n = olyap.discretization.nindex
+            init = np.zeros(n, dtype=bool)
+            init[cases.initial_safe_mask(case)] = True
+            negative = olyap.negative(olyap.discretization.index_to_state(np.arange(n)))
+            engine = NumpyShardEngine(0, n, olyap.values, negative, init, init)
+            c_max = prefix_rule(engine, n, 100, True, torch.device("cpu"))
+            olyap.update_safe_set()
+            assert np.array_equal(engine.safe, olyap.safe_set), name
+            assert c_max == olyap.c_max, name
+    finally:
+        oracle.config.gp_batch_size = old

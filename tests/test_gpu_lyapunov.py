@@ -297,9 +297,9 @@ def test_select_kth(sl):
     vals[rng.choice(len(vals), 10)] = -0.0
     lyap._d_values.copy_(torch.from_numpy(vals))
     order = np.argsort(vals, kind="stable")
-    from safe_learning_amd.lyapunov import vbits_to_float
+    from safe_learning_amd.lyapunov import vbits_to_float, select_kth, _HipShardEngine
     for k in [0, 1, 17, 500, len(vals) // 2, len(vals) - 11, len(vals) - 1]:
-        vbits, index = lyap._select_kth(k)
+        vbits, index = select_kth(_HipShardEngine(lyap), k, lyap._ctx.torch_device)
         assert index == order[k]
         got, ref = vbits_to_float(vbits), vals[order[k]]
         assert (np.isnan(got) and np.isnan(ref)) or got == ref
