@@ -66,7 +66,8 @@ enum sl_lipschitz_kind {
     SL_LIP_CONST       = 0, /* scalar                                  (lyapunov.py:241-263) */
     SL_LIP_ABS_LINEAR  = 1, /* |x G^T| per column  (adaptive_safety_verification.ipynb c.17) */
     SL_LIP_NORM_LINEAR = 2, /* ||x G^T||_1, one column                                       */
-    SL_LIP_ABS_GRAD    = 3  /* |grad V(x)| of the value function (NN or triangulation)       */
+    SL_LIP_ABS_GRAD    = 3, /* |grad V(x)| per column (inverted_pendulum.ipynb cell 14)      */
+    SL_LIP_NORM_GRAD   = 4  /* ||grad V(x)||_1, one column (lyapunov_function_learning c.19) */
 };
 
 /* ---- plain-old-data model description (copied by sl_model_set) ---------------------- */

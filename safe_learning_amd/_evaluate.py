@@ -1,0 +1,107 @@
+"""Evaluate function specs at explicit points on the GPU (``Function.__call__`` of the reference,
+``safe_learning/functions.py:63-82``), through ``sl_eval_points``.
+
+A spec is evaluated by putting it into the slot of a throw-away engine model that matches its
+role (value function, policy, dynamics); all arithmetic runs in the same device functions as
+the grid sweeps."""
+
+import numpy as np
+
+from . import _hip
+from ._model import ModelBuilder
+
+_context = None
+
+
+def _ctx():
+    global _context
+    if _context is None:
+        _context = _hip.Context()
+    return _context
+
+
+def _dummy_grid(d):
+    from .functions import GridWorld
+    return GridWorld([[0., 1.]] * d, 2)
+
+
+def _to_device(ctx, array):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64)).to(ctx.torch_device)
+
+
+def _builder(d):
+    ctx = _ctx()
+    return ctx, ModelBuilder(ctx, _dummy_grid(d))
+
+
+def value(spec, points, lipschitz=None):
+    """``V(points)`` -> ``[n, 1]``; with ``lipschitz`` also returns ``L_v(points)``."""
+    import torch
+    from .functions import ConstantFunction, LinearSystem
+    points = np.atleast_2d(np.asarray(points, dtype=np.float64))
+    n, d = points.shape
+    ctx, builder = _builder(d)
+    builder.upload(ConstantFunction(np.zeros(1)), LinearSystem((np.eye(d), np.zeros((d, 1)))),
+                   spec, 0.0 if lipschitz is None else lipschitz, 0.0, 0.0)
+    d_pts = _to_device(ctx, points)
+    out = torch.empty((n, 1), dtype=torch.float64, device=ctx.torch_device)
+    ctx.eval_points(_hip.EVAL_VALUE, n, d_pts, out)
+    if lipschitz is None:
+        return out.cpu().numpy()
+    cols = 1 if builder._desc.lipschitz.lv_kind in (_hip.LIP_CONST, _hip.LIP_NORM_LINEAR,
+                                                    _hip.LIP_NORM_GRAD) else d
+    lv = torch.empty((n, cols), dtype=torch.float64, device=ctx.torch_device)
+    ctx.eval_points(_hip.EVAL_LV, n, d_pts, lv)
+    return out.cpu().numpy(), lv.cpu().numpy()
+
+
+def policy(spec, points):
+    """``policy(points)`` -> ``[n, m]``."""
+    import torch
+    from .functions import LinearSystem, QuadraticFunction
+    points = np.atleast_2d(np.asarray(points, dtype=np.float64))
+    n, d = points.shape
+    ctx, builder = _builder(d)
+    m = _policy_output_dim(spec)
+    desc = builder.upload(spec, LinearSystem((np.eye(d), np.zeros((d, m)))),
+                          QuadraticFunction(np.eye(d)))
+    out = torch.empty((n, m), dtype=torch.float64, device=ctx.torch_device)
+    ctx.eval_points(_hip.EVAL_POLICY, n, _to_device(ctx, points), out)
+    return out.cpu().numpy()
+
+
+def _policy_output_dim(spec):
+    inner = getattr(spec, 'fun', spec) if type(spec).__name__ == 'Saturation' else spec
+    return int(inner.output_dim)
+
+
+def dynamics(spec, states, actions):
+    """``dynamics(states, actions)`` -> next states, or ``(mean, error)`` for uncertain specs."""
+    import torch
+    from .functions import QuadraticFunction, UncertainFunction
+    states = np.atleast_2d(np.asarray(states, dtype=np.float64))
+    actions = np.atleast_2d(np.asarray(actions, dtype=np.float64))
+    n, d = states.shape
+    ctx, builder = _builder(d)
+    builder.grid.nindex = n                      # the action table is indexed by the point index
+    builder.upload(np.ascontiguousarray(actions), spec, QuadraticFunction(np.eye(d)))
+    out = torch.empty((n, 2 + 2 * d), dtype=torch.float64, device=ctx.torch_device)
+    ctx.eval_points(_hip.EVAL_DYNAMICS, n, _to_device(ctx, states), out)
+    rec = out.cpu().numpy()
+    mean, err = rec[:, 2:2 + d], rec[:, 2 + d:]
+    return (mean, err) if isinstance(spec, UncertainFunction) else mean
+
+
+def linear_map(spec, points):
+    """``[x] M^T`` for a LinearSystem called with already-concatenated inputs."""
+    from .functions import ConstantFunction, LinearSystem
+    points = np.atleast_2d(np.asarray(points, dtype=np.float64))
+    n, k = points.shape
+    rows = spec.matrix.shape[0]
+    if rows > k:
+        raise NotImplementedError('LinearSystem evaluation needs output_dim <= input_dim')
+    padded = np.zeros((k, k + 1))
+    padded[:rows, :k] = spec.matrix
+    out = dynamics(LinearSystem((padded,)), points, np.zeros((n, 1)))
+    return out[:, :rows]

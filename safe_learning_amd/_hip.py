@@ -24,7 +24,7 @@ MAX_SIMPLICES = 32
 POLICY_LINEAR, POLICY_CONST, POLICY_TABLE, POLICY_TRI = 1, 2, 3, 4
 DYN_LINEAR, DYN_PENDULUM, DYN_CARTPOLE, DYN_GP = 1, 2, 3, 4
 V_QUADRATIC, V_TRI, V_NETWORK = 1, 2, 3
-LIP_CONST, LIP_ABS_LINEAR, LIP_NORM_LINEAR, LIP_ABS_GRAD = 0, 1, 2, 3
+LIP_CONST, LIP_ABS_LINEAR, LIP_NORM_LINEAR, LIP_ABS_GRAD, LIP_NORM_GRAD = 0, 1, 2, 3, 4
 EVAL_VALUE, EVAL_POLICY, EVAL_DYNAMICS, EVAL_DECREASE, EVAL_LV = 1, 2, 3, 4, 5
 
 c_double_p = C.POINTER(C.c_double)

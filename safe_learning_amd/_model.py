@@ -9,8 +9,8 @@ table / network payloads are uploaded once (and again only when they change).
 import numpy as np
 
 from . import _hip
-from .functions import (AbsFunction, AbsGradient, CartPole, ConstantFunction, FunctionStack,
-                        GaussianProcess, InvertedPendulum, LinearSystem, LyapunovNetwork,
+from .functions import (AbsFunction, CartPole, ConstantFunction, FunctionStack,
+                        GaussianProcess, Gradient, InvertedPendulum, LinearSystem, LyapunovNetwork,
                         Norm1Function, QuadraticFunction, Saturation, Triangulation, _gp_heads)
 
 
@@ -138,7 +138,11 @@ class ModelBuilder(object):
 
     def _write_lipschitz(self, ld, lipschitz_lyapunov, lipschitz_dynamics, tau):
         d = self.grid.ndim
-        if isinstance(lipschitz_lyapunov, (AbsFunction, Norm1Function)):
+        if (isinstance(lipschitz_lyapunov, (AbsFunction, Norm1Function))
+                and isinstance(lipschitz_lyapunov.fun, Gradient)):
+            ld.lv_kind = (_hip.LIP_ABS_GRAD if isinstance(lipschitz_lyapunov, AbsFunction)
+                          else _hip.LIP_NORM_GRAD)
+        elif isinstance(lipschitz_lyapunov, (AbsFunction, Norm1Function)):
             inner = lipschitz_lyapunov.fun
             if not isinstance(inner, LinearSystem) or inner.matrix.shape != (d, d):
                 raise TypeError('AbsFunction / Norm1Function need a %d x %d LinearSystem' % (d, d))
@@ -147,14 +151,12 @@ class ModelBuilder(object):
             for i in range(d):
                 for j in range(d):
                     ld.lv_matrix[i][j] = float(inner.matrix[i, j])
-        elif isinstance(lipschitz_lyapunov, AbsGradient):
-            ld.lv_kind = _hip.LIP_ABS_GRAD
         elif np.isscalar(lipschitz_lyapunov):
             ld.lv_kind = _hip.LIP_CONST
             ld.lv_const = float(lipschitz_lyapunov)
         else:
             raise TypeError('lipschitz_lyapunov must be a float, AbsFunction(LinearSystem), '
-                            'Norm1Function(LinearSystem) or AbsGradient(V); arbitrary Python '
+                            'Norm1Function(LinearSystem), AbsFunction/Norm1Function(Gradient(V)); arbitrary Python '
                             'callables cannot run inside a GPU kernel')
         if not np.isscalar(lipschitz_dynamics):
             raise TypeError('lipschitz_dynamics must be a scalar')

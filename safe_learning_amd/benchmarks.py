@@ -183,15 +183,40 @@ def build_specs(case):
             gp = F.GPRCached(dyn['X'], dyn['Y'], kern, F.LinearSystem((dyn['prior'],)),
                              likelihood_variance=dyn['noise_variance'])
             dynamics = F.GaussianProcess(gp, dyn['beta'])
-    value = F.QuadraticFunction(case['P'])
-    kind, arg = case['lv']
+    vspec = case.get('V', {'kind': 'quadratic'})
+    if vspec['kind'] == 'quadratic':
+        value = F.QuadraticFunction(case['P'])
+    elif vspec['kind'] == 'network':
+        value = F.LyapunovNetwork(case['d'], vspec['layer_dims'], vspec['activations'],
+                                  vspec['eps'], vspec['weights'])
+    else:
+        value = F.Triangulation(F.GridWorld(case['limits'], case['num_points']), vspec['values'],
+                                project=vspec.get('project', False))
+    kind, arg = (case['lv'] + (None,))[:2]
     if kind == 'const':
         lv = arg
     elif kind == 'abs_linear':
         lv = F.AbsFunction(F.LinearSystem((arg,)))
-    else:
+    elif kind == 'norm_linear':
         lv = F.Norm1Function(F.LinearSystem((arg,)))
+    elif kind == 'abs_grad':
+        lv = F.AbsFunction(F.Gradient(value))
+    else:
+        lv = F.Norm1Function(F.Gradient(value))
     return policy, dynamics, value, lv
+
+
+def network_weights(input_dim, layer_dims, seed=1):
+    """Xavier-uniform weights in the variable order of ``examples/utilities.py:95-99``."""
+    rng = np.random.default_rng(seed)
+    weights, in_dim = [], input_dim
+    for out_dim in layer_dims:
+        hidden = int(np.ceil((in_dim + 1) / 2))
+        shapes = [(hidden, in_dim)] + ([(out_dim - in_dim, in_dim)] if out_dim > in_dim else [])
+        for s in shapes:
+            weights.append(rng.uniform(-1, 1, s) * np.sqrt(6. / (s[0] + s[1])))
+        in_dim = out_dim
+    return weights
 
 
 def build_lyapunov(case):

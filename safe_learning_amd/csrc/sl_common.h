@@ -196,12 +196,24 @@ __device__ __forceinline__ double sl_value_any(const SlDevModel& M, int d, const
 template <bool GENERAL>
 __device__ __forceinline__ void sl_lv_any(const SlDevModel& M, int d, const SlAux& aux,
                                           const double* z, double* lv) {
-    if (!GENERAL || M.m.lipschitz.lv_kind != SL_LIP_ABS_GRAD) { sl_lv(M, d, z, lv); return; }
+    const int kind = M.m.lipschitz.lv_kind;
+    if (!GENERAL || (kind != SL_LIP_ABS_GRAD && kind != SL_LIP_NORM_GRAD)) { sl_lv(M, d, z, lv); return; }
     double g[SL_D];
     if (M.m.value.kind == SL_V_TRI) sl_tri_eval(aux.tri[0], z, 0, g);
     else sl_network_value(*aux.net, z, d, g);
+    if (M.m.value.negate) {
 #pragma unroll
-    for (int k = 0; k < SL_D; ++k) if (k < d) lv[k] = fabs(g[k]);
+        for (int k = 0; k < SL_D; ++k) if (k < d) g[k] = g[k] * -1.0;
+    }
+    if (kind == SL_LIP_ABS_GRAD) {
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) if (k < d) lv[k] = fabs(g[k]);
+    } else {
+        double acc = fabs(g[0]);
+#pragma unroll
+        for (int k = 1; k < SL_D; ++k) if (k < d) acc = acc + fabs(g[k]);
+        lv[0] = acc;
+    }
 }
 
 template <bool GENERAL>
@@ -229,5 +241,5 @@ static inline int sl_dim_variant_of(const SlDevModel& M) {
 // true when the model needs the table / network code paths
 static inline bool sl_model_is_general(const SlDevModel& M) {
     return M.m.value.kind != SL_V_QUADRATIC || M.m.policy.kind == SL_POLICY_TRI ||
-           M.m.lipschitz.lv_kind == SL_LIP_ABS_GRAD;
+           M.m.lipschitz.lv_kind == SL_LIP_ABS_GRAD || M.m.lipschitz.lv_kind == SL_LIP_NORM_GRAD;
 }

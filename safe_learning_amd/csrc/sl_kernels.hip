@@ -154,11 +154,11 @@ extern "C" int sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model) {
     if (vk < SL_V_QUADRATIC || vk > SL_V_NETWORK)
         return sl_fail(ctx, SL_ERR_INVALID, "unknown value-function kind %d", vk);
     const int lk = M.m.lipschitz.lv_kind;
-    if (lk < SL_LIP_CONST || lk > SL_LIP_ABS_GRAD)
+    if (lk < SL_LIP_CONST || lk > SL_LIP_NORM_GRAD)
         return sl_fail(ctx, SL_ERR_INVALID, "unknown L_v kind %d", lk);
-    if (lk == SL_LIP_CONST || lk == SL_LIP_NORM_LINEAR) M.m.lipschitz.lv_cols = 1;
+    if (lk == SL_LIP_CONST || lk == SL_LIP_NORM_LINEAR || lk == SL_LIP_NORM_GRAD) M.m.lipschitz.lv_cols = 1;
     else M.m.lipschitz.lv_cols = M.m.grid.d;
-    if (lk == SL_LIP_ABS_GRAD && vk == SL_V_QUADRATIC)
+    if ((lk == SL_LIP_ABS_GRAD || lk == SL_LIP_NORM_GRAD) && vk == SL_V_QUADRATIC)
         return sl_fail(ctx, SL_ERR_INVALID, "ABS_GRAD L_v needs a table or network V "
                                              "(use ABS_LINEAR with P + P^T)");
     ctx->h_model = M;
@@ -409,9 +409,7 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
     if (rc) return rc;
     if (lo < 0 || hi < lo || (!d_points && hi > ctx->h_model.gf.nindex) || (lo & 63))
         return sl_fail(ctx, SL_ERR_INVALID, "sl_lyap_sweep: bad range (lo must be a multiple of 64)");
-    if (d_points && ctx->h_model.m.policy.kind == SL_POLICY_TABLE)
-        return sl_fail(ctx, SL_ERR_UNSUPPORTED, "a per-vertex policy table cannot be evaluated "
-                                                "at arbitrary points");
+    // with explicit points a TABLE policy is indexed by the point number (one action per point)
     if (!d_neg_bits || !d_result) return sl_fail(ctx, SL_ERR_INVALID, "sl_lyap_sweep: NULL output");
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int blocks = 1;

@@ -447,7 +447,7 @@ SL_HD void sl_lv(const SlDevModel& M, int d, const double* z, double* lv) {
 SL_HD double sl_threshold(const SlDevModel& M, int d, const double* lv_x, double tau) {
     const sl_lipschitz_desc& l = M.m.lipschitz;
     double l1 = lv_x[0];
-    if (l.lv_kind != SL_LIP_CONST && l.lv_kind != SL_LIP_NORM_LINEAR && d > 1) {
+    if ((l.lv_kind == SL_LIP_ABS_LINEAR || l.lv_kind == SL_LIP_ABS_GRAD) && d > 1) {
         l1 = fabs(lv_x[0]);
 #pragma unroll
         for (int j = 1; j < SL_D; ++j) if (j < d) l1 = l1 + fabs(lv_x[j]);
@@ -463,7 +463,7 @@ SL_HD double sl_decrease(const SlDevModel& M, int d, double v_x, double v_next,
     double bound = 0.0;
     if (M.uncertain) {
         const sl_lipschitz_desc& l = M.m.lipschitz;
-        const bool bcast = (l.lv_kind == SL_LIP_CONST) || (l.lv_kind == SL_LIP_NORM_LINEAR) || d == 1;
+        const bool bcast = !(l.lv_kind == SL_LIP_ABS_LINEAR || l.lv_kind == SL_LIP_ABS_GRAD) || d == 1;
         bound = lv_next[0] * err[0];
 #pragma unroll
         for (int j = 1; j < SL_D; ++j) {

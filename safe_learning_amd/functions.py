@@ -26,7 +26,7 @@ from .configuration import config
 
 __all__ = ['GridWorld', 'DimensionError', 'DeterministicFunction', 'UncertainFunction',
            'QuadraticFunction', 'LinearSystem', 'Saturation', 'AbsFunction', 'Norm1Function',
-           'AbsGradient', 'ConstantFunction', 'RBF', 'GPRCached', 'GaussianProcess',
+           'AbsGradient', 'Gradient', 'ConstantFunction', 'RBF', 'GPRCached', 'GaussianProcess',
            'FunctionStack', 'Triangulation', 'InvertedPendulum', 'CartPole', 'LyapunovNetwork']
 
 
@@ -72,7 +72,8 @@ class GridWorld(object):
 
         Only for small grids / plotting: the kernels generate states from indices instead."""
         if self._all_points is None:
-            self._all_points = self.index_to_state(np.arange(self.nindex))
+            mesh = np.meshgrid(*self.discrete_points, indexing='ij')
+            self._all_points = np.stack([m.ravel() for m in mesh], axis=1).astype(config.np_dtype)
         return self._all_points
 
     def sample_continuous(self, num_samples):
@@ -160,10 +161,30 @@ class Function(object):
         other.negate = not self.negate
         return other
 
+    _role = None      # 'value', 'policy', 'dynamics' or 'linear'
+
     def __call__(self, *points):
-        raise NotImplementedError(
-            '%s is a declarative spec evaluated inside the HIP kernels; evaluate it through '
-            'Lyapunov / PolicyIteration (or their .evaluate helpers).' % type(self).__name__)
+        """Evaluate at explicit points on the GPU (``functions.py:63-82``); several inputs are
+        concatenated like ``concatenate_inputs`` does (``utilities.py:123-159``)."""
+        from . import _evaluate
+        arrays = [np.atleast_2d(np.asarray(p, dtype=config.np_dtype)) for p in points]
+        if self._role == 'value':
+            out = _evaluate.value(self, np.hstack(arrays))
+            return out
+        if self._role == 'policy':
+            return _evaluate.policy(self, np.hstack(arrays))
+        if self._role == 'dynamics':
+            joined = np.hstack(arrays)
+            d = self.output_dim
+            return _evaluate.dynamics(self, joined[:, :d], joined[:, d:])
+        if self._role == 'linear':
+            joined = np.hstack(arrays)
+            if len(arrays) == 2 and self.matrix.shape[0] == arrays[0].shape[1]:
+                return _evaluate.dynamics(self, arrays[0], arrays[1])
+            if self.matrix.shape[0] <= _hip.MAX_ACTION_DIM and len(arrays) == 1:
+                return _evaluate.policy(self, joined)
+            return _evaluate.linear_map(self, joined)
+        raise NotImplementedError('%s cannot be evaluated on its own' % type(self).__name__)
 
 
 class DeterministicFunction(Function):
@@ -182,6 +203,8 @@ def _hstack_matrices(matrices):
 
 class QuadraticFunction(DeterministicFunction):
     """``x P x^T`` (``functions.py:1513-1543``); ``P`` need not be symmetric."""
+
+    _role = 'value'
 
     def __init__(self, matrix, name='quadratic'):
         self.matrix = np.atleast_2d(matrix).astype(config.np_dtype)
@@ -206,6 +229,8 @@ class QuadraticFunction(DeterministicFunction):
 class LinearSystem(DeterministicFunction):
     """``[x, u] M^T`` with ``M = hstack(matrices)`` (``functions.py:1546-1583``)."""
 
+    _role = 'linear'
+
     def __init__(self, matrices, name='linear_system'):
         self.matrix = _hstack_matrices(matrices)
         self.output_dim, self.input_dim = self.matrix.shape
@@ -214,6 +239,8 @@ class LinearSystem(DeterministicFunction):
 
 class Saturation(DeterministicFunction):
     """Clamp ``fun`` to ``[lower, upper]`` (``functions.py:310-354``)."""
+
+    _role = 'policy'
 
     def __init__(self, fun, lower, upper, name='saturation'):
         self.fun, self.lower, self.upper = fun, lower, upper
@@ -245,12 +272,18 @@ class Norm1Function(DeterministicFunction):
         self.fun = fun
 
 
-class AbsGradient(DeterministicFunction):
-    """``|dV/dx|`` of a table / network value function (``inverted_pendulum.ipynb`` cell 14,
-    ``lyapunov_function_learning.ipynb``: ``tf.gradients``)."""
+class Gradient(DeterministicFunction):
+    """``dV/dx`` of a table / network value function: ``tri.gradient`` (``functions.py:1302-1326``)
+    or ``tf.gradients(V(x), x)`` of the notebooks.  Use inside ``AbsFunction`` / ``Norm1Function``
+    as the local Lipschitz constant ``L_v``."""
 
     def __init__(self, fun):
         self.fun = fun
+
+
+def AbsGradient(fun):
+    """``|dV/dx|`` per dimension (``inverted_pendulum.ipynb`` cell 14)."""
+    return AbsFunction(Gradient(fun))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -317,6 +350,8 @@ class GPRCached(object):
 class GaussianProcess(UncertainFunction):
     """``(mean, beta * sqrt(var))`` of a GP model (``functions.py:461-546``)."""
 
+    _role = 'dynamics'
+
     def __init__(self, gaussian_process, beta=2., name='gaussian_process'):
         self.gaussian_process = gaussian_process
         self.beta = float(beta)
@@ -343,6 +378,8 @@ class GaussianProcess(UncertainFunction):
 
 class FunctionStack(UncertainFunction):
     """One uncertain function per output column (``functions.py:254-307``)."""
+
+    _role = 'dynamics'
 
     def __init__(self, functions, name='function_stack'):
         self.functions = list(functions)
@@ -381,6 +418,8 @@ class Triangulation(DeterministicFunction):
     As in the reference only ONE unit cell is triangulated (SciPy/Qhull on the cell's corners,
     ``functions.py:1019-1022``) and reused for every cell.  ``parameters`` is the ``[nindex, k]``
     vertex table; the device copy is refreshed whenever it is assigned."""
+
+    _role = 'value'
 
     def __init__(self, discretization, vertex_values=None, project=False, name='triangulation'):
         self.discretization = disc = discretization
@@ -467,6 +506,8 @@ def _normalization(normalization):
 class InvertedPendulum(DeterministicFunction):
     """Pendulum with 10 explicit-Euler sub-steps (``examples/utilities.py:144-289``)."""
 
+    _role = 'dynamics'
+
     def __init__(self, mass, length, friction=0, dt=1 / 80, normalization=None):
         self.mass, self.length, self.friction, self.dt = mass, length, friction, dt
         self.gravity = 9.81
@@ -502,6 +543,8 @@ class InvertedPendulum(DeterministicFunction):
 
 class CartPole(DeterministicFunction):
     """Cart-pole with 10 explicit-Euler sub-steps (``examples/utilities.py:292-437``)."""
+
+    _role = 'dynamics'
 
     def __init__(self, pendulum_mass, cart_mass, length, rot_friction=0.0, dt=0.01,
                  normalization=None):
@@ -560,6 +603,8 @@ class LyapunovNetwork(DeterministicFunction):
     (``examples/utilities.py:48-104``).  ``activations`` are names ('tanh', 'relu', None);
     ``weights`` the flat variable list in the reference's creation order, or ``None`` for
     Xavier-uniform initialisation from ``seed``."""
+
+    _role = 'value'
 
     def __init__(self, input_dim, layer_dims, activations, eps=1e-6, weights=None, seed=0,
                  name='lyapunov_network'):

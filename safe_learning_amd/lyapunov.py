@@ -135,6 +135,46 @@ class Lyapunov(object):
         """The (scalar) Lipschitz constant of the dynamics (``lyapunov.py:227-244``)."""
         return self._lipschitz_dynamics
 
+    def lipschitz_lyapunov(self, states):
+        """``L_v`` at explicit states (``lyapunov.py:246-263``): the scalar, or ``[n, cols]``."""
+        if np.isscalar(self._lipschitz_lyapunov):
+            return self._lipschitz_lyapunov
+        from . import _evaluate
+        return _evaluate.value(self.lyapunov_function, states, self._lipschitz_lyapunov)[1]
+
+    def threshold(self, states, tau=None):
+        """``-|L_v(states)|_1 (1 + L_f) tau`` (``lyapunov.py:265-288``), computed on the host from
+        the device-evaluated ``L_v`` (same operation order as the kernels)."""
+        tau = self.tau if tau is None else tau
+        lv = self.lipschitz_lyapunov(states)
+        if not np.isscalar(lv) and lv.shape[1] > 1:
+            acc = np.abs(lv[:, 0])
+            for k in range(1, lv.shape[1]):
+                acc = acc + np.abs(lv[:, k])
+            lv = acc[:, None]
+        return (-lv) * (1. + self._lipschitz_dynamics) * tau
+
+    def v_decrease_confidence(self, states, next_states):
+        """``(V(next) - V(states), sum_j L_v(next)_j error_j)`` (``lyapunov.py:324-354``)."""
+        from . import _evaluate
+        if isinstance(next_states, (tuple, list)):
+            next_states, error_bounds = next_states
+            lv = self.lipschitz_lyapunov(next_states)
+            prod = lv * np.asarray(error_bounds)
+            bound = prod[:, [0]].copy()
+            for k in range(1, prod.shape[1]):
+                bound = bound + prod[:, [k]]
+        else:
+            bound = 0.
+        v_decrease = (_evaluate.value(self.lyapunov_function, next_states)
+                      - _evaluate.value(self.lyapunov_function, states))
+        return v_decrease, bound
+
+    def v_decrease_bound(self, states, next_states):
+        """``lyapunov.py:356-376``."""
+        v_dot, v_dot_error = self.v_decrease_confidence(states, next_states)
+        return v_dot + v_dot_error
+
     @property
     def values(self):
         """V at every grid point, ``float64[nindex]`` (``lyapunov.py:305-322``); gathered from all

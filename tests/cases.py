@@ -36,14 +36,29 @@ def oracle_specs(case):
             gp = oracle.GPRCached(dyn['X'], dyn['Y'], kern, oracle.LinearSystem((dyn['prior'],)),
                                   likelihood_variance=dyn['noise_variance'])
             dynamics = oracle.GaussianProcess(gp, dyn['beta'])
-    value = oracle.QuadraticFunction(case['P'])
-    kind, arg = case['lv']
+    vspec = case.get('V', {'kind': 'quadratic'})
+    if vspec['kind'] == 'quadratic':
+        value = oracle.QuadraticFunction(case['P'])
+        gradient = None
+    elif vspec['kind'] == 'network':
+        value = oracle.LyapunovNetwork(case['d'], vspec['layer_dims'], vspec['activations'],
+                                       vspec['eps'], vspec['weights'])
+        gradient = value.gradient
+    else:
+        value = oracle.Triangulation(oracle.GridWorld(case['limits'], case['num_points']),
+                                     vspec['values'], project=vspec.get('project', False))
+        gradient = value.gradient
+    kind, arg = (case['lv'] + (None,))[:2]
     if kind == 'const':
         lv = arg
     elif kind == 'abs_linear':
         lv = oracle.AbsFunction(oracle.LinearSystem((arg,)))
-    else:
+    elif kind == 'norm_linear':
         lv = oracle.Norm1Function(oracle.LinearSystem((arg,)))
+    elif kind == 'abs_grad':
+        lv = oracle.AbsFunction(gradient)
+    else:
+        lv = oracle.Norm1Function(gradient)
     return policy, dynamics, value, lv
 
 

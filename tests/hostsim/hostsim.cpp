@@ -23,7 +23,7 @@ static void make_model(const sl_model_desc* desc, SlDevModel* M) {
     M->in_dim = desc->grid.d + desc->policy.m;
     M->uncertain = 0;
     const int lk = desc->lipschitz.lv_kind;
-    M->m.lipschitz.lv_cols = (lk == SL_LIP_CONST || lk == SL_LIP_NORM_LINEAR) ? 1 : desc->grid.d;
+    M->m.lipschitz.lv_cols = (lk == SL_LIP_CONST || lk == SL_LIP_NORM_LINEAR || lk == SL_LIP_NORM_GRAD) ? 1 : desc->grid.d;
 }
 
 extern "C" {

@@ -193,6 +193,72 @@ def test_gp_dynamics(sl, name, kw, cfg, monkeypatch):
     _compare_safe_sets(lyap, olyap, flips)
 
 
+# ---------------------------------------------------------------------------------------------
+# network / table Lyapunov functions with gradient-based L_v (configs C3 and the NIPS-17 loop)
+# ---------------------------------------------------------------------------------------------
+def _network_case(name, lv_kind, **kw):
+    from safe_learning_amd.benchmarks import network_weights
+    case = cases.make_case(name, **kw)
+    dims = [8, 8, 12] if case["d"] == 2 else [6, 8]
+    case["V"] = {"kind": "network", "layer_dims": dims, "activations": ["tanh"] * len(dims),
+                 "eps": 1e-8, "weights": network_weights(case["d"], dims, seed=1)}
+    case["lv"] = (lv_kind,)
+    return case
+
+
+@pytest.mark.parametrize("name,lv_kind,kw", [
+    ("pendulum", "norm_grad", dict(num_points=40, dynamics="analytic", tau_scale=0.0)),
+    ("pendulum", "norm_grad", dict(num_points=40, dynamics="analytic", tau_scale=0.01)),
+    ("pendulum", "abs_grad", dict(num_points=32, n_gp=100, tau_scale=0.0)),
+    ("cartpole", "norm_grad", dict(num_points=6, dynamics="linear", tau_scale=0.0)),
+])
+def test_network_lyapunov_function(sl, name, lv_kind, kw):
+    """LyapunovNetwork V with L_v from its input gradient (lyapunov_function_learning.ipynb c.19)."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = _network_case(name, lv_kind, **kw)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    assert_allclose(lyap.values, olyap.values, rtol=1e-12, atol=1e-15)        # V within 1e-5 req.
+    values, neg, rec = _engine_records(lyap)
+    ref_rec, ref_neg = _oracle_all(olyap)
+    assert_allclose(rec, ref_rec, rtol=1e-8, atol=1e-13)
+    flips, _ = _check_masks(neg, ref_neg, rec, ref_rec, allowed=4)
+    if flips == 0 and np.array_equal(lyap.values, olyap.values):
+        _compare_safe_sets(lyap, olyap, 0)
+
+
+@pytest.mark.parametrize("lv_kind", ["abs_grad", "norm_grad"])
+def test_table_lyapunov_function(sl, lv_kind):
+    """Triangulation V (e.g. -value_function of the RL loop) with |gradient| as L_v
+    (inverted_pendulum.ipynb cell 14)."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case("pendulum", num_points=33, dynamics="linear", tau_scale=0.0)
+    g = oracle.GridWorld(case["limits"], case["num_points"])
+    pts = g.all_points
+    vals = np.einsum("ij,jk,ik->i", pts, case["P"], pts) + 0.05 * np.sin(3 * pts[:, 0]) * pts[:, 1]
+    case["V"] = {"kind": "table", "values": vals[:, None], "project": True}
+    case["lv"] = (lv_kind,)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    values, neg, rec = _engine_records(lyap)
+    ref_rec, ref_neg = _oracle_all(olyap)
+    # The cell's own state is a grid vertex, where the gradient of a piecewise-linear table (and
+    # with it the reference's L_v(x), hence the threshold for tau > 0) depends on the simplex
+    # scipy happens to return; tau = 0 here, so the threshold is exactly -0.0 for every choice.
+    # Successor states on cell faces are excluded for the same reason.
+    from test_gpu_rl import ambiguous_points
+    otri = olyap.lyapunov_function
+    nxt = ref_rec[:, 2:4]
+    frac = (g._center_states(nxt, clip=True) % g.unit_maxes) / g.unit_maxes
+    on_face = (np.abs(frac) < 1e-9).any(axis=1) | (np.abs(frac - 1) < 1e-9).any(axis=1)
+    on_face |= np.abs(frac.sum(axis=1) - 1) < 1e-9
+    on_face |= ambiguous_points(otri, nxt)
+    ok = ~on_face
+    assert ok.sum() > 50
+    assert_allclose(values, olyap.values, rtol=1e-12, atol=1e-14)
+    assert np.all(rec[:, 1] == 0.0) and np.all(ref_rec[:, 1] == 0.0)
+    assert_allclose(rec[ok][:, [0, 2, 3]], ref_rec[ok][:, [0, 2, 3]], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(neg[ok], ref_neg[ok])
+
+
 def test_gp_known_answer_through_engine(sl, golden):
     """tests/test_functions.py:237-261 evaluated by the MFMA kernel (explicit points)."""
     import torch
@@ -346,3 +412,40 @@ def test_errors_are_loud(sl):
     ctx = _hip.Context()
     with pytest.raises(_hip.HipEngineError):
         ctx.values(0, 10, None)                        # model not set
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluation at explicit points (Function.__call__, Lyapunov.threshold / v_decrease_bound)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [
+    ("pendulum", dict(num_points=20, dynamics="linear")),
+    ("pendulum", dict(num_points=20, dynamics="analytic")),
+    ("pendulum", dict(num_points=20, n_gp=90)),
+    ("cartpole", dict(num_points=5, n_gp=120)),
+    ("cartpole", dict(num_points=5, n_gp=60, stack=True)),
+])
+def test_point_evaluation_api(sl, name, kw):
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case(name, **kw)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    rng = np.random.default_rng(11)
+    d = case["d"]
+    x = rng.uniform(-1, 1, (37, d))
+    u = rng.uniform(-1, 1, (37, 1))
+    assert_allclose(lyap.lyapunov_function(x), olyap.lyapunov_function(x), rtol=1e-13)
+    assert_allclose(lyap.policy(x), olyap.policy(x), rtol=1e-13, atol=1e-15)
+    got, ref = lyap.dynamics(x, u), olyap.dynamics(x, u)
+    if isinstance(ref, tuple):
+        assert_allclose(got[0], ref[0], rtol=1e-9, atol=1e-13)
+        assert_allclose(got[1], ref[1], rtol=1e-7, atol=1e-12)
+        nxt, onxt = got, ref
+    else:
+        assert_allclose(got, ref, rtol=1e-12, atol=1e-15)
+        nxt, onxt = got, ref
+    assert_allclose(lyap.lipschitz_lyapunov(x), olyap.lipschitz_lyapunov(x), rtol=1e-13)
+    assert_allclose(lyap.threshold(x), olyap.threshold(x), rtol=1e-13)
+    assert_allclose(lyap.threshold(x, 0.3), olyap.threshold(x, 0.3), rtol=1e-13)
+    assert_allclose(lyap.v_decrease_bound(x, nxt), olyap.v_decrease_bound(x, onxt),
+                    rtol=1e-7, atol=1e-12)
+    grad = sl.LinearSystem((2 * case["P"],))
+    assert_allclose(grad(x), oracle.LinearSystem((2 * case["P"],))(x), rtol=1e-13)
