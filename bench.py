@@ -111,6 +111,15 @@ def main():
     avg_ms = float(np.mean(kernel_ms))
     achieved = flops / (avg_ms * 1e-3) / 1e12
 
+    traffic = None
+    try:                                           # PMC result of the same command (tools/pmc_traffic.py)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if world == 1 and args.num_points == 128 and args.n_gp == 1024 and args.family == "cartpole":
+            traffic = pmc["bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     if rank == 0:
         out = {
             "metric": "grid-cell Lyapunov checks/sec",
@@ -131,7 +140,7 @@ def main():
                        "grid_sharding": "contiguous index ranges over %d GPU(s)" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "kernel": "k_gp_sweep", "kernel_ms": avg_ms,
                          "flops_per_check": flops_per_check(n_gp, p, d)},
         }

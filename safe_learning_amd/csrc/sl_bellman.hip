@@ -12,7 +12,7 @@
 
 #define SL_MAX_ACTIONS 16
 
-template <bool ACTIONS, int DT, int MT>
+template <int AMAX, int DT, int MT>
 __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int n_actions,
     const double* __restrict__ actions, double* __restrict__ v_new, int32_t* __restrict__ argmax,
@@ -21,6 +21,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
     __shared__ double red_max[SL_BLOCK / 64], red_sum[SL_BLOCK / 64];
     const SlDims nd = sl_dims<DT, MT>(M);
     const int d = nd.d, m = nd.m, p = nd.p;
+    constexpr bool ACTIONS = AMAX > 0;
     const int A = ACTIONS ? n_actions : 1;
     const bool is_gp = M.m.dynamics.kind == SL_DYN_GP;
     const SlTri& vt = aux.tri[0];
@@ -32,16 +33,22 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
         for (int h = 0; h < gp.nheads; ++h) {
             const SlGpHeadDev& hd = gp.head[h];
             e_off[h] = off;
-            for (int t = threadIdx.x; t < hd.n_pad * A; t += SL_BLOCK) {
-                const int j = t / A, a = t - j * A;
-                double z = 0.0;
-                for (int c = 0; c < m; ++c) {
-                    const double dlt = hd.xs[(d + c) * hd.n_pad + j] - actions[a * m + c] * hd.inv_ls[d + c];
-                    z = fma(dlt, dlt, z);
+            // [n_pad][AMAX]; columns a >= A are zero so that the inner loops need no predicate
+            for (int t = threadIdx.x; t < hd.n_pad * AMAX; t += SL_BLOCK) {
+                const int j = t / AMAX, a = t - j * AMAX;
+                double e = 0.0;
+                if (a < A) {
+                    double z = 0.0;
+                    for (int c = 0; c < m; ++c) {
+                        const double dlt = hd.xs[(d + c) * hd.n_pad + j] -
+                                           actions[a * m + c] * hd.inv_ls[d + c];
+                        z = fma(dlt, dlt, z);
+                    }
+                    e = exp(-0.5 * z);
                 }
-                smem[off + t] = exp(-0.5 * z);
+                smem[off + t] = e;
             }
-            off += hd.n_pad * A;
+            off += hd.n_pad * AMAX;
         }
         __syncthreads();
     }
@@ -108,9 +115,10 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
             }
         } else {
             // ---- GP + action set: state factors shared by all actions ---------------------------
-            double mean[SL_MAX_ACTIONS][DT > 0 ? DT : SL_D];
+            constexpr int AM = AMAX > 0 ? AMAX : 1;
+            double mean[AM][DT > 0 ? DT : SL_D];
 #pragma unroll
-            for (int a = 0; a < SL_MAX_ACTIONS; ++a)
+            for (int a = 0; a < AM; ++a)
 #pragma unroll
                 for (int k = 0; k < (DT > 0 ? DT : SL_D); ++k) mean[a][k] = 0.0;
             for (int h = 0; h < gp.nheads; ++h) {
@@ -129,22 +137,24 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
                         }
                     }
                     const double s = hd.variance * exp(-0.5 * z);
+                    // s * alpha'[j][.] once per training point, then one FMA per (action, column)
+                    double sa[DT > 0 ? DT : SL_D];
 #pragma unroll
-                    for (int a = 0; a < SL_MAX_ACTIONS; ++a) {
-                        if (a < A) {
-                            const double kx = s * etab[j * A + a];
+                    for (int k = 0; k < (DT > 0 ? DT : SL_D); ++k) {
+                        const int dd = k - hd.col0;
+                        sa[k] = (dd >= 0 && dd < hd.dout) ? s * hd.alpha[j * hd.dout + dd] : 0.0;
+                    }
 #pragma unroll
-                            for (int k = 0; k < (DT > 0 ? DT : SL_D); ++k) {
-                                const int dd = k - hd.col0;
-                                if (dd >= 0 && dd < hd.dout)
-                                    mean[a][k] = fma(kx, hd.alpha[j * hd.dout + dd], mean[a][k]);
-                            }
-                        }
+                    for (int a = 0; a < AM; ++a) {
+                        const double e = etab[j * AM + a];
+#pragma unroll
+                        for (int k = 0; k < (DT > 0 ? DT : SL_D); ++k)
+                            mean[a][k] = fma(e, sa[k], mean[a][k]);
                     }
                 }
             }
 #pragma unroll
-            for (int a = 0; a < SL_MAX_ACTIONS; ++a) {
+            for (int a = 0; a < AM; ++a) {
                 if (a < A) {
                     double u[SL_M], prior[SL_D], nxt[SL_D];
 #pragma unroll
@@ -224,14 +234,16 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
     SL_HIP_CHECK(ctx, hipMemsetAsync(d_stats, 0, 2 * sizeof(double), ctx->stream));
     if (hi == lo) return SL_OK;
     size_t lds = 0;
+    int amax = 0;
     if (n_actions > 0) {
         SL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_actions, h_actions,
                                          sizeof(double) * n_actions * M.m.policy.m,
                                          hipMemcpyHostToDevice, ctx->stream));
         SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        amax = n_actions <= 3 ? 3 : (n_actions <= 9 ? 9 : SL_MAX_ACTIONS);
         if (is_gp)
             for (int h = 0; h < ctx->h_gp.nheads; ++h)
-                lds += sizeof(double) * (size_t)ctx->gp_heads[h].n_pad * n_actions;
+                lds += sizeof(double) * (size_t)ctx->gp_heads[h].n_pad * amax;
         if (lds > 150 * 1024)
             return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_bellman_sweep: action-factor table needs %zu "
                                                     "bytes of LDS", lds);
@@ -252,17 +264,18 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
                            ctx->h_gp, aux, lo, hi, n_actions, ctx->d_actions, d_v_new, d_argmax, \
                            d_q, d_stats);                                                        \
     } while (0)
-    if (n_actions > 0) {
-        if (variant == 4) SL_BELLMAN(true, 4, 1);
-        else if (variant == 2) SL_BELLMAN(true, 2, 1);
-        else if (variant == 1) SL_BELLMAN(true, 1, 1);
-        else SL_BELLMAN(true, 0, 0);
-    } else {
-        if (variant == 4) SL_BELLMAN(false, 4, 1);
-        else if (variant == 2) SL_BELLMAN(false, 2, 1);
-        else if (variant == 1) SL_BELLMAN(false, 1, 1);
-        else SL_BELLMAN(false, 0, 0);
-    }
+#define SL_BELLMAN_DIMS(AM_)                                     \
+    do {                                                        \
+        if (variant == 4) SL_BELLMAN(AM_, 4, 1);                \
+        else if (variant == 2) SL_BELLMAN(AM_, 2, 1);           \
+        else if (variant == 1) SL_BELLMAN(AM_, 1, 1);           \
+        else SL_BELLMAN(AM_, 0, 0);                             \
+    } while (0)
+    if (amax == 3) SL_BELLMAN_DIMS(3);
+    else if (amax == 9) SL_BELLMAN_DIMS(9);
+    else if (amax == SL_MAX_ACTIONS) SL_BELLMAN_DIMS(SL_MAX_ACTIONS);
+    else SL_BELLMAN_DIMS(0);
+#undef SL_BELLMAN_DIMS
 #undef SL_BELLMAN
     SL_HIP_CHECK(ctx, hipGetLastError());
     return SL_OK;

@@ -216,17 +216,43 @@ __device__ __forceinline__ void sl_lv_any(const SlDevModel& M, int d, const SlAu
     }
 }
 
+// V(z) and L_v(z) together: a network value function shares one forward pass between the value
+// and its input gradient (lyapunov_function_learning.ipynb cell 19: L_v = |grad V|_1).
+template <bool GENERAL>
+__device__ __forceinline__ double sl_value_and_lv(const SlDevModel& M, int d, const SlAux& aux,
+                                                  const double* z, double* lv) {
+    const int kind = M.m.lipschitz.lv_kind;
+    if (GENERAL && M.m.value.kind == SL_V_NETWORK &&
+        (kind == SL_LIP_ABS_GRAD || kind == SL_LIP_NORM_GRAD)) {
+        double g[SL_D];
+        double v = sl_network_value(*aux.net, z, d, g);
+        if (M.m.value.negate) v = v * -1.0;          // |grad| is sign independent
+        if (kind == SL_LIP_ABS_GRAD) {
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) if (k < d) lv[k] = fabs(g[k]);
+        } else {
+            double acc = fabs(g[0]);
+#pragma unroll
+            for (int k = 1; k < SL_D; ++k) if (k < d) acc = acc + fabs(g[k]);
+            lv[0] = acc;
+        }
+        return v;
+    }
+    sl_lv_any<GENERAL>(M, d, aux, z, lv);
+    return sl_value_any<GENERAL>(M, d, aux, z);
+}
+
 template <bool GENERAL>
 __device__ __forceinline__ SlCellCheck sl_cell_check(const SlDevModel& M, int d, const SlAux& aux,
                                                      const double* x, const double* next_mean,
                                                      const double* err) {
     SlCellCheck r;
     double lv_x[SL_D], lv_n[SL_D];
-    r.v_x = sl_value_any<GENERAL>(M, d, aux, x);
-    double v_next = sl_value_any<GENERAL>(M, d, aux, next_mean);
-    if (M.uncertain) sl_lv_any<GENERAL>(M, d, aux, next_mean, lv_n);
+    r.v_x = sl_value_and_lv<GENERAL>(M, d, aux, x, lv_x);
+    double v_next;
+    if (M.uncertain) v_next = sl_value_and_lv<GENERAL>(M, d, aux, next_mean, lv_n);
+    else v_next = sl_value_any<GENERAL>(M, d, aux, next_mean);
     r.decrease = sl_decrease(M, d, r.v_x, v_next, lv_n, err);
-    sl_lv_any<GENERAL>(M, d, aux, x, lv_x);
     r.threshold = sl_threshold(M, d, lv_x, M.m.lipschitz.tau);
     r.negative = r.decrease < r.threshold;
     return r;

@@ -26,6 +26,9 @@ typedef double sl_d4 __attribute__((ext_vector_type(4)));
 typedef double sl_d2 __attribute__((ext_vector_type(2)));
 
 #define SL_GP_SLABS_PER_CHUNK 16          // 64 training points per chunk
+#ifndef SL_GP_STAGGER
+#define SL_GP_STAGGER 1
+#endif
 #define SL_GP_DOUT_MAX SL_MAX_STATE_DIM
 
 // configurations: {W wavefronts, R row blocks per wavefront, CB cell blocks}
@@ -188,7 +191,11 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                             q1 = load_a(rowblk[r], 8 * ch + 1);
                         }
                     }
-                    if (ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
+                    // The two wavefronts that share a SIMD (w and w + 4) generate the next chunk at
+                    // opposite ends of this chunk's MFMA phase, so that one of them always feeds
+                    // the matrix pipe while the other computes exponentials on the VALU.
+                    const bool gen_first = (W < 8) || ((wave & 4) == 0) || !SL_GP_STAGGER;
+                    if (gen_first && ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
                     const double* kxb = kx_l + buf * KXBUF;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -218,6 +225,7 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                             q1 = q2;
                         }
                     }
+                    if (!gen_first && ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
                     __syncthreads();
                 }
                 // |a|^2 of this panel's rows (row order inside a tile does not matter)

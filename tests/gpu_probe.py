@@ -11,7 +11,7 @@ from safe_learning_amd.benchmarks import build_lyapunov, make_case
 
 out = {}
 ctx = _hip.Context()
-for per_cu in ("1", "2", "4"):
+for per_cu in (("2",) if os.environ.get("SL_PROBE_SWEEPS") == "short" else ("1", "2", "4")):
     os.environ["SL_PROBE_BLOCKS_PER_CU"] = per_cu
     for which, name in ((0, "mfma_f64"), (1, "valu_fma_f64"), (2, "both")):
         out["rate_%s_x%s" % (name, per_cu)] = ctx.debug_fp64_rate(which, 20000)
@@ -38,9 +38,11 @@ def time_sweep(family, num_points, n_gp, cfg, reps=3):
             "checks_per_s": n / (ms * 1e-3)}
 
 runs = []
-for args in [("cartpole", 32, 1024, 1), ("cartpole", 32, 1024, 2), ("cartpole", 48, 1024, 1),
-             ("pendulum", 512, 512, 1), ("pendulum", 512, 512, 2), ("pendulum", 512, 2048, 1),
-             ("pendulum", 512, 2048, 2)]:
+SWEEPS = [("cartpole", 48, 1024, 2), ("cartpole", 48, 1024, 1), ("pendulum", 512, 512, 2),
+          ("pendulum", 512, 2048, 2), ("pendulum", 512, 2048, 1)]
+if os.environ.get("SL_PROBE_SWEEPS") == "short":
+    SWEEPS = SWEEPS[:1] + SWEEPS[3:4]
+for args in SWEEPS:
     try:
         r = time_sweep(*args)
     except Exception as e:          # keep going: this is a probe
