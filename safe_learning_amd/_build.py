@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["sl_kernels.hip", "sl_gp.hip", "sl_bellman.hip"]
+SOURCES = ["sl_kernels.hip", "sl_gp.hip", "sl_bellman.hip", "sl_nn.hip"]
 LIB = os.path.join(HERE, "libslhip.so")
 
 

@@ -44,6 +44,8 @@ struct sl_ctx {
 
     void* d_scratch = nullptr;         // grown on demand (sl_eval_points)
     size_t scratch_bytes = 0;
+    void* d_records = nullptr;         // GP posterior records of the two-pass network check
+    size_t records_bytes = 0;
     sl_key* d_partials = nullptr;      // SL_MAX_GRID entries x 4 keys
     int64_t* d_partial_counts = nullptr;
     double* d_actions = nullptr;       // bellman action list
@@ -53,6 +55,15 @@ struct sl_ctx {
 extern thread_local std::string g_sl_last_error;
 
 int sl_fail(sl_ctx* ctx, int code, const char* fmt, ...);
+
+// launchers defined in the other translation units
+int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
+                       const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
+                       int* nblocks, double* d_dbg, const double* d_points);
+int sl_nn_values_launch(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values);
+int sl_nn_check_launch(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
+                       const double* d_values, const double* d_records, uint64_t* d_neg_bits,
+                       int* nblocks, double* d_dbg, const double* d_points);
 
 #define SL_HIP_CHECK(ctx, call)                                                             \
     do {                                                                                    \

@@ -431,14 +431,14 @@ extern "C" int sl_gp_configure(sl_ctx* ctx, int nheads, double beta) {
 }
 
 template <int W, int R, int CB, bool GENERAL, int DT, int MT>
-static int launch_cfg(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
-                      const double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
+static int launch_cfg(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
+                      const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
                       const double* d_points) {
     constexpr int C = 16 * CB;
     const int64_t nwords = (hi - lo + 63) / 64;
     const int64_t ntiles = nwords * (64 / C);
     int xs_doubles = 0;
-    const int p = ctx->h_model.in_dim;
+    const int p = model.in_dim;
     for (int h = 0; h < ctx->h_gp.nheads; ++h) {
         if (ctx->gp_heads[h].p != p)
             return sl_fail(ctx, SL_ERR_INVALID, "GP head %d has input dim %d, model has %d", h,
@@ -459,27 +459,27 @@ static int launch_cfg(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_ini
     if (blocks > SL_MAX_GRID) blocks = SL_MAX_GRID;
     *nblocks = (int)blocks;
     SlAux aux{ctx->d_tri, ctx->d_net};
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, ctx->stream, ctx->h_model,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, ctx->stream, model,
                        ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits, ctx->d_partials, d_dbg,
                        xs_doubles, d_points);
     SL_HIP_CHECK(ctx, hipGetLastError());
     return SL_OK;
 }
 
-int sl_gp_sweep_launch(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
-                       const double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
+int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
+                       const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
                        const double* d_points) {
     if (ctx->h_gp.nheads < 1)
         return sl_fail(ctx, SL_ERR_INVALID, "GP dynamics selected but sl_gp_configure not called");
     int covered = 0;
     for (int h = 0; h < ctx->h_gp.nheads; ++h) covered += ctx->gp_heads[h].dout;
-    if (covered != ctx->h_model.m.grid.d)
+    if (covered != model.m.grid.d)
         return sl_fail(ctx, SL_ERR_INVALID, "GP heads cover %d outputs, state dimension is %d",
-                       covered, ctx->h_model.m.grid.d);
-    const bool general = sl_model_is_general(ctx->h_model);
-    const int variant = sl_dim_variant_of(ctx->h_model);
+                       covered, model.m.grid.d);
+    const bool general = sl_model_is_general(model);
+    const int variant = sl_dim_variant_of(model);
 #define SL_GP_LAUNCH(W_, R_, CB_, G, D_, M_)                                                      \
-    return launch_cfg<W_, R_, CB_, G, D_, M_>(ctx, lo, hi, d_init_bits, d_values, d_neg_bits,     \
+    return launch_cfg<W_, R_, CB_, G, D_, M_>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,     \
                                               nblocks, d_dbg, d_points)
 #define SL_GP_CASE(id, W_, R_, CB_)                                                               \
     case id:                                                                                      \

@@ -85,6 +85,7 @@ extern "C" int sl_ctx_destroy(sl_ctx* ctx) {
     (void)hipFree(ctx->d_tri);
     (void)hipFree(ctx->d_net);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_records) (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_partials);
     (void)hipFree(ctx->d_partial_counts);
     (void)hipFree(ctx->d_actions);
@@ -250,10 +251,20 @@ extern "C" int sl_network_set(sl_ctx* ctx, int nlayers, const int32_t* h_dims,
     }
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (ctx->d_net_kernels) { (void)hipFree(ctx->d_net_kernels); ctx->d_net_kernels = nullptr; }
-    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_net_kernels, sizeof(double) * total));
-    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_net_kernels, h_kernels, sizeof(double) * total,
+    std::vector<double> both(2 * (size_t)total);
+    memcpy(both.data(), h_kernels, sizeof(double) * total);
+    for (int l = 0; l < nlayers; ++l) {
+        const int in = h_dims[l], out = h_dims[l + 1];
+        const double* src = h_kernels + n.koff[l];
+        double* dst = both.data() + total + n.koff[l];
+        for (int o = 0; o < out; ++o)
+            for (int i = 0; i < in; ++i) dst[(size_t)i * out + o] = src[(size_t)o * in + i];
+    }
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_net_kernels, sizeof(double) * 2 * total));
+    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_net_kernels, both.data(), sizeof(double) * 2 * total,
                                 hipMemcpyHostToDevice));
     n.kernels = ctx->d_net_kernels;
+    n.kernels_t = ctx->d_net_kernels + total;
     SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_net, &n, sizeof(SlNet), hipMemcpyHostToDevice));
     return SL_OK;
 }
@@ -323,6 +334,7 @@ extern "C" int sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values) 
         return sl_fail(ctx, SL_ERR_INVALID, "sl_values: bad range or NULL output");
     if (hi == lo) return SL_OK;
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (ctx->h_model.m.value.kind == SL_V_NETWORK) return sl_nn_values_launch(ctx, lo, hi, d_values);
     SlAux aux{ctx->d_tri, ctx->d_net};
     const int blocks = sl_grid_blocks(hi - lo);
 #define SL_CALL(G, D_, M_)                                                                    \
@@ -397,9 +409,6 @@ __global__ __launch_bounds__(SL_BLOCK) void k_reduce_fail(const sl_key* __restri
     if (threadIdx.x == 0) { result->fail.vbits = v; result->fail.index = i; }
 }
 
-int sl_gp_sweep_launch(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
-                       const double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
-                       const double* d_points);
 
 // shared by sl_lyap_sweep (grid cells) and sl_eval_points (explicit points)
 int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
@@ -415,9 +424,39 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
     int blocks = 1;
     if (hi == lo) {
         blocks = 0;
+    } else if (ctx->h_model.m.value.kind == SL_V_NETWORK) {
+        // network V: (1) GP posterior records from the MFMA kernel, (2) cooperative network check
+        const double* records = nullptr;
+        if (ctx->h_model.m.dynamics.kind == SL_DYN_GP) {
+            const int d = ctx->h_model.m.grid.d;
+            const size_t need = sizeof(double) * (size_t)(hi - lo) * (2 + 2 * d) +
+                                sizeof(uint64_t) * (size_t)((hi - lo + 63) / 64 + 1);
+            if (need > ctx->records_bytes) {
+                if (ctx->d_records) (void)hipFree(ctx->d_records);
+                ctx->d_records = nullptr;
+                ctx->records_bytes = 0;
+                SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_records, need));
+                ctx->records_bytes = need;
+            }
+            double* rec = reinterpret_cast<double*>(ctx->d_records);
+            uint64_t* tmp_bits = reinterpret_cast<uint64_t*>(rec + (size_t)(hi - lo) * (2 + 2 * d));
+            SlDevModel posterior_only = ctx->h_model;      // quadratic zero V, scalar L_v: fast path
+            memset(&posterior_only.m.value, 0, sizeof(posterior_only.m.value));
+            posterior_only.m.value.kind = SL_V_QUADRATIC;
+            posterior_only.m.lipschitz.lv_kind = SL_LIP_CONST;
+            posterior_only.m.lipschitz.lv_cols = 1;
+            int gp_blocks = 0;
+            rc = sl_gp_sweep_launch(ctx, posterior_only, lo, hi, nullptr, nullptr, tmp_bits,
+                                    &gp_blocks, rec, d_points);
+            if (rc) return rc;
+            records = rec;
+        }
+        rc = sl_nn_check_launch(ctx, lo, hi, d_init_bits, d_values, records, d_neg_bits, &blocks,
+                                d_dbg, d_points);
+        if (rc) return rc;
     } else if (ctx->h_model.m.dynamics.kind == SL_DYN_GP) {
-        rc = sl_gp_sweep_launch(ctx, lo, hi, d_init_bits, d_values, d_neg_bits, &blocks, d_dbg,
-                                d_points);
+        rc = sl_gp_sweep_launch(ctx, ctx->h_model, lo, hi, d_init_bits, d_values, d_neg_bits,
+                                &blocks, d_dbg, d_points);
         if (rc) return rc;
     } else {
         blocks = sl_grid_blocks(hi - lo);

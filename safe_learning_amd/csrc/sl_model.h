@@ -48,7 +48,8 @@ struct SlNet {
     int32_t dims[SL_MAX_NN_LAYERS + 1];
     int32_t act[SL_MAX_NN_LAYERS];
     int32_t koff[SL_MAX_NN_LAYERS];                  // offset of layer kernel in `kernels`
-    const double* kernels;                           // device
+    const double* kernels;                           // device, per layer [out][in]
+    const double* kernels_t;                         // device, per layer [in][out] (same offsets)
 };
 
 // ---------------------------------------------------------------------------------------------
