@@ -16,7 +16,8 @@ What it restates (reference file:line, relative to the upstream checkout):
   (_Triangulation), ``:1513-1583`` (QuadraticFunction, LinearSystem) and
   ``examples/utilities.py:48-104, 144-437`` (LyapunovNetwork, InvertedPendulum,
   CartPole).
-* ``oracle.np_lyapunov`` - ``safe_learning/lyapunov.py:22-56, 142-606``.
+* ``oracle.np_lyapunov`` - ``safe_learning/lyapunov.py:22-56, 142-606`` and ``:609-797``
+  (``perturb_actions``, ``get_safe_sample``).
 * ``oracle.np_rl`` - ``safe_learning/reinforcement_learning.py:26-140,
   213-279``.
 
@@ -50,5 +51,6 @@ from .np_functions import (ordered_matmul, QuadraticFunction, LinearSystem, Satu
                         InvertedPendulum, CartPole, LyapunovNetwork, AbsFunction,
                         Norm1Function, NegatedFunction, ConstantPolicy,
                         TriangulationGradient)
-from .np_lyapunov import Lyapunov, smallest_boundary_value, config
+from .np_lyapunov import (Lyapunov, smallest_boundary_value, config, get_safe_sample,
+                          perturb_actions, unique_rows)
 from .np_rl import PolicyIteration

@@ -160,3 +160,72 @@ class Lyapunov(object):
         if self.initial_safe_set is not None:                             # :604-606
             self.safe_set[self.initial_safe_set] = True
             self._refinement[self.initial_safe_set] = 1
+
+
+def unique_rows(array):
+    """Unique rows through a void view (byte-wise order).  Reference: ``utilities.py:496-516``."""
+    array = np.ascontiguousarray(array)
+    dtype = np.dtype((np.void, array.dtype.itemsize * array.shape[1]))
+    combined = array.view(dtype=dtype)
+    _, idx = np.unique(combined, return_index=True)
+    return array[idx]
+
+
+def perturb_actions(states, actions, perturbations, limits=None):
+    """All (state, action + perturbation) pairs, clipped and de-duplicated.
+    Reference: ``lyapunov.py:609-651``."""
+    num_states, state_dim = states.shape
+    states_new = np.repeat(states, len(perturbations), axis=0)
+    actions_new = (np.repeat(actions, len(perturbations), axis=0)
+                   + np.tile(perturbations, (num_states, 1)))
+    state_actions = np.column_stack((states_new, actions_new))
+    if limits is not None:
+        limits = np.asarray(limits)
+        view = state_actions[:, state_dim:]
+        np.clip(view, limits[:, 0], limits[:, 1], out=view)
+        state_actions = unique_rows(state_actions)
+    return state_actions
+
+
+def get_safe_sample(lyapunov, perturbations=None, limits=None, positive=False,
+                    num_samples=None, actions=None):
+    """Most uncertain state-action pair that provably maps back into the level set.
+    Reference: ``lyapunov.py:657-797`` (the warning of ``:782-783`` is kept)."""
+    import warnings
+    safe_idx = np.where(lyapunov.safe_set)
+    safe_states = lyapunov.discretization.index_to_state(safe_idx)
+    if num_samples is not None and len(safe_states) > num_samples:
+        idx = np.random.choice(len(safe_states), num_samples, replace=True)
+        safe_states = safe_states[idx]
+    if perturbations is None:
+        arrays = [arr.ravel() for arr in np.meshgrid(safe_states, actions, indexing='ij')]
+        state_actions = np.column_stack(arrays)
+        safe_actions = None
+    else:
+        safe_actions = lyapunov.policy(safe_states)
+        state_actions = perturb_actions(safe_states, safe_actions, perturbations=perturbations,
+                                        limits=limits)
+
+    def evaluate(state_actions):
+        mean, std = lyapunov.dynamics(state_actions)                    # :714
+        bound = ordered_rowsum(std)                                     # :715
+        lv = lyapunov.lipschitz_lyapunov(mean)                          # :716
+        error = ordered_rowsum(np.atleast_2d(lv * std))                 # :717
+        future_values = lyapunov.lyapunov_function(mean) + error        # :718-721
+        return mean, bound, np.less(future_values, lyapunov.c_max).squeeze(axis=1)
+
+    mean, bound, maps_inside = evaluate(state_actions)
+    if not positive:                                                    # :773-776
+        next_state_index = lyapunov.discretization.state_to_index(mean)
+        maps_inside = maps_inside & lyapunov.safe_set[next_state_index]
+    bound_safe = bound[maps_inside]
+    if len(bound_safe) == 0:                                            # :780-793
+        warnings.warn("No safe state-action pairs found! Using backup policy ...", RuntimeWarning)
+        zero_perturbation = np.array([[0.]], dtype=np.float64)
+        state_actions = perturb_actions(safe_states, safe_actions, perturbations=zero_perturbation,
+                                        limits=limits)
+        _, bound, _ = evaluate(state_actions)
+        max_id = np.argmax(bound)
+        return state_actions[[max_id]], bound[max_id].squeeze()
+    max_id = np.argmax(bound_safe)
+    return state_actions[maps_inside, :][[max_id]], bound_safe[max_id].squeeze()

@@ -346,6 +346,37 @@ class GPRCached(object):
         self.cholesky_inverse = np.tril(self.cholesky_inverse)
         self._version = getattr(self, '_version', 0) + 1
 
+    def append_data(self, x, y):
+        """Add observations with a rank-one extension of the cached factors, O(n^2) per point
+        instead of the reference's O(n^3) rebuild (``functions.py:525-546`` calls
+        ``update_cache``).  For ``L' = [[L, 0], [l^T, s]]``: ``l = L^-1 k(X, x)``,
+        ``s = sqrt(k(x, x) + sigma_n^2 - l.l)``, ``L'^-1 = [[L^-1, 0], [-(l^T L^-1)/s, 1/s]]`` and
+        ``alpha' = [alpha; (r - l^T alpha)/s]`` with ``r = y - m(x)``."""
+        x = np.atleast_2d(np.asarray(x, dtype=config.np_dtype))
+        y = np.atleast_2d(np.asarray(y, dtype=config.np_dtype))
+        for xi, yi in zip(x, y):
+            xi, yi = xi[None, :], yi[None, :]
+            n = len(self.X)
+            k_vec = self.kern.K(self.X, xi)[:, 0]
+            row = self.cholesky_inverse.dot(k_vec)                       # l = L^-1 k
+            s2 = self.kern.variance + self.likelihood_variance - row.dot(row)
+            if not s2 > 0:
+                raise np.linalg.LinAlgError('kernel matrix is not positive definite')
+            s = np.sqrt(s2)
+            resid = yi[0] - (xi.dot(self.mean_function.matrix.T)[0]
+                             if self.mean_function is not None else 0.0)
+            chol = np.zeros((n + 1, n + 1))
+            chol[:n, :n], chol[n, :n], chol[n, n] = self.cholesky, row, s
+            inv = np.zeros((n + 1, n + 1))
+            inv[:n, :n] = self.cholesky_inverse
+            inv[n, :n] = -row.dot(self.cholesky_inverse) / s
+            inv[n, n] = 1.0 / s
+            self.alpha = np.vstack((self.alpha, ((resid - row.dot(self.alpha)) / s)[None, :]))
+            self.cholesky, self.cholesky_inverse = chol, inv
+            self.X = np.vstack((self.X, xi))
+            self.Y = np.vstack((self.Y, yi))
+        self._version += 1
+
 
 class GaussianProcess(UncertainFunction):
     """``(mean, beta * sqrt(var))`` of a GP model (``functions.py:461-546``)."""
@@ -369,11 +400,9 @@ class GaussianProcess(UncertainFunction):
         return self.gaussian_process.Y
 
     def add_data_point(self, x, y):
-        """Append observations and rebuild the cache (``functions.py:525-546``)."""
-        gp = self.gaussian_process
-        gp.X = np.vstack((gp.X, np.atleast_2d(x)))
-        gp.Y = np.vstack((gp.Y, np.atleast_2d(y)))
-        gp.update_cache()
+        """Append observations (``functions.py:525-546``); the cached factors are extended by a
+        rank-one update instead of being rebuilt."""
+        self.gaussian_process.append_data(x, y)
 
 
 class FunctionStack(UncertainFunction):

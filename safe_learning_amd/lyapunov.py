@@ -23,7 +23,7 @@ from . import distributed as dist_utils
 from ._model import ModelBuilder
 from .configuration import config
 
-__all__ = ['Lyapunov', 'smallest_boundary_value']
+__all__ = ['Lyapunov', 'smallest_boundary_value', 'get_safe_sample', 'perturb_actions']
 
 _U64_MAX = (1 << 64) - 1
 _I64_MAX = (1 << 63) - 1
@@ -378,3 +378,76 @@ class _CMaxView(dict):
 
     def __getitem__(self, key):
         return self._owner.c_max
+
+
+def _unique_rows(array):
+    """Unique rows in byte-wise order (``safe_learning/utilities.py:496-516``)."""
+    array = np.ascontiguousarray(array)
+    void = np.dtype((np.void, array.dtype.itemsize * array.shape[1]))
+    _, keep = np.unique(array.view(void), return_index=True)
+    return array[keep]
+
+
+def perturb_actions(states, actions, perturbations, limits=None):
+    """State-action pairs around a baseline policy (``lyapunov.py:609-651``): every state is
+    paired with ``action + perturbation`` for every perturbation row; with ``limits`` the actions
+    are clipped and duplicate rows dropped."""
+    states = np.asarray(states, dtype=np.float64)
+    perturbations = np.atleast_2d(np.asarray(perturbations, dtype=np.float64))
+    count, state_dim = len(perturbations), states.shape[1]
+    pairs = np.column_stack((np.repeat(states, count, axis=0),
+                             np.repeat(actions, count, axis=0)
+                             + np.tile(perturbations, (len(states), 1))))
+    if limits is not None:
+        limits = np.asarray(limits, dtype=np.float64)
+        np.clip(pairs[:, state_dim:], limits[:, 0], limits[:, 1], out=pairs[:, state_dim:])
+        pairs = _unique_rows(pairs)
+    return pairs
+
+
+def get_safe_sample(lyapunov, perturbations=None, limits=None, positive=False,
+                    num_samples=None, actions=None):
+    """Most uncertain safe state-action pair for the next measurement (``lyapunov.py:657-797``).
+
+    The candidate bookkeeping is host-side NumPy as in the reference; the GP posterior, ``V`` and
+    ``L_v`` at the candidates are evaluated by the HIP kernels (explicit-point mode of the sweep
+    kernels).  Returns ``(state_action[1, d+m], bound)``."""
+    import warnings
+    from . import _evaluate
+    grid = lyapunov.discretization
+    safe_states = grid.index_to_state(np.where(lyapunov.safe_set)[0])
+    if num_samples is not None and len(safe_states) > num_samples:
+        safe_states = safe_states[np.random.choice(len(safe_states), num_samples, replace=True)]
+    safe_actions = None
+    if perturbations is None:
+        mesh = np.meshgrid(safe_states, actions, indexing='ij')
+        state_actions = np.column_stack([m.ravel() for m in mesh])
+    else:
+        safe_actions = _evaluate.policy(lyapunov.policy, safe_states)
+        state_actions = perturb_actions(safe_states, safe_actions, perturbations, limits)
+    d = grid.ndim
+
+    def evaluate(pairs):
+        mean, std = _evaluate.dynamics(lyapunov.dynamics, pairs[:, :d], pairs[:, d:])
+        value, lv = _evaluate.value(lyapunov.lyapunov_function, mean, lyapunov._lipschitz_lyapunov)
+        bound = std[:, [0]].copy()
+        scaled = lv * std
+        error = scaled[:, [0]].copy()
+        for k in range(1, std.shape[1]):
+            bound = bound + std[:, [k]]
+            error = error + scaled[:, [k]]
+        return mean, bound, ((value + error) < lyapunov.c_max)[:, 0]
+
+    mean, bound, maps_inside = evaluate(state_actions)
+    if not positive:
+        maps_inside &= lyapunov.safe_set[grid.state_to_index(mean)]
+    if not maps_inside.any():
+        warnings.warn("No safe state-action pairs found! Using backup policy ...", RuntimeWarning)
+        state_actions = perturb_actions(safe_states, safe_actions, np.array([[0.]]), limits)
+        _, bound, _ = evaluate(state_actions)
+        best = int(np.argmax(bound))
+        return state_actions[[best]], float(bound[best, 0])
+    candidates = state_actions[maps_inside]
+    bound = bound[maps_inside]
+    best = int(np.argmax(bound))
+    return candidates[[best]], float(bound[best, 0])

@@ -289,3 +289,23 @@ def test_policy_iteration_integration(golden):
 
     assert_allclose(value_function.parameters, true_value(rl.state_space), atol=g["atol"])
     assert_allclose(policy.parameters, -k * pgrid.all_points, atol=g["atol"])
+
+
+def test_rank_one_cache_update_matches_rebuild():
+    """safe_learning_amd.GPRCached.append_data (O(n^2)) == full rebuild (functions.py:395-415)."""
+    from safe_learning_amd import functions as F
+    rng = np.random.default_rng(2)
+    X, Y = rng.uniform(-1, 1, (30, 3)), rng.normal(size=(30, 2))
+    prior = rng.normal(size=(2, 3))
+    kern = F.RBF(3, 0.3, [0.5, 0.7, 1.1], ARD=True)
+    gp = F.GPRCached(X[:25], Y[:25], kern, F.LinearSystem((prior,)), likelihood_variance=0.01)
+    gp.append_data(X[25:], Y[25:])
+    full = F.GPRCached(X, Y, kern, F.LinearSystem((prior,)), likelihood_variance=0.01)
+    assert_allclose(gp.cholesky, full.cholesky, rtol=1e-10, atol=1e-13)
+    assert_allclose(gp.cholesky_inverse, full.cholesky_inverse, rtol=1e-9, atol=1e-12)
+    assert_allclose(gp.alpha, full.alpha, rtol=1e-9, atol=1e-12)
+    # and both equal the oracle's cache
+    ogp = GPRCached(X, Y, RBF(3, 0.3, [0.5, 0.7, 1.1], ARD=True), LinearSystem((prior,)),
+                    likelihood_variance=0.01)
+    assert_allclose(full.cholesky, ogp.cholesky, rtol=1e-11, atol=1e-14)
+    assert_allclose(full.alpha, ogp.alpha, rtol=1e-9, atol=1e-12)
