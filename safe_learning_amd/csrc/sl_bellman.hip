@@ -103,7 +103,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
 #pragma unroll
                     for (int k = 0; k < SL_D; ++k) if (k < d) nxt[k] = nxt[k] + prior[k];
                 } else {
-                    sl_dynamics_det(M, nd, x, nxt);
+                    sl_dynamics_det<0>(M, nd, x, nxt);
                 }
                 const double r = sl_quadratic(M.m.reward, p, x);
                 double v = sl_tri_eval(vt, nxt, 0, nullptr);

@@ -349,7 +349,7 @@ extern "C" int sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values) 
 // =============================================================================================
 // deterministic-dynamics decrease check                    (lyapunov.py:436-441, 524-535)
 // =============================================================================================
-template <bool GENERAL, int DT, int MT>
+template <bool GENERAL, int DT, int MT, int DYN>
 __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
     const SlDevModel M, SlAux aux, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
     const double* __restrict__ values, uint64_t* __restrict__ neg_bits,
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
             sl_cell_state(M, d, idx, points, x);
             sl_policy_any<GENERAL>(M, n, aux.tri, idx, x, u);
             sl_append_action(n, u, x);
-            sl_dynamics_det(M, n, x, nxt);
+            sl_dynamics_det<DYN>(M, n, x, nxt);
             SlCellCheck c = sl_cell_check<GENERAL>(M, d, aux, x, nxt, err);
             negative = c.negative;
             v_x = values ? values[idx - lo] : c.v_x;       // ordering key: lyapunov.py:512
@@ -461,12 +461,21 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
     } else {
         blocks = sl_grid_blocks(hi - lo);
         SlAux aux{ctx->d_tri, ctx->d_net};
+        const int dyn = ctx->h_model.m.dynamics.kind;
+#define SL_LAUNCH_DET(G, D_, M_, DYN_)                                                          \
+    hipLaunchKernelGGL((k_det_sweep<G, D_, M_, DYN_>), dim3(blocks), dim3(SL_BLOCK), 0,         \
+                       ctx->stream, ctx->h_model, aux, lo, hi, d_init_bits, d_values,          \
+                       d_neg_bits, ctx->d_partials, d_dbg, d_points)
 #define SL_CALL(G, D_, M_)                                                                     \
-    hipLaunchKernelGGL((k_det_sweep<G, D_, M_>), dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream, \
-                       ctx->h_model, aux, lo, hi, d_init_bits, d_values, d_neg_bits,           \
-                       ctx->d_partials, d_dbg, d_points)
+    do {                                                                                       \
+        if (!(G) && (D_) > 0 && dyn == SL_DYN_LINEAR) SL_LAUNCH_DET(G, D_, M_, SL_DYN_LINEAR); \
+        else if (!(G) && (D_) == 2 && dyn == SL_DYN_PENDULUM) SL_LAUNCH_DET(G, D_, M_, SL_DYN_PENDULUM); \
+        else if (!(G) && (D_) == 4 && dyn == SL_DYN_CARTPOLE) SL_LAUNCH_DET(G, D_, M_, SL_DYN_CARTPOLE); \
+        else SL_LAUNCH_DET(G, D_, M_, 0);                                                      \
+    } while (0)
         SL_DISPATCH_DIMS(sl_dim_variant(ctx->h_model), sl_model_is_general(ctx->h_model), SL_CALL);
 #undef SL_CALL
+#undef SL_LAUNCH_DET
         SL_HIP_CHECK(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(k_reduce_fail, dim3(1), dim3(SL_BLOCK), 0, ctx->stream, ctx->d_partials,

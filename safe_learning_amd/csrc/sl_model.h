@@ -499,14 +499,20 @@ SL_HD void sl_append_action(SlDims n, const double* u, double* z) {
     }
 }
 
-// deterministic dynamics f(z), z = [x, u] (an SL_P-sized array)
+// deterministic dynamics f(z), z = [x, u] (an SL_P-sized array).  DYN > 0 fixes the kind at
+// compile time (the kernels are instantiated per kind so that the other kinds' constants and code
+// do not occupy scalar registers).
+template <int DYN = 0>
 SL_HD void sl_dynamics_det(const SlDevModel& M, SlDims n, const double* z, double* nxt) {
     const sl_dynamics_desc& f = M.m.dynamics;
-    double u0 = 0.0;
+    const int kind = DYN > 0 ? DYN : f.kind;
+    if (kind == SL_DYN_PENDULUM || kind == SL_DYN_CARTPOLE) {
+        double u0 = 0.0;
 #pragma unroll
-    for (int q = 0; q < SL_P; ++q) if (q == n.d) u0 = z[q];
-    if (f.kind == SL_DYN_PENDULUM) { sl_pendulum(f, z, &u0, nxt); return; }
-    if (f.kind == SL_DYN_CARTPOLE) { sl_cartpole(f, z, &u0, nxt); return; }
+        for (int q = 0; q < SL_P; ++q) if (q == n.d) u0 = z[q];
+        if (kind == SL_DYN_PENDULUM) sl_pendulum(f, z, &u0, nxt); else sl_cartpole(f, z, &u0, nxt);
+        return;
+    }
     sl_rows_dot<SL_D, SL_P>(f.matrix, n.d, n.p, z, nxt);
 }
 

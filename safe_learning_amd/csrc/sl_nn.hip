@@ -171,7 +171,7 @@ __global__ __launch_bounds__(SL_NN_BLOCK) void k_nn_check(
         } else {
             sl_policy_any<true>(M, n, aux.tri, idx, x, u);
             sl_append_action(n, u, x);
-            sl_dynamics_det(M, n, x, nxt);
+            sl_dynamics_det<0>(M, n, x, nxt);
         }
         double v_x = nn_eval(net, act, lane, wave, x, d, grad_lv ? g : nullptr);
         if (grad_lv) nn_lv_from_grad(lvk, d, g, lv_x); else sl_lv(M, d, x, lv_x);

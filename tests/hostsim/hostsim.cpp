@@ -40,7 +40,7 @@ int hs_det_cells(const sl_model_desc* desc, int64_t lo, int64_t hi, double* valu
         sl_index_to_state(M.m.grid, M.gf, d, idx, x);
         sl_policy_closed_form(M, n, x, u);
         sl_append_action(n, u, x);
-        sl_dynamics_det(M, n, x, nxt);
+        sl_dynamics_det<0>(M, n, x, nxt);
         const double v_x = sl_quadratic(M.m.value, d, x);
         const double v_n = sl_quadratic(M.m.value, d, nxt);
         const double dec = sl_decrease(M, d, v_x, v_n, lv_n, err);
