@@ -235,7 +235,10 @@ class Lyapunov(object):
             version = 'none'
         else:
             arr = np.asarray(init)
-            version = (id(init), arr.shape, arr.dtype.str, int(np.count_nonzero(arr)))
+            # large masks are identified by object identity (re-assign ``initial_safe_set`` after
+            # editing one in place); small ones also by content
+            checksum = int(np.count_nonzero(arr)) if arr.size <= (1 << 20) else -1
+            version = (id(init), arr.shape, arr.dtype.str, checksum)
         if version == self._init_version:
             return
         if init is None:
