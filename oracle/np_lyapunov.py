@@ -118,12 +118,39 @@ class Lyapunov(object):
         threshold = self.threshold(states, self.tau)
         return np.squeeze(np.less(decrease, threshold), axis=1)
 
+    def _decrease_and_threshold(self, states):
+        actions = self.policy(states)
+        next_states = self.dynamics(states, actions)
+        decrease = self.v_decrease_bound(states, next_states)
+        threshold = np.broadcast_to(self.threshold(states, self.tau), decrease.shape)
+        return decrease, threshold
+
+    def n_required(self, states, safety_factor):
+        """Refinement ``N(x)`` with ``dv < threshold(tau / N)``.  Reference: ``lyapunov.py:445-454``."""
+        decrease, threshold = self._decrease_and_threshold(states)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            ratio = safety_factor * threshold / decrease
+        n_req = np.where(np.isnan(ratio), 0., ratio)
+        return np.ceil(np.maximum(n_req, 0))
+
+    def refined_negative(self, states, refinement):
+        """``refined_safety_check`` mapped over the fed states.  Reference: ``lyapunov.py:459-485``.
+
+        As written in the reference the refined points are built but never evaluated: every row
+        compares the decrease of the WHOLE fed batch with its own refined threshold
+        ``threshold(center, tau / n_req)`` and reduces with ``all`` - restated as is."""
+        decrease, _ = self._decrease_and_threshold(states)
+        out = np.zeros(len(states), dtype=bool)
+        for k in range(len(states)):
+            n_req = int(refinement[k])
+            refined_threshold = self.threshold(states[[k]], self.tau / n_req)
+            out[k] = np.all(np.less(decrease, refined_threshold))
+        return out
+
     def update_safe_set(self, can_shrink=True, max_refinement=1, safety_factor=1.,
                         parallel_iterations=1):
-        """Non-adaptive branch of ``lyapunov.py:407-606``."""
-        if self.adaptive and max_refinement > 1:
-            raise NotImplementedError('adaptive refinement is outside the oracle (SURVEY 8f-2)')
-
+        """``lyapunov.py:407-606`` including the adaptive branch (``:540-582``)."""
+        safety_factor = np.maximum(safety_factor, 1.)                     # :428
         if can_shrink:                                                    # :500-506
             safe_sorted_src = np.zeros_like(self.safe_set, dtype=bool)
             refinement_src = np.zeros_like(self._refinement, dtype=int)
@@ -138,7 +165,7 @@ class Lyapunov(object):
         safe_sorted = safe_sorted_src[order]                              # :513 (copy)
         refinement = refinement_src[order]
 
-        start = bound = 0
+        start = bound = refine_bound = 0
         for start, (indices, safe_batch, refine_batch) in batchify(
                 (order, safe_sorted, refinement), config.gp_batch_size):  # :517-524
             states = self.discretization.index_to_state(indices)
@@ -146,12 +173,32 @@ class Lyapunov(object):
             safe_batch |= negative                                        # :530
             refine_batch[negative] = 1                                    # :531
             bound = int(np.argmin(safe_batch))                            # :535 first False, 0 if none
+            refine_bound = 0
             if bound > 0 or not safe_batch[0]:                            # :539
-                safe_batch[bound:] = False                                # :585
-                refine_batch[bound:] = 0                                  # :586
-                break                                                     # :587
+                if self.adaptive and max_refinement > 1:                  # :540
+                    refine_batch[bound:] = self.n_required(states[bound:], safety_factor).ravel()
+                    idx_safe = np.logical_or(negative, self.initial_safe_set[indices])   # :547
+                    refine_batch[idx_safe] = 1
+                    states_to_check = np.logical_and(refine_batch >= 1,
+                                                     refine_batch <= max_refinement)[bound:]
+                    stop = len(states_to_check) if np.all(states_to_check) \
+                        else int(np.argmin(states_to_check))
+                    if stop > 0:                                          # :562-575
+                        refined_safe = self.refined_negative(states[bound:bound + stop],
+                                                             refine_batch[bound:bound + stop])
+                        refine_bound = len(refined_safe) if np.all(refined_safe) \
+                            else int(np.argmin(refined_safe))
+                        safe_batch[bound:bound + refine_bound] = True
+                    if stop < len(states_to_check) or refine_bound < stop:    # :579-582
+                        safe_batch[bound + refine_bound:] = False
+                        refine_batch[bound + refine_bound:] = 0
+                        break
+                else:
+                    safe_batch[bound:] = False                            # :585
+                    refine_batch[bound:] = 0                              # :586
+                    break                                                 # :587
 
-        max_index = start + bound - 1                                     # :590 (refine_bound = 0)
+        max_index = start + bound + refine_bound - 1                      # :590
         self.c_max = self.values[order[max_index]]                        # :595
 
         self.safe_set[:] = False                                          # :598-601

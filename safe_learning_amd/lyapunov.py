@@ -68,9 +68,7 @@ class Lyapunov(object):
         self._lipschitz_dynamics = lipschitz_dynamics
         self._lipschitz_lyapunov = lipschitz_lyapunov
         self.adaptive = adaptive
-        if adaptive:
-            raise NotImplementedError('adaptive refinement (lyapunov.py:445-487, 540-582) is not '
-                                      'part of the accelerated path yet')
+        self._refinement_host = None
         self.c_max = 0.
         self.feed_dict = _CMaxView(self)
         self.initial_safe_set = initial_set
@@ -210,8 +208,10 @@ class Lyapunov(object):
 
     @property
     def _refinement(self):
-        """Refinement N(x) of the non-adaptive case: 1 on safe cells, 0 elsewhere
-        (``lyapunov.py:220-225, 531, 586, 601-606``)."""
+        """Refinement N(x) per cell (``lyapunov.py:220-225``): the array kept by the adaptive
+        branch, otherwise 1 on safe cells and 0 elsewhere (``:531, 586, 601-606``)."""
+        if self._refinement_host is not None:
+            return self._refinement_host
         return self.safe_set.astype(int)
 
     def is_safe(self, state):
@@ -265,7 +265,12 @@ class Lyapunov(object):
 
     def update_safe_set(self, can_shrink=True, max_refinement=1, safety_factor=1.,
                         parallel_iterations=1):
-        """Recompute the safe set (``lyapunov.py:407-606``, non-adaptive branch)."""
+        """Recompute the safe set (``lyapunov.py:407-606``).  ``max_refinement > 1`` on an adaptive
+        instance takes the adaptive branch (``:540-582``): the per-cell quantities still come from
+        one GPU sweep, the sequential refinement bookkeeping runs on the host like the reference's."""
+        if self.adaptive and max_refinement > 1:
+            return self._update_safe_set_adaptive(can_shrink, max_refinement, safety_factor)
+        self._refinement_host = None
         self._upload_model()
         self._refresh_init_bits()
         if not can_shrink and not self._safe_dev_valid:          # lyapunov.py:507-510
@@ -275,6 +280,87 @@ class Lyapunov(object):
                                  can_shrink, self._ctx.torch_device)
         self._safe_host_valid = False
         self._safe_dev_valid = True
+
+
+    def _update_safe_set_adaptive(self, can_shrink, max_refinement, safety_factor):
+        """Adaptive discretisation (``lyapunov.py:445-487, 540-582``), bug-compatible: as written
+        in the reference the refined check compares the decrease of every cell of the candidate
+        run with each cell's refined threshold ``threshold(x, tau / N(x))`` (the refined points
+        themselves are never evaluated), see DESIGN.md."""
+        import torch
+        if self._world != 1:
+            raise NotImplementedError('adaptive refinement runs on a single rank')
+        grid, n, d = self.discretization, self.discretization.nindex, self.discretization.ndim
+        batch = int(config.gp_batch_size)
+        safety_factor = max(float(safety_factor), 1.)
+        self._upload_model()
+        self._refresh_init_bits()
+        # one sweep: negative mask and the per-cell [decrease, threshold] records
+        records = torch.empty((n, 2 + 2 * d), dtype=torch.float64, device=self._ctx.torch_device)
+        self._ctx.lyap_sweep(0, n, self._d_init, self._d_values, self._d_neg, self._d_result, records)
+        rec = records[:, :2].cpu().numpy()
+        decrease, threshold = rec[:, 0], rec[:, 1]
+        negative = np.unpackbits(self._d_neg.cpu().numpy().view(np.uint8),
+                                 bitorder='little')[:n].astype(bool)
+        values = self.values
+        # -|L_v(x)|_1 (1 + L_f): the refined threshold is this times tau / N(x)
+        base = self.threshold(grid.index_to_state(np.arange(n)), tau=1.0)
+        base = np.broadcast_to(np.asarray(base, dtype=np.float64).reshape(-1), (n,)) \
+            if np.ndim(base) else np.full(n, float(base))
+        init_mask = np.zeros(n, dtype=bool)
+        if self._initial_safe_set is not None:
+            init_mask[self._initial_safe_set] = True
+
+        if can_shrink:
+            safe_src = init_mask.copy()
+            refine_src = init_mask.astype(int)
+        else:
+            safe_src = self.safe_set.copy()
+            refine_src = np.array(self._refinement, dtype=int)
+        order = np.argsort(values, kind='stable')
+        safe_sorted, refinement = safe_src[order], refine_src[order]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            ratio = safety_factor * threshold / decrease
+        n_req_all = np.ceil(np.maximum(np.where(np.isnan(ratio), 0., ratio), 0.))
+
+        start = bound = refine_bound = 0
+        for start in range(0, n, batch):
+            idx = order[start:start + batch]
+            safe_b, ref_b = safe_sorted[start:start + batch], refinement[start:start + batch]
+            neg_b = negative[idx]
+            safe_b |= neg_b
+            ref_b[neg_b] = 1
+            unsafe = np.flatnonzero(~safe_b)
+            bound, refine_bound = (int(unsafe[0]) if len(unsafe) else 0), 0
+            if not len(unsafe):
+                continue
+            ref_b[bound:] = n_req_all[idx[bound:]]
+            ref_b[neg_b | init_mask[idx]] = 1
+            checkable = ((ref_b >= 1) & (ref_b <= max_refinement))[bound:]
+            stop = len(checkable) if checkable.all() else int(np.argmin(checkable))
+            if stop > 0:
+                run = idx[bound:bound + stop]
+                run_dec = decrease[run]
+                refined_thr = base[run] * (self.tau / ref_b[bound:bound + stop])
+                worst = np.max(run_dec) if not np.isnan(run_dec).any() else np.inf
+                refined_safe = worst < refined_thr
+                refine_bound = stop if refined_safe.all() else int(np.argmin(refined_safe))
+                safe_b[bound:bound + refine_bound] = True
+            if stop < len(checkable) or refine_bound < stop:
+                safe_b[bound + refine_bound:] = False
+                ref_b[bound + refine_bound:] = 0
+                break
+
+        self.c_max = float(values[order[start + bound + refine_bound - 1]])
+        self._safe_host[:] = False
+        self._safe_host[order[safe_sorted]] = True
+        self._refinement_host = np.zeros(n, dtype=int)
+        self._refinement_host[order] = refinement
+        if self._initial_safe_set is not None:
+            self._safe_host[self._initial_safe_set] = True
+            self._refinement_host[self._initial_safe_set] = 1
+        self._safe_host_valid = True
+        self._safe_dev_valid = False
 
 
 class _HipShardEngine(object):

@@ -449,3 +449,32 @@ def test_point_evaluation_api(sl, name, kw):
                     rtol=1e-7, atol=1e-12)
     grad = sl.LinearSystem((2 * case["P"],))
     assert_allclose(grad(x), oracle.LinearSystem((2 * case["P"],))(x), rtol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------
+# adaptive branch (lyapunov.py:445-487, 540-582), bug-compatible restatement
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kw", [
+    ("pendulum", dict(num_points=61, dynamics="analytic", tau_scale=1.0)),
+    ("pendulum", dict(num_points=61, dynamics="analytic", tau_scale=0.05)),
+    ("pendulum", dict(num_points=45, n_gp=80, tau_scale=0.3, noise_std=0.001)),
+    ("pendulum", dict(num_points=45, dynamics="linear", tau_scale=0.02)),
+])
+def test_adaptive_branch(sl, name, kw, small_batches):
+    from safe_learning_amd.benchmarks import build_specs
+    case = cases.make_case(name, **kw)
+    init = np.zeros(int(np.prod(case["num_points"])), dtype=bool)
+    init[cases.initial_safe_mask(case)] = True
+    policy, dynamics, value, lv = build_specs(case)
+    lyap = sl.Lyapunov(sl.GridWorld(case["limits"], case["num_points"]), value, dynamics, case["lf"],
+                       lv, case["tau"], policy, initial_set=init, adaptive=True)
+    opolicy, odynamics, ovalue, olv = cases.oracle_specs(case)
+    olyap = oracle.Lyapunov(oracle.GridWorld(case["limits"], case["num_points"]), ovalue, odynamics,
+                            case["lf"], olv, case["tau"], opolicy, initial_set=init, adaptive=True)
+    for shrink, factor in ((True, 1.0), (False, 1.5), (True, 1.0)):
+        lyap.update_safe_set(can_shrink=shrink, max_refinement=16, safety_factor=factor)
+        olyap.update_safe_set(can_shrink=shrink, max_refinement=16, safety_factor=factor)
+        assert_array_equal(lyap.safe_set, olyap.safe_set)
+        assert_array_equal(lyap._refinement, olyap._refinement)
+        assert lyap.c_max == olyap.c_max
+        lyap.tau = olyap.tau = lyap.tau * 0.5
