@@ -52,5 +52,5 @@ from .np_functions import (ordered_matmul, QuadraticFunction, LinearSystem, Satu
                         Norm1Function, NegatedFunction, ConstantPolicy,
                         TriangulationGradient)
 from .np_lyapunov import (Lyapunov, smallest_boundary_value, config, get_safe_sample,
-                          perturb_actions, unique_rows)
+                          perturb_actions, unique_rows, get_lyapunov_region)
 from .np_rl import PolicyIteration

@@ -276,3 +276,38 @@ def get_safe_sample(lyapunov, perturbations=None, limits=None, positive=False,
         return state_actions[[max_id]], bound[max_id].squeeze()
     max_id = np.argmax(bound_safe)
     return state_actions[maps_inside, :][[max_id]], bound_safe[max_id].squeeze()
+
+
+def get_lyapunov_region(lyapunov, discretization, init_node):
+    """Flood fill of the region around ``init_node`` in which ``lyapunov`` increases monotonically
+    along the fill order.  Reference: ``lyapunov.py:59-139`` (heap order, tie-breaking counter,
+    boundary stop and pruning of unvisited queue entries kept as they are)."""
+    import itertools
+    from heapq import heappush, heappop
+    values = np.asarray(lyapunov(discretization.all_points)).reshape(discretization.num_points)
+    init_node = tuple(int(v) for v in init_node)
+    ndim, num_points = discretization.ndim, discretization.num_points
+    offsets = np.array(tuple(itertools.product(*[(0, -1, 1) for _ in range(ndim)]))[1:])
+    visited = np.zeros(num_points, dtype=bool)
+    visited[init_node] = True
+    tiebreaker = itertools.count()
+    last_value = values[init_node]
+    queue = [(values[init_node], next(tiebreaker), np.array(init_node))]
+    while queue:
+        value, _, node = heappop(queue)
+        if np.any(node == 0) or np.any(node == num_points - 1):       # :107-109
+            visited[tuple(node)] = False
+            break
+        if value < last_value:                                        # :112-113
+            break
+        last_value = value
+        neighbors = node + offsets
+        is_new = ~visited[tuple(neighbors.T)]
+        neighbors = neighbors[is_new]
+        if neighbors.size:
+            visited[tuple(neighbors.T)] = True
+            for nvalue, neighbor in zip(values[tuple(neighbors.T)], neighbors):
+                heappush(queue, (nvalue, next(tiebreaker), neighbor))
+    for _, _, node in queue:                                          # :136-137
+        visited[tuple(node)] = False
+    return visited

@@ -23,7 +23,8 @@ from . import distributed as dist_utils
 from ._model import ModelBuilder
 from .configuration import config
 
-__all__ = ['Lyapunov', 'smallest_boundary_value', 'get_safe_sample', 'perturb_actions']
+__all__ = ['Lyapunov', 'smallest_boundary_value', 'get_safe_sample', 'perturb_actions',
+           'get_lyapunov_region']
 
 _U64_MAX = (1 << 64) - 1
 _I64_MAX = (1 << 63) - 1
@@ -540,3 +541,42 @@ def get_safe_sample(lyapunov, perturbations=None, limits=None, positive=False,
     bound = bound[maps_inside]
     best = int(np.argmax(bound))
     return candidates[[best]], float(bound[best, 0])
+
+
+def get_lyapunov_region(lyapunov, discretization, init_node):
+    """Region around ``init_node`` in which the function ``lyapunov`` keeps increasing when the
+    grid is flooded in order of increasing value (``lyapunov.py:59-139``).  The values come from
+    the engine's value pass; the priority-queue flood fill is inherently sequential and runs on the
+    host exactly like the reference's (same neighbour order and tie-breaking counter)."""
+    import heapq
+    import itertools
+    helper = Lyapunov.__new__(Lyapunov)
+    helper._bare_init(discretization, lyapunov)
+    shape = tuple(int(v) for v in discretization.num_points)
+    values = helper.values.reshape(shape)
+    ndim = discretization.ndim
+    steps = np.array(list(itertools.product((0, -1, 1), repeat=ndim))[1:])
+    upper = np.array(shape) - 1
+    start = tuple(int(v) for v in init_node)
+    visited = np.zeros(shape, dtype=bool)
+    visited[start] = True
+    counter = itertools.count()
+    heap = [(values[start], next(counter), start)]
+    last = values[start]
+    while heap:
+        value, _, node = heapq.heappop(heap)
+        at = np.array(node)
+        if (at == 0).any() or (at == upper).any():
+            visited[node] = False
+            break
+        if value < last:
+            break
+        last = value
+        for step in steps:
+            nb = tuple(int(v) for v in at + step)
+            if not visited[nb]:
+                visited[nb] = True
+                heapq.heappush(heap, (values[nb], next(counter), nb))
+    for _, _, node in heap:
+        visited[node] = False
+    return visited

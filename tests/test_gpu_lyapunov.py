@@ -478,3 +478,21 @@ def test_adaptive_branch(sl, name, kw, small_batches):
         assert_array_equal(lyap._refinement, olyap._refinement)
         assert lyap.c_max == olyap.c_max
         lyap.tau = olyap.tau = lyap.tau * 0.5
+
+
+def test_get_lyapunov_region(sl):
+    """Flood fill of lyapunov.py:59-139 on engine values vs the oracle."""
+    limits, num = [[-1, 1], [-1, 1]], [21, 25]
+    P = np.array([[1.0, 0.3], [0.3, 0.5]])
+    region = sl.get_lyapunov_region(sl.QuadraticFunction(P), sl.GridWorld(limits, num), (10, 12))
+    ref = oracle.get_lyapunov_region(oracle.QuadraticFunction(P), oracle.GridWorld(limits, num),
+                                     (10, 12))
+    assert ref.sum() > 20
+    assert_array_equal(region, ref)
+    # a table with a local bump: the fill must stop where the values decrease
+    grid, ogrid = sl.GridWorld(limits, num), oracle.GridWorld(limits, num)
+    pts = ogrid.all_points
+    vals = np.einsum("ij,jk,ik->i", pts, P, pts) - 0.4 * np.exp(-20 * ((pts[:, 0] - 0.5) ** 2 + pts[:, 1] ** 2))
+    region = sl.get_lyapunov_region(sl.Triangulation(grid, vals), grid, (10, 12))
+    ref = oracle.get_lyapunov_region(oracle.Triangulation(ogrid, vals), ogrid, (10, 12))
+    assert_array_equal(region, ref)
