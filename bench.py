@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--n-gp", type=int, default=1024)
     ap.add_argument("--family", default="cartpole", choices=["cartpole", "pendulum"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     args = ap.parse_args()
 
     import torch
@@ -75,8 +76,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
 

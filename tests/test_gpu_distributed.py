@@ -1,0 +1,73 @@
+"""The sharded engine end to end with two ranks on ONE MI355X (gloo rendezvous on 127.0.0.1,
+both ranks drive cuda:0): each rank sweeps its half of the grid with the HIP kernels, the key /
+count / histogram reductions and the mask gather go through torch.distributed, and every rank
+must reproduce the oracle's safe set.  (With one GPU per rank the only difference is the RCCL
+backend.)"""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+import oracle
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, results):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import safe_learning_amd as sl
+    from safe_learning_amd.benchmarks import build_lyapunov
+    sl.config.gp_batch_size = oracle.config.gp_batch_size = 100
+    failures = []
+    scenarios = [
+        ("det", cases.make_case("pendulum", num_points=50, dynamics="linear", tau_scale=0.02)),
+        ("gp", cases.make_case("pendulum", num_points=45, n_gp=90, tau_scale=0.0)),
+        ("cartpole-gp", cases.make_case("cartpole", num_points=7, n_gp=100, tau_scale=0.0)),
+    ]
+    for name, case in scenarios:
+        lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+        assert lyap._world == world and lyap._hi - lyap._lo < lyap.discretization.nindex
+        if not np.array_equal(lyap.values, olyap.values):
+            failures.append((name, "values"))
+        rng = np.random.default_rng(3)
+        for step, shrink in enumerate((True, False, False)):
+            if step == 1:
+                extra = rng.choice(lyap.discretization.nindex, 200, replace=False)
+                lyap.safe_set[extra] = True
+                olyap.safe_set[extra] = True
+                lyap.tau = olyap.tau = case["tau"] * 3 if case["tau"] else 0.0
+            lyap.update_safe_set(can_shrink=shrink)
+            olyap.update_safe_set(can_shrink=shrink)
+            if not np.array_equal(lyap.safe_set, olyap.safe_set) or lyap.c_max != olyap.c_max:
+                failures.append((name, step, int((lyap.safe_set != olyap.safe_set).sum()),
+                                 lyap.c_max, olyap.c_max))
+    results[rank] = failures
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu():
+    port = _free_port()
+    results = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, port, results), nprocs=2, join=True)
+    for rank in range(2):
+        assert results[rank] == [], results[rank]
