@@ -82,6 +82,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
                         double xg[SL_P];
 #pragma unroll
                         for (int qd = 0; qd < SL_P; ++qd) xg[qd] = (qd < p) ? x[qd] * hd.inv_ls[qd] : 0.0;
+#pragma unroll 4
                         for (int j = 0; j < hd.n; ++j) {
                             double z = 0.0;
 #pragma unroll
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
 #pragma unroll
                 for (int k = 0; k < SL_D; ++k) xg[k] = (k < d) ? x[k] * hd.inv_ls[k] : 0.0;
                 const double* etab = smem + e_off[h];
+#pragma unroll 4
                 for (int j = 0; j < hd.n; ++j) {
                     double z = 0.0;
 #pragma unroll

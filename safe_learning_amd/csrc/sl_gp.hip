@@ -29,6 +29,9 @@ typedef double sl_d2 __attribute__((ext_vector_type(2)));
 #ifndef SL_GP_STAGGER
 #define SL_GP_STAGGER 1
 #endif
+#ifndef SL_GP_GEN_UNROLL
+#define SL_GP_GEN_UNROLL 1             // more than one exp chain in flight only adds spills
+#endif
 #define SL_GP_DOUT_MAX SL_MAX_STATE_DIM
 
 // configurations: {W wavefronts, R row blocks per wavefront, CB cell blocks}
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                 // k_x chunk `ch` -> LDS buffer `buf`, B-fragment order [slab pair][cb][lane][2]
                 auto generate = [&](int ch, int buf) {
                     const bool add_mean = ch >= first_new_chunk;
-#pragma unroll 1
+#pragma unroll SL_GP_GEN_UNROLL
                     for (int k = 0; k < FRAGS; ++k) {
                         const int f = wave + k * W;
                         const int s = f / CB;
