@@ -107,7 +107,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
                     sl_dynamics_det<0>(M, nd, x, nxt);
                 }
                 const double r = sl_quadratic(M.m.reward, p, x);
-                double v = sl_tri_eval(vt, nxt, 0, nullptr);
+                double v = sl_tri_value_fast<DT>(vt, nxt);
                 if (M.m.value.negate) v = v * -1.0;
                 const double t = M.m.gamma * v;
                 const double q = r + t;                          // reinforcement_learning.py:104
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
 #pragma unroll
                     for (int k = 0; k < (DT > 0 ? DT : SL_D); ++k) if (k < d) nxt[k] = mean[a][k] + prior[k];
                     const double r = sl_quadratic(M.m.reward, p, x);
-                    double v = sl_tri_eval(vt, nxt, 0, nullptr);
+                    double v = sl_tri_value_fast<DT>(vt, nxt);
                     if (M.m.value.negate) v = v * -1.0;
                     const double t = M.m.gamma * v;
                     const double q = r + t;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
         // stats[1]: sum (target - V(x))^2 with V(x) interpolated like the reference does
         //           (reinforcement_learning.py:130-133)
         double v_old = vt.table[idx * vt.ncols];
-        double v_int = sl_tri_eval(vt, x, 0, nullptr);
+        double v_int = sl_tri_value_fast<DT>(vt, x);
         if (M.m.value.negate) { v_old = v_old * -1.0; v_int = v_int * -1.0; }
         lmax = fmax(lmax, fabs(best_q - v_old));
         const double diff = best_q - v_int;
@@ -201,6 +201,324 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
                   (unsigned long long)__double_as_longlong(lmax));
         atomicAdd(&stats[1], lsum);
     }
+}
+
+// =============================================================================================
+// Bellman max sweep on the matrix cores (one shared-input GP head, finite action set)
+// =============================================================================================
+// mean[cell, (a, dd)] = sum_j S[cell, j] * B[j, (a, dd)]:  the dense K_nm @ alpha contraction of
+// reinforcement_learning.py:98-99 as an FP64 MFMA GEMM [cells x n] . [n x A*D] with
+//   B[j, (a, dd)] = variance * E_j(u_a) * alpha'[j, dd]       (action factor, packed per sweep)
+//   S[cell, j]    = prod_k T_k[i_k(cell)][j]                   (state factor)
+// The state factor of the RBF separates over the axes of the product grid, so it is a product of
+// d table entries T_k[i][j] = exp(-(x_k(i) - X_jk)^2 / (2 l_k^2)) (N_k x n entries per axis, built
+// per sweep by k_bellman_pack) - no exponential in the sweep itself.  A wavefront owns 4 tiles of
+// 16 consecutive cells that share every B fragment; lane (c = l & 15, k = l >> 4) produces its own
+// A-operand element S[c][4s + k].  The GEMM result goes through LDS to the (cell, action)
+// epilogue: prior mean, reward, value-table lookup, arg-max.
+typedef double sl_bd4 __attribute__((ext_vector_type(4)));
+#define SL_BM_WAVES 8
+#define SL_BM_T 4                         // cell tiles per wavefront
+// cells per epilogue step of a wavefront (bounded by the LDS the staged means need)
+#define SL_BM_SUB_OF(NCB) ((NCB) > 3 ? 16 : 32)
+
+struct SlBellmanPack {
+    int32_t ncb, rowlen;                  // column blocks, padded (action, output) columns
+    int64_t toff[SL_D];                   // offset (doubles) of axis k's table after the B pack
+    int64_t tab0;                         // start of the tables in the pack buffer
+};
+
+__global__ __launch_bounds__(256) void k_bellman_pack(const SlDevModel M, const SlGpDev gp,
+                                                      SlBellmanPack pk, int n_actions,
+                                                      const double* __restrict__ actions,
+                                                      double* __restrict__ pack) {
+    const SlGpHeadDev& hd = gp.head[0];
+    const int d = M.m.grid.d, m = M.m.policy.m;
+    const int nslab = hd.n_pad / 4, ncb = pk.ncb, n_pad = hd.n_pad;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    const int64_t total = (int64_t)nslab * ncb * 64;
+    for (int64_t t = tid; t < total; t += nthreads) {
+        const int lane = (int)(t & 63);
+        const int cb = (int)((t >> 6) % ncb);
+        const int s = (int)((t >> 6) / ncb);
+        const int j = 4 * s + (lane >> 4), col = 16 * cb + (lane & 15);
+        const int a = col / hd.dout, dd = col - a * hd.dout;
+        double v = 0.0;
+        if (a < n_actions && j < hd.n) {
+            double z = 0.0;
+            for (int c = 0; c < m; ++c) {
+                const double dlt = hd.xs[(d + c) * n_pad + j] - actions[a * m + c] * hd.inv_ls[d + c];
+                z = fma(dlt, dlt, z);
+            }
+            v = hd.variance * exp(-0.5 * z) * hd.alpha[j * hd.dout + dd];
+        }
+        pack[t] = v;
+    }
+    int64_t stride = 1;                    // flat-index stride of axis k (last axis fastest)
+    for (int k = d - 1; k >= 0; --k) {
+        const int nk = M.m.grid.num_points[k];
+        double* tab = pack + pk.tab0 + pk.toff[k];
+        for (int64_t t = tid; t < (int64_t)nk * n_pad; t += nthreads) {
+            // axis d-1: [j][i] (16 consecutive cells read one line); other axes: [i][j]
+            const int i = (k == d - 1) ? (int)(t % nk) : (int)(t / n_pad);
+            const int j = (k == d - 1) ? (int)(t / nk) : (int)(t % n_pad);
+            double x[SL_P];
+            sl_index_to_state(M.m.grid, M.gf, d, (int64_t)i * stride, x);
+            double v = 0.0;
+            if (j < hd.n) {
+                const double dlt = hd.xs[k * n_pad + j] - x[k] * hd.inv_ls[k];
+                v = exp(-0.5 * (dlt * dlt));
+            }
+            tab[t] = v;
+        }
+        stride *= nk;
+    }
+}
+
+template <int DT, int NCB>
+__global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
+    const SlDevModel M, const SlGpDev gp, SlAux aux, SlBellmanPack pk, int64_t lo, int64_t hi,
+    int n_actions, const double* __restrict__ actions, const double* __restrict__ pack,
+    double* __restrict__ v_new, int32_t* __restrict__ argmax, double* __restrict__ q_out,
+    double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red_max[SL_BM_WAVES], red_sum[SL_BM_WAVES];
+    constexpr int SL_BM_SUB = SL_BM_SUB_OF(NCB);
+    const SlDims nd = sl_dims<DT, 1>(M);
+    const int d = nd.d, p = nd.p, A = n_actions;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, lk = lane >> 4;
+    const int rowlen = pk.rowlen;
+    double* my_mean = smem + (size_t)wave * SL_BM_SUB * rowlen;                 // [32 cells][rowlen]
+    double* my_q = smem + (size_t)SL_BM_WAVES * SL_BM_SUB * rowlen + wave * SL_BM_SUB * SL_MAX_ACTIONS;
+    const SlTri& vt = aux.tri[0];
+    const SlGpHeadDev& hd = gp.head[0];
+    const int n_pad = hd.n_pad, nslab = n_pad / 4, dout = hd.dout;
+    const int n_last = M.m.grid.num_points[d - 1];
+    const double* tabs = pack + pk.tab0;
+    double lmax = 0.0, lsum = 0.0;
+    const int64_t wg_cells = 16 * SL_BM_T * SL_BM_WAVES;
+    const int64_t ntiles = (hi - lo + wg_cells - 1) / wg_cells;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t wbase = lo + tile * wg_cells + 16 * SL_BM_T * wave;   // first cell of the wavefront
+        // byte offsets into the tables of this lane's cell in each of the SL_BM_T tiles (element
+        // 4s + lk of slab s): 32-bit so that the loads use the scalar-base + vector-offset form
+        uint32_t off[SL_BM_T][SL_D];
+#pragma unroll
+        for (int t = 0; t < SL_BM_T; ++t) {
+            int64_t gidx = wbase + 16 * t + lc;
+            gidx = gidx < hi ? gidx : hi - 1;
+            int64_t ijk[SL_D];
+            sl_unravel(M.m.grid, M.gf, d, gidx, ijk);
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) {
+                if (k < d - 1) off[t][k] = 8u * (uint32_t)(pk.toff[k] + ijk[k] * n_pad + lk);
+                else if (k == d - 1) off[t][k] = 8u * (uint32_t)(pk.toff[k] + (int64_t)lk * n_last + ijk[k]);
+            }
+        }
+        const uint32_t step_last = 32u * (uint32_t)n_last;       // bytes per slab, axis d-1 ([j][i])
+        const char* tabs_b = reinterpret_cast<const char*>(tabs);
+        sl_bd4 acc[SL_BM_T][NCB];
+#pragma unroll
+        for (int t = 0; t < SL_BM_T; ++t)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = (sl_bd4){0.0, 0.0, 0.0, 0.0};
+        const double* bp = pack + lane;
+        double s_cur[SL_BM_T], b_cur[NCB];
+#pragma unroll
+        for (int t = 0; t < SL_BM_T; ++t) {
+            double v = 1.0;
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k)
+                if (k < d) v *= *reinterpret_cast<const double*>(tabs_b + off[t][k]);
+            s_cur[t] = v;
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) b_cur[cb] = bp[(size_t)cb * 64];
+        for (int s = 0; s < nslab; ++s) {
+            // next slab's operands are requested before, and combined after, this slab's MFMAs
+            const bool more = s + 1 < nslab;                   // the last iteration reloads itself
+            double raw[SL_BM_T][SL_D], b_nxt[NCB];
+            bp += more ? NCB * 64 : 0;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) b_nxt[cb] = bp[cb * 64];
+#pragma unroll
+            for (int t = 0; t < SL_BM_T; ++t) {
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k) {
+                    if (k < d) {
+                        off[t][k] += more ? (k == d - 1 ? step_last : 32u) : 0u;
+                        raw[t][k] = *reinterpret_cast<const double*>(tabs_b + off[t][k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < SL_BM_T; ++t)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                    acc[t][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_cur[t], b_cur[cb], acc[t][cb], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < SL_BM_T; ++t) {
+                double v = raw[t][0];
+#pragma unroll
+                for (int k = 1; k < SL_D; ++k)
+                    if (k < d) v *= raw[t][k];
+                s_cur[t] = v;
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) b_cur[cb] = b_nxt[cb];
+        }
+#pragma unroll
+        for (int sub = 0; sub < 16 * SL_BM_T / SL_BM_SUB; ++sub) {
+            const int64_t sbase = wbase + SL_BM_SUB * sub;
+            // D tile: column = lane & 15, row (cell) = (lane >> 4) + 4 * reg
+#pragma unroll
+            for (int tt = 0; tt < SL_BM_SUB / 16; ++tt) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const sl_bd4 v = acc[sub * (SL_BM_SUB / 16) + tt][cb];
+                    double* dst = my_mean + (16 * tt + lk) * rowlen + 16 * cb + lc;
+                    dst[0] = v.x;
+                    dst[4 * rowlen] = v.y;
+                    dst[8 * rowlen] = v.z;
+                    dst[12 * rowlen] = v.w;
+                }
+            }
+            __syncthreads();
+            // ---- (cell, action) pairs: prior mean, reward, value lookup --------------------------
+            for (int t = lane; t < SL_BM_SUB * A; t += 64) {
+                const int cell = t / A, a = t - cell * A;
+                int64_t idx = sbase + cell;
+                idx = idx < hi ? idx : hi - 1;
+                double x[SL_P], u[SL_M], prior[SL_D], nxt[SL_D];
+                sl_index_to_state(M.m.grid, M.gf, d, idx, x);
+#pragma unroll
+                for (int c = 0; c < SL_M; ++c) if (c < nd.m) u[c] = actions[a * nd.m + c];
+                sl_append_action(nd, u, x);
+                sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k) {
+                    if (k < d) {
+                        const int dd = k - hd.col0;
+                        const double mu = (dd >= 0 && dd < dout) ? my_mean[cell * rowlen + a * dout + dd] : 0.0;
+                        nxt[k] = mu + prior[k];
+                    }
+                }
+                const double r = sl_quadratic(M.m.reward, p, x);
+                double v = sl_tri_value_fast<DT>(vt, nxt);
+                if (M.m.value.negate) v = v * -1.0;
+                const double tq = M.m.gamma * v;
+                my_q[cell * SL_MAX_ACTIONS + a] = r + tq;
+            }
+            __syncthreads();
+            if (lane < SL_BM_SUB) {
+                const int64_t idx = sbase + lane;
+                if (idx < hi) {
+                    double best_q = my_q[lane * SL_MAX_ACTIONS];
+                    int best_a = 0;
+                    for (int a = 0; a < A; ++a) {
+                        const double q = my_q[lane * SL_MAX_ACTIONS + a];
+                        if (q_out) q_out[(idx - lo) * A + a] = q;
+                        if (q > best_q) { best_q = q; best_a = a; }
+                    }
+                    v_new[idx - lo] = best_q;
+                    if (argmax) argmax[idx - lo] = best_a;
+                    double x[SL_P];
+                    sl_index_to_state(M.m.grid, M.gf, d, idx, x);
+                    double v_old = vt.table[idx * vt.ncols];
+                    double v_int = sl_tri_value_fast<DT>(vt, x);
+                    if (M.m.value.negate) { v_old = v_old * -1.0; v_int = v_int * -1.0; }
+                    lmax = fmax(lmax, fabs(best_q - v_old));
+                    const double diff = best_q - v_int;
+                    lsum = fma(diff, diff, lsum);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        lmax = fmax(lmax, __shfl_xor(lmax, o, 64));
+        lsum += __shfl_xor(lsum, o, 64);
+    }
+    if (lane == 0) { red_max[wave] = lmax; red_sum[wave] = lsum; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < SL_BM_WAVES; ++w) { lmax = fmax(lmax, red_max[w]); lsum += red_sum[w]; }
+        atomicMax(reinterpret_cast<unsigned long long*>(&stats[0]),
+                  (unsigned long long)__double_as_longlong(lmax));
+        atomicAdd(&stats[1], lsum);
+    }
+}
+
+// Sets *done = 1 when the matrix-core path handled the sweep (one GP head whose outputs span the
+// state, at most 96 (action, output) columns); otherwise the caller runs the VALU kernel.
+static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, double* d_v_new,
+                        int32_t* d_argmax, double* d_q, double* d_stats, int* done) {
+    *done = 0;
+    const SlDevModel& M = ctx->h_model;
+    const char* env = getenv("SL_BELLMAN_MFMA");
+    if (env && env[0] == '0') return SL_OK;
+    if (M.m.policy.m != 1 || ctx->h_gp.nheads != 1) return SL_OK;
+    const int variant = sl_dim_variant_of(M);
+    if (variant != 4 && variant != 2) return SL_OK;        // compiled for 2 and 4 state dimensions
+    const SlGpHeadHost& hh = ctx->gp_heads[0];
+    const int d = M.m.grid.d;
+    SlBellmanPack pk;
+    memset(&pk, 0, sizeof(pk));
+    const int ncb = (n_actions * hh.dout + 15) / 16;
+    const int ncb_t = ncb <= 1 ? 1 : (ncb <= 3 ? 3 : 6);
+    if (ncb > 6) return SL_OK;
+    pk.ncb = ncb_t;
+    pk.rowlen = 16 * ncb_t;
+    pk.tab0 = (int64_t)(hh.n_pad / 4) * ncb_t * 64;
+    int64_t toff = 0;
+    for (int k = 0; k < d; ++k) {
+        pk.toff[k] = toff;
+        toff += (int64_t)M.m.grid.num_points[k] * hh.n_pad;
+    }
+    if (toff + 4 * (int64_t)hh.n_pad * M.m.grid.num_points[d - 1] > 0x7fffffffll) return SL_OK;
+    const size_t lds = sizeof(double) * (size_t)SL_BM_WAVES * SL_BM_SUB_OF(ncb_t) * (pk.rowlen + SL_MAX_ACTIONS);
+    const size_t need = sizeof(double) * (size_t)(pk.tab0 + toff);
+    if (need > ctx->scratch_bytes) {
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    double* pack = reinterpret_cast<double*>(ctx->d_scratch);
+    hipLaunchKernelGGL(k_bellman_pack, dim3(512), dim3(256), 0, ctx->stream, ctx->h_model, ctx->h_gp,
+                       pk, n_actions, ctx->d_actions, pack);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    const int64_t wg_cells = 16 * SL_BM_T * SL_BM_WAVES;
+    const int64_t ntiles = (hi - lo + wg_cells - 1) / wg_cells;
+    const int blocks = (int)(ntiles < ctx->num_cu ? ntiles : ctx->num_cu);
+    SlAux aux{ctx->d_tri, ctx->d_net};
+#define SL_BM_LAUNCH(D_, N_)                                                                      \
+    do {                                                                                          \
+        auto kern = k_bellman_mfma<D_, N_>;                                                       \
+        SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                              (int)lds));                                         \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * SL_BM_WAVES), lds, ctx->stream,          \
+                           ctx->h_model, ctx->h_gp, aux, pk, lo, hi, n_actions, ctx->d_actions,   \
+                           pack, d_v_new, d_argmax, d_q, d_stats);                                \
+    } while (0)
+#define SL_BM_DIMS(N_)                                  \
+    do {                                                \
+        if (variant == 4) SL_BM_LAUNCH(4, N_);          \
+        else SL_BM_LAUNCH(2, N_);                       \
+    } while (0)
+    if (ncb_t == 1) SL_BM_DIMS(1);
+    else if (ncb_t == 3) SL_BM_DIMS(3);
+    else SL_BM_DIMS(6);
+#undef SL_BM_DIMS
+#undef SL_BM_LAUNCH
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    *done = 1;
+    return SL_OK;
 }
 
 extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions,
@@ -249,6 +567,12 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
         if (lds > 150 * 1024)
             return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_bellman_sweep: action-factor table needs %zu "
                                                     "bytes of LDS", lds);
+    }
+    if (n_actions > 0 && is_gp) {                 // dense K_nm @ alpha contraction on the matrix cores
+        int done = 0;
+        int rc = bellman_mfma(ctx, lo, hi, n_actions, d_v_new, d_argmax, d_q, d_stats, &done);
+        if (rc) return rc;
+        if (done) return SL_OK;
     }
     int64_t blocks64 = (hi - lo + SL_BLOCK - 1) / SL_BLOCK;
     const int cap = ctx->num_cu * 4;

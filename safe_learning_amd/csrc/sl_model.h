@@ -36,6 +36,7 @@ struct SlTri {
     int32_t nsimplex, project, ncols, set;
     int32_t simplices[SL_MAX_SIMPLICES][SL_D + 1];   // corner codes, bit k = dimension k
     double  hyper[SL_MAX_SIMPLICES][SL_D][SL_D];
+    double  hyper_c[SL_MAX_SIMPLICES][SL_D];         // sum_k origin_s[k] * hyper[s][k][j] (sl_tri_finish)
     int64_t stride[SL_D];                            // flat-index stride per dimension
     const double* points;                            // concatenated linspace tables (device)
     int32_t points_off[SL_D];
@@ -378,6 +379,100 @@ SL_HD double sl_tri_eval(const SlTri& t, const double* x, int col, double* grad)
         }
     }
     return value;
+}
+
+// Derived constants of a triangulation; call after filling simplices / hyper / grid.
+inline void sl_tri_finish(SlTri& t) {
+    const int d = t.grid.d;
+    for (int s = 0; s < t.nsimplex; ++s)
+        for (int j = 0; j < d; ++j) {
+            double c = 0.0;
+            for (int k = 0; k < d; ++k)
+                if ((t.simplices[s][0] >> k) & 1) c = fma(t.grid.unit_maxes[k], t.hyper[s][k][j], c);
+            t.hyper_c[s][j] = c;
+        }
+}
+
+// a mod b for a >= 0, b > 0, exactly as fmod: the remainder is representable, so one fused
+// multiply-add with the right integer quotient returns it without rounding.
+SL_HD double sl_fmod_exact(double a, double b) {
+    double q = floor(a / b);
+    double r = fma(-q, b, a);
+    if (r < 0.0) { q -= 1.0; r = fma(-q, b, a); }
+    else if (r >= b) { q += 1.0; r = fma(-q, b, a); }
+    return r;
+}
+
+// Column 0 of the interpolant at x for a compile-time dimension (the Bellman sweeps evaluate it
+// A times per vertex).  Same rule as sl_tri_eval - the unit-cell simplex whose smallest
+// barycentric weight is largest - with the weights as fused w = G_s u - c_s; where several
+// simplices contain the point (a shared face) the candidates agree on the value.
+template <int DT>
+SL_HD double sl_tri_value_fast(const SlTri& t, const double* x) {
+    if (DT == 0) return sl_tri_eval(t, x, 0, nullptr);
+    constexpr int D = DT > 0 ? DT : 1;
+    const double eps2 = 2.0 * 2.220446049250313e-16;
+    int64_t corner = 0;
+    double base[D], unitc[D], xc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double* pts = t.points + t.points_off[k];
+        const int64_t r = sl_rectangle_1d(pts, t.grid.num_points[k], t.grid.offset[k],
+                                          t.grid.unit_maxes[k], x[k]);
+        corner += r * t.stride[k];
+        base[k] = (double)r;
+        double c = x[k] - t.grid.offset[k];
+        const double lo = 0.0 + eps2, hi = (t.grid.upper[k] - t.grid.offset[k]) - eps2;
+        c = (c < lo) ? lo : c;
+        c = (c > hi) ? hi : c;
+        unitc[k] = sl_fmod_exact(c, t.grid.unit_maxes[k]);
+        double pp = x[k];
+        if (t.project) {
+            pp = (pp > t.grid.offset[k]) ? pp : t.grid.offset[k];
+            pp = (pp < t.grid.upper[k]) ? pp : t.grid.upper[k];
+        }
+        xc[k] = pp;
+    }
+    int best = 0;
+    double best_min = -1e300;
+    for (int s = 0; s < t.nsimplex; ++s) {
+        double w0 = 1.0, wmin = 1e300;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double w = -t.hyper_c[s][j];
+#pragma unroll
+            for (int k = 0; k < D; ++k) w = fma(unitc[k], t.hyper[s][k][j], w);
+            w0 -= w;
+            wmin = fmin(wmin, w);
+        }
+        wmin = fmin(wmin, w0);
+        if (wmin > best_min) { best_min = wmin; best = s; }
+    }
+    // weights relative to the simplex origin in physical coordinates (functions.py:1180-1200)
+    const int code0 = t.simplices[best][0];
+    int64_t v0 = corner;
+    double rel[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const int bit = (code0 >> k) & 1;
+        v0 += bit * t.stride[k];
+        const double tt = (base[k] + (double)bit) * t.grid.unit_maxes[k];
+        rel[k] = xc[k] - (tt + t.grid.offset[k]);
+    }
+    double wsum = 0.0, acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double w = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) w = fma(rel[k], t.hyper[best][k][j], w);
+        const int code = t.simplices[best][j + 1];
+        int64_t vj = corner;
+#pragma unroll
+        for (int k = 0; k < D; ++k) vj += ((code >> k) & 1) * t.stride[k];
+        acc = fma(w, t.table[vj * t.ncols], acc);
+        wsum += w;
+    }
+    return fma(1.0 - wsum, t.table[v0 * t.ncols], acc);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -494,7 +494,7 @@ def test_get_lyapunov_region(sl):
     num = [17, 33]
     grid, ogrid = sl.GridWorld(limits, num), oracle.GridWorld(limits, num)
     pts = ogrid.all_points
-    vals = np.einsum("ij,jk,ik->i", pts, P, pts) - 0.4 * np.exp(-20 * ((pts[:, 0] - 0.5) ** 2 + pts[:, 1] ** 2))
+    vals = np.einsum("ij,jk,ik->i", pts, P, pts) - 0.2 * np.exp(-200 * ((pts[:, 0] - 0.5) ** 2 + pts[:, 1] ** 2))
     region = sl.get_lyapunov_region(sl.Triangulation(grid, vals), grid, (8, 16))
     ref = oracle.get_lyapunov_region(oracle.Triangulation(ogrid, vals), ogrid, (8, 16))
     assert ref.sum() > 20

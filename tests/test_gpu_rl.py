@@ -123,16 +123,18 @@ def test_value_iteration(sl, name, kw, nv):
         assert_allclose(vf._host_parameters()[ok], ovf.parameters[ok], rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("name,kw,nv", [
-    ("pendulum", dict(dynamics="analytic"), 15),
-    ("pendulum", dict(n_gp=70), 15),
-    ("cartpole", dict(n_gp=90), 5),
-    ("cartpole", dict(n_gp=60, stack=True), 4),
+@pytest.mark.parametrize("name,kw,nv,na", [
+    ("pendulum", dict(dynamics="analytic"), 15, 9),
+    ("pendulum", dict(n_gp=70), 15, 9),             # matrix-core sweep, 2 column blocks (of 3)
+    ("pendulum", dict(n_gp=70), [16, 32], 3),       # 1 column block, tiles aligned with the rows
+    ("cartpole", dict(n_gp=90), 5, 9),              # 3 column blocks, ragged tiles
+    ("cartpole", dict(n_gp=130), [3, 4, 4, 16], 16),  # 4 column blocks (of 6), n_pad > n
+    ("cartpole", dict(n_gp=60, stack=True), 4, 9),  # one head per output: VALU kernel
 ])
-def test_discrete_policy_optimization(sl, name, kw, nv):
+def test_discrete_policy_optimization(sl, name, kw, nv, na):
     case = cases.make_case(name, num_points=nv, **kw)
     rl, orl, vf, ovf = _rl_pair(sl, case, nv)
-    actions = np.linspace(-1, 1, 9)[:, None]
+    actions = np.linspace(-1, 1, na)[:, None]
     grid, ogrid = vf.discretization, ovf.discretization
     rl.policy = sl.Triangulation(grid, np.zeros((grid.nindex, 1)))
     orl.policy = oracle.Triangulation(ogrid, np.zeros((ogrid.nindex, 1)))

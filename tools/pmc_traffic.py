@@ -34,9 +34,11 @@ def main():
     out = {"workload": workload, "kernel": kname.split("(")[0],
            "fetch_size_kib_reported": fetch_kib, "write_size_kib_reported": write_kib,
            "bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
-           "note": "L2<->fabric bytes per k_gp_sweep launch: (2 x FETCH_SIZE + WRITE_SIZE) x 1024; "
-                   "mostly re-reads of the packed inverse Cholesky factor that miss L2 and are "
-                   "served by the Infinity Cache"}
+           "note": "L2<->fabric bytes per k_gp_sweep launch: (2 x FETCH_SIZE + WRITE_SIZE) x 1024. "
+                   "Reads: the packed inverse Cholesky factor (one pass per tile of cells) where it "
+                   "misses the 4 MiB L2 and is served by the Infinity Cache; writes: register "
+                   "spills of the per-tile set-up (scratch), WRITE_SIZE being uncalibrated on "
+                   "gfx950.  Algorithmic bytes are 8.25 per cell."}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(out)
