@@ -7,15 +7,21 @@ counters, the Bellman residual) and, for value iteration, an all-gather of the v
 over gloo.
 """
 
+import os
+
 import numpy as np
 
 _MASK63 = (1 << 63) - 1
 
 
 def is_distributed():
+    """True when the collectives have to run: more than one rank, or SL_FORCE_COLLECTIVES=1 with an
+    initialised process group (lets a single-GPU box exercise the RCCL calls at world size 1)."""
     try:
         import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or os.environ.get("SL_FORCE_COLLECTIVES") == "1"
     except Exception:
         return False
 

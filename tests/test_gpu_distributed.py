@@ -27,13 +27,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, results):
+def _worker(rank, world, port, results, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if world == 1:
+        os.environ["SL_FORCE_COLLECTIVES"] = "1"
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     import safe_learning_amd as sl
     from safe_learning_amd.benchmarks import build_lyapunov
     sl.config.gp_batch_size = oracle.config.gp_batch_size = 100
@@ -45,7 +47,8 @@ def _worker(rank, world, port, results):
     ]
     for name, case in scenarios:
         lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
-        assert lyap._world == world and lyap._hi - lyap._lo < lyap.discretization.nindex
+        assert lyap._world == world
+        assert world == 1 or lyap._hi - lyap._lo < lyap.discretization.nindex
         if not np.array_equal(lyap.values, olyap.values):
             failures.append((name, "values"))
         rng = np.random.default_rng(3)
@@ -71,3 +74,12 @@ def test_two_ranks_one_gpu():
     mp.spawn(_worker, args=(2, port, results), nprocs=2, join=True)
     for rank in range(2):
         assert results[rank] == [], results[rank]
+
+
+def test_rccl_collectives_world_one():
+    """The same scenarios over the `nccl` backend (RCCL) with one rank: every reduction, the key
+    all-gather and the mask gather are issued as RCCL calls on device tensors."""
+    port = _free_port()
+    results = mp.Manager().dict()
+    mp.spawn(_worker, args=(1, port, results, "nccl"), nprocs=1, join=True)
+    assert results[0] == [], results[0]
