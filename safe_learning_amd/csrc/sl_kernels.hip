@@ -261,11 +261,32 @@ extern "C" int sl_network_set(sl_ctx* ctx, int nlayers, const int32_t* h_dims,
         for (int o = 0; o < out; ++o)
             for (int i = 0; i < in; ++i) dst[(size_t)i * out + o] = src[(size_t)o * in + i];
     }
-    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_net_kernels, sizeof(double) * 2 * total));
-    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_net_kernels, both.data(), sizeof(double) * 2 * total,
+    // padded copies for the matrix-core kernels: rows = output features (multiple of 16),
+    // row stride = padded input features + 2 (LDS bank spread)
+    int64_t wtotal = 0;
+    for (int l = 0; l < nlayers; ++l) {
+        n.nfb[l] = (h_dims[l + 1] + 15) / 16;
+        n.nib[l] = l == 0 ? (h_dims[0] + 15) / 16 : n.nfb[l - 1];
+        n.nslab[l] = l == 0 ? (h_dims[0] + 3) / 4 : 4 * n.nfb[l - 1];
+        n.wstride[l] = 16 * n.nib[l] + 2;
+        n.woff[l] = (int32_t)wtotal;
+        wtotal += (int64_t)16 * n.nfb[l] * n.wstride[l];
+    }
+    n.wtotal = (int32_t)wtotal;
+    both.resize(2 * (size_t)total + (size_t)wtotal, 0.0);
+    for (int l = 0; l < nlayers; ++l) {
+        const int in = h_dims[l], out = h_dims[l + 1];
+        const double* src = h_kernels + n.koff[l];
+        double* dst = both.data() + 2 * total + n.woff[l];
+        for (int o = 0; o < out; ++o)
+            for (int i = 0; i < in; ++i) dst[(size_t)o * n.wstride[l] + i] = src[(size_t)o * in + i];
+    }
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_net_kernels, sizeof(double) * both.size()));
+    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_net_kernels, both.data(), sizeof(double) * both.size(),
                                 hipMemcpyHostToDevice));
     n.kernels = ctx->d_net_kernels;
     n.kernels_t = ctx->d_net_kernels + total;
+    n.wpad = ctx->d_net_kernels + 2 * total;
     SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_net, &n, sizeof(SlNet), hipMemcpyHostToDevice));
     return SL_OK;
 }

@@ -51,6 +51,14 @@ struct SlNet {
     int32_t koff[SL_MAX_NN_LAYERS];                  // offset of layer kernel in `kernels`
     const double* kernels;                           // device, per layer [out][in]
     const double* kernels_t;                         // device, per layer [in][out] (same offsets)
+    // zero-padded row-major copies for the MFMA kernels (sl_nn.hip): layer l is
+    // [16 * nfb[l]][wstride[l]] at wpad + woff[l]
+    const double* wpad;
+    int32_t woff[SL_MAX_NN_LAYERS], wstride[SL_MAX_NN_LAYERS];
+    int32_t nfb[SL_MAX_NN_LAYERS];                   // 16-wide blocks of output features
+    int32_t nib[SL_MAX_NN_LAYERS];                   // 16-wide blocks of input features
+    int32_t nslab[SL_MAX_NN_LAYERS];                 // 4-wide slabs of (padded) input features
+    int32_t wtotal, reserved;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -196,11 +196,13 @@ def test_gp_dynamics(sl, name, kw, cfg, monkeypatch):
 # ---------------------------------------------------------------------------------------------
 # network / table Lyapunov functions with gradient-based L_v (configs C3 and the NIPS-17 loop)
 # ---------------------------------------------------------------------------------------------
-def _network_case(name, lv_kind, **kw):
+def _network_case(name, lv_kind, dims=None, acts=None, **kw):
     from safe_learning_amd.benchmarks import network_weights
     case = cases.make_case(name, **kw)
-    dims = [8, 8, 12] if case["d"] == 2 else [6, 8]
-    case["V"] = {"kind": "network", "layer_dims": dims, "activations": ["tanh"] * len(dims),
+    if dims is None:
+        dims = [8, 8, 12] if case["d"] == 2 else [6, 8]
+    acts = ["tanh"] * len(dims) if acts is None else acts
+    case["V"] = {"kind": "network", "layer_dims": dims, "activations": acts,
                  "eps": 1e-8, "weights": network_weights(case["d"], dims, seed=1)}
     case["lv"] = (lv_kind,)
     return case
@@ -211,6 +213,13 @@ def _network_case(name, lv_kind, **kw):
     ("pendulum", "norm_grad", dict(num_points=40, dynamics="analytic", tau_scale=0.01)),
     ("pendulum", "abs_grad", dict(num_points=32, n_gp=100, tau_scale=0.0)),
     ("cartpole", "norm_grad", dict(num_points=6, dynamics="linear", tau_scale=0.0)),
+    # several 16-wide feature blocks per layer, widths that are not multiples of 4 or 16
+    ("pendulum", "norm_grad", dict(num_points=24, n_gp=60, tau_scale=0.0, dims=[20, 33, 64])),
+    ("pendulum", "abs_grad", dict(num_points=30, dynamics="analytic", tau_scale=0.01, dims=[64])),
+    ("pendulum", "norm_grad", dict(num_points=30, dynamics="linear", tau_scale=0.0, dims=[18, 40],
+                                   acts=["relu", "tanh"])),
+    ("cartpole", "abs_grad", dict(num_points=5, n_gp=80, tau_scale=0.0, dims=[16, 17, 40, 64],
+                                  acts=["tanh", "relu", "tanh", "tanh"])),
 ])
 def test_network_lyapunov_function(sl, name, lv_kind, kw):
     """LyapunovNetwork V with L_v from its input gradient (lyapunov_function_learning.ipynb c.19)."""
