@@ -77,10 +77,22 @@ int hs_tri_eval(const sl_grid_desc* grid, int nsimplex, const int32_t* simplices
     for (int k = 0; k < d; ++k) { t.points_off[k] = (int32_t)total; total += grid->num_points[k]; }
     t.points = discrete_points;
     t.table = table;
+    sl_tri_finish(t);
+    if (col == -1) {             // the Bellman sweeps' lookup (column 0, compile-time dimension)
+        for (int64_t i = 0; i < npts; ++i) {
+            const double* x = pts + i * d;
+            out[i] = d == 1 ? sl_tri_value_fast<1>(t, x) : d == 2 ? sl_tri_value_fast<2>(t, x)
+                   : d == 3 ? sl_tri_value_fast<3>(t, x) : d == 4 ? sl_tri_value_fast<4>(t, x)
+                   : sl_tri_value_fast<0>(t, x);
+        }
+        return 0;
+    }
     for (int64_t i = 0; i < npts; ++i)
         out[i] = sl_tri_eval(t, pts + i * d, col, grad ? grad + i * d : nullptr);
     return 0;
 }
+
+double hs_fmod_exact(double a, double b) { return sl_fmod_exact(a, b); }
 
 uint64_t hs_vbits(double v) { return sl_vbits(v); }
 double hs_vbits_to_double(uint64_t b) { return sl_vbits_to_double(b); }

@@ -155,7 +155,8 @@ def _tri_eval(hostsim, tri, points, col=0, want_grad=False):
     ([[-1, 1]] * 4, [4, 5, 3, 4], True),
     ([[-1, 1]] * 4, [4, 5, 3, 4], False),
 ])
-def test_triangulation_matches_oracle(hostsim, limits, num, project):
+@pytest.mark.parametrize("col", [0, -1], ids=["reference-order", "bellman-fast"])
+def test_triangulation_matches_oracle(hostsim, limits, num, project, col):
     rng = np.random.default_rng(1)
     grid = F.GridWorld(limits, num)
     values = rng.normal(size=(grid.nindex, 1))
@@ -170,8 +171,23 @@ def test_triangulation_matches_oracle(hostsim, limits, num, project):
         # whichever unit-cell simplex Qhull's walk returns for a point on a shared vertex
         pts.append(rng.uniform(-0.3, 1.3, (100, grid.ndim)) * span + grid.offset)
     pts = np.vstack(pts)
-    got = _tri_eval(hostsim, tri, pts)
+    got = _tri_eval(hostsim, tri, pts, col=col)
     assert_allclose(got[:, None], otri(pts), rtol=1e-10, atol=1e-12)
+
+
+def test_fmod_exact(hostsim):
+    """sl_fmod_exact (one fma with the integer quotient) returns numpy's `%` bit for bit."""
+    hostsim.hs_fmod_exact.restype = C.c_double
+    hostsim.hs_fmod_exact.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(5)
+    b = np.concatenate([rng.uniform(1e-3, 3, 2000), [0.1, 0.125, 1 / 3, 2 / 63, 1e-9]])
+    a = np.concatenate([rng.uniform(0, 50, 2000), [0.3, 0.375, 1.0, 62 * (2 / 63), 1.0]])
+    # exact multiples and their neighbours, where the rounded quotient is off by one
+    k = rng.integers(0, 200, len(b))
+    for aa in (a, k * b, np.nextafter(k * b, np.inf), np.nextafter(k * b, 0)):
+        aa = np.abs(aa)
+        got = np.array([hostsim.hs_fmod_exact(float(x), float(y)) for x, y in zip(aa, b)])
+        assert_array_equal(got, np.fmod(aa, b))
 
 
 def test_triangulation_golden_cases(hostsim, golden):
