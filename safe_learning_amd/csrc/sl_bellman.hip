@@ -337,39 +337,50 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
         }
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) b_cur[cb] = bp[(size_t)cb * 64];
-        for (int s = 0; s < nslab; ++s) {
-            // next slab's operands are requested before, and combined after, this slab's MFMAs
-            const bool more = s + 1 < nslab;                   // the last iteration reloads itself
-            double raw[SL_BM_T][SL_D], b_nxt[NCB];
-            bp += more ? NCB * 64 : 0;
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) b_nxt[cb] = bp[cb * 64];
-#pragma unroll
-            for (int t = 0; t < SL_BM_T; ++t) {
-#pragma unroll
-                for (int k = 0; k < SL_D; ++k) {
-                    if (k < d) {
-                        off[t][k] += more ? (k == d - 1 ? step_last : 32u) : 0u;
-                        raw[t][k] = *reinterpret_cast<const double*>(tabs_b + off[t][k]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < SL_BM_T; ++t)
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb)
-                    acc[t][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(s_cur[t], b_cur[cb], acc[t][cb], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < SL_BM_T; ++t) {
-                double v = raw[t][0];
-#pragma unroll
-                for (int k = 1; k < SL_D; ++k)
-                    if (k < d) v *= raw[t][k];
-                s_cur[t] = v;
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) b_cur[cb] = b_nxt[cb];
+        // Two slabs per iteration with two named operand sets: the operands of the next slab are
+        // requested before, and combined after, the MFMAs of the current one (nslab is even; the
+        // look-ahead of the last slab wraps to slab 0 and is discarded).
+        double b_odd[NCB], s_odd[SL_BM_T];
+#define SL_BM_REQUEST(RAW, BDST, SLAB)                                                          \
+        do {                                                                                    \
+            const int sl_ = (SLAB) < nslab ? (SLAB) : 0;                                        \
+            const double* bq_ = bp + (size_t)sl_ * (NCB * 64);                                  \
+            _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb) BDST[cb] = bq_[cb * 64];         \
+            _Pragma("unroll") for (int t = 0; t < SL_BM_T; ++t) {                               \
+                _Pragma("unroll") for (int k = 0; k < SL_D; ++k) {                              \
+                    if (k < d)                                                                  \
+                        RAW[t][k] = *reinterpret_cast<const double*>(                           \
+                            tabs_b + (off[t][k] + (uint32_t)sl_ * (k == d - 1 ? step_last : 32u))); \
+                }                                                                               \
+            }                                                                                   \
+        } while (0)
+#define SL_BM_COMBINE(RAW, SDST)                                                                \
+        do {                                                                                    \
+            _Pragma("unroll") for (int t = 0; t < SL_BM_T; ++t) {                               \
+                double v_ = RAW[t][0];                                                          \
+                _Pragma("unroll") for (int k = 1; k < SL_D; ++k) if (k < d) v_ *= RAW[t][k];    \
+                SDST[t] = v_;                                                                   \
+            }                                                                                   \
+        } while (0)
+#define SL_BM_MFMAS(SSRC, BSRC)                                                                 \
+        do {                                                                                    \
+            _Pragma("unroll") for (int t = 0; t < SL_BM_T; ++t)                                 \
+                _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                              \
+                    acc[t][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(SSRC[t], BSRC[cb],        \
+                                                                      acc[t][cb], 0, 0, 0);     \
+        } while (0)
+        for (int s = 0; s < nslab; s += 2) {
+            double raw_a[SL_BM_T][SL_D], raw_b[SL_BM_T][SL_D];
+            SL_BM_REQUEST(raw_a, b_odd, s + 1);
+            SL_BM_MFMAS(s_cur, b_cur);
+            SL_BM_COMBINE(raw_a, s_odd);
+            SL_BM_REQUEST(raw_b, b_cur, s + 2);
+            SL_BM_MFMAS(s_odd, b_odd);
+            SL_BM_COMBINE(raw_b, s_cur);
         }
+#undef SL_BM_REQUEST
+#undef SL_BM_COMBINE
+#undef SL_BM_MFMAS
 #pragma unroll
         for (int sub = 0; sub < 16 * SL_BM_T / SL_BM_SUB; ++sub) {
             const int64_t sbase = wbase + SL_BM_SUB * sub;
