@@ -463,6 +463,195 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Policy-evaluation sweep on the matrix cores (V <- r(x, pi(x)) + gamma V(f(x, pi(x))))
+// ---------------------------------------------------------------------------------------------
+// The policies of the value-iteration loop are piecewise constant (the greedy table over a finite
+// action set), so the 64 consecutive cells of a wavefront - one row of the last grid axis, hence
+// one common product P[j] = sigma^2 prod_k T_k[i_k][j] of the leading axes' tables, kept in LDS -
+// take only a few distinct actions.  Up to G = 16 / dout of them share one GEMM
+//   mean[64 cells x (g, dd)] = T_last[cells x n] . B[n x (g, dd)],  B = P[j] E_j(u_g) alpha'[j, dd]:
+// the A operand is the last axis' table entry itself, the B element costs its lane one exponential
+// per slab, hidden under the four MFMAs.  Rows with more than SL_BP_MAXG distinct actions (smooth
+// policies) take the scalar loop instead.
+#define SL_BP_MAXG 12
+template <int DT>
+__global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
+    const SlDevModel M, const SlGpDev gp, SlAux aux, SlBellmanPack pk, int64_t lo, int64_t hi,
+    const double* __restrict__ pack, double* __restrict__ v_new, double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red_max[SL_BM_WAVES], red_sum[SL_BM_WAVES];
+    const SlDims nd = sl_dims<DT, 1>(M);
+    const int d = nd.d, p = nd.p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, lk = lane >> 4;
+    const SlTri& vt = aux.tri[0];
+    const SlGpHeadDev& hd = gp.head[0];
+    const int n_pad = hd.n_pad, nslab = n_pad / 4, dout = hd.dout;
+    const int n_last = M.m.grid.num_points[d - 1];
+    const double* tabs = pack + pk.tab0;
+    double* p_l = smem + (size_t)wave * (n_pad + 64 * 16 + SL_BP_MAXG);   // [n_pad]
+    double* mean_l = p_l + n_pad;                                          // [64 cells][16 columns]
+    double* dist_l = mean_l + 64 * 16;                                     // distinct actions of the row
+    const double inv_ls_u = hd.inv_ls[d];
+    const double* __restrict__ xs_u = hd.xs + (size_t)d * n_pad;           // action inputs / l
+    const int G = 16 / dout;                                               // actions per GEMM
+    const int cg = lc / dout, cdd = lc - cg * dout;                        // this lane's B column
+    double lmax = 0.0, lsum = 0.0;
+    const int64_t wg_cells = 64 * SL_BM_WAVES;
+    const int64_t nsteps = (hi - lo + wg_cells - 1) / wg_cells;
+    for (int64_t step = blockIdx.x; step < nsteps; step += gridDim.x) {
+        const int64_t wbase = lo + step * wg_cells + 64 * wave;            // lo and the rows are 64-aligned
+        if (wbase >= hi) continue;
+        const int64_t idx = wbase + lane;
+        const bool valid = idx < hi;
+        const int64_t cidx = valid ? idx : hi - 1;
+        double x[SL_P], u[SL_M];
+        sl_index_to_state(M.m.grid, M.gf, d, cidx, x);
+        sl_policy_any<true>(M, nd, aux.tri, cidx, x, u);
+        // distinct actions of the row and this lane's group
+        int gid = -1, ng = 0;
+        uint64_t remaining = __ballot(valid);
+        while (remaining && ng < SL_BP_MAXG) {
+            const int leader = __ffsll((unsigned long long)remaining) - 1;
+            const double ul = __shfl(u[0], leader, 64);
+            const bool mine = valid && fabs(u[0] - ul) <= 1e-14 * (1.0 + fabs(ul));
+            const uint64_t same = __ballot(mine) & remaining;
+            if ((same >> lane) & 1ull) gid = ng;
+            if (lane == 0) dist_l[ng] = ul;
+            remaining &= ~same;
+            ++ng;
+        }
+        const bool use_gemm = remaining == 0ull;
+        // leading-axis table rows of this wavefront's grid row
+        int64_t ijk[SL_D];
+        sl_unravel(M.m.grid, M.gf, d, wbase, ijk);
+        const double* trow[SL_D];
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) if (k < d - 1) trow[k] = tabs + pk.toff[k] + ijk[k] * n_pad;
+        double mean[SL_D];
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) mean[k] = 0.0;
+        if (use_gemm) {
+            for (int j = lane; j < n_pad; j += 64) {
+                double v = hd.variance;
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k) if (k < d - 1) v *= trow[k][j];
+                p_l[j] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const double* ap = tabs + pk.toff[d - 1] + (int64_t)lk * n_last + ijk[d - 1] + lc;
+            const size_t astep = (size_t)4 * n_last;
+            for (int g0 = 0; g0 < ng; g0 += G) {
+                const bool col_on = cg < G && g0 + cg < ng;
+                const double ug = dist_l[col_on ? g0 + cg : 0] * inv_ls_u;
+                const double cmask = col_on ? 1.0 : 0.0;
+                const double* alp = hd.alpha + (size_t)lk * dout + cdd;    // + 4 dout per slab
+                const double* xsp = xs_u + lk, *pp = p_l + lk;             // + 4 per slab
+                auto b_elem = [&](int sl) -> double {
+                    const double dlt = xsp[4 * sl] - ug;
+                    return (pp[4 * sl] * cmask) * (exp(-0.5 * (dlt * dlt)) * alp[(size_t)sl * 4 * dout]);
+                };
+                sl_bd4 acc[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = (sl_bd4){0.0, 0.0, 0.0, 0.0};
+                double a_cur[4], a_nxt[4], b_cur, b_nxt;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a_cur[t] = ap[16 * t];
+                b_cur = b_elem(0);
+                for (int s = 0; s < nslab; s += 2) {
+                    const int s1 = s + 1, s2 = s + 2 < nslab ? s + 2 : 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a_nxt[t] = ap[s1 * astep + 16 * t];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], b_cur, acc[t], 0, 0, 0);
+                    b_nxt = b_elem(s1);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a_cur[t] = ap[s2 * astep + 16 * t];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_nxt[t], b_nxt, acc[t], 0, 0, 0);
+                    b_cur = b_elem(s2);
+                }
+                // D tile: column (g, dd) = lane & 15, row (cell) = (lane >> 4) + 4 * reg
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    double* dst = mean_l + (16 * t + lk) * 16 + lc;
+                    dst[0] = acc[t].x;
+                    dst[4 * 16] = acc[t].y;
+                    dst[8 * 16] = acc[t].z;
+                    dst[12 * 16] = acc[t].w;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (gid >= g0 && gid < g0 + G) {
+#pragma unroll
+                    for (int k = 0; k < SL_D; ++k)
+                        if (k < dout) mean[k] = mean_l[lane * 16 + (gid - g0) * dout + k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (valid) {
+            // smooth policy: one exponential per (cell, training point)
+            const double ug = u[0] * inv_ls_u;
+            const double* tl = tabs + pk.toff[d - 1] + ijk[d - 1] + lane;
+            for (int j = 0; j < hd.n; ++j) {
+                double v = hd.variance * tl[(size_t)j * n_last];
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k) if (k < d - 1) v *= trow[k][j];
+                const double dlt = xs_u[j] - ug;
+                v *= exp(-0.5 * (dlt * dlt));
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k)
+                    if (k < dout) mean[k] = fma(v, hd.alpha[(size_t)j * dout + k], mean[k]);
+            }
+        }
+        if (valid) {
+            double prior[SL_D], nxt[SL_D];
+            sl_append_action(nd, u, x);
+            sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) {
+                if (k < d) {
+                    const int dd = k - hd.col0;
+                    double mu = 0.0;
+#pragma unroll
+                    for (int q = 0; q < SL_D; ++q) mu = (q == dd) ? mean[q] : mu;
+                    nxt[k] = mu + prior[k];
+                }
+            }
+            const double r = sl_quadratic(M.m.reward, p, x);
+            double v = sl_tri_value_fast<DT>(vt, nxt);
+            if (M.m.value.negate) v = v * -1.0;
+            const double tq = M.m.gamma * v;
+            const double q = r + tq;
+            v_new[idx - lo] = q;
+            double v_old = vt.table[idx * vt.ncols];
+            double v_int = sl_tri_value_fast<DT>(vt, x);
+            if (M.m.value.negate) { v_old = v_old * -1.0; v_int = v_int * -1.0; }
+            lmax = fmax(lmax, fabs(q - v_old));
+            const double diff = q - v_int;
+            lsum = fma(diff, diff, lsum);
+        }
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        lmax = fmax(lmax, __shfl_xor(lmax, o, 64));
+        lsum += __shfl_xor(lsum, o, 64);
+    }
+    if (lane == 0) { red_max[wave] = lmax; red_sum[wave] = lsum; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < SL_BM_WAVES; ++w) { lmax = fmax(lmax, red_max[w]); lsum += red_sum[w]; }
+        atomicMax(reinterpret_cast<unsigned long long*>(&stats[0]),
+                  (unsigned long long)__double_as_longlong(lmax));
+        atomicAdd(&stats[1], lsum);
+    }
+}
+
 // Sets *done = 1 when the matrix-core path handled the sweep (one GP head whose outputs span the
 // state, at most 96 (action, output) columns); otherwise the caller runs the VALU kernel.
 static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, double* d_v_new,
@@ -478,8 +667,15 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
     const int d = M.m.grid.d;
     SlBellmanPack pk;
     memset(&pk, 0, sizeof(pk));
+    const bool policy_mode = n_actions == 0;
+    if (policy_mode) {
+        // worthwhile for piecewise-constant policies; rows of the last axis must be whole wavefronts
+        const int pkind = M.m.policy.kind;
+        if (pkind != SL_POLICY_TRI && pkind != SL_POLICY_TABLE && pkind != SL_POLICY_CONST) return SL_OK;
+        if (M.m.grid.num_points[d - 1] % 64 != 0 || lo % 64 != 0 || hh.dout > SL_D) return SL_OK;
+    }
     const int ncb = (n_actions * hh.dout + 15) / 16;
-    const int ncb_t = ncb <= 1 ? 1 : (ncb <= 3 ? 3 : 6);
+    const int ncb_t = policy_mode ? 0 : (ncb <= 1 ? 1 : (ncb <= 3 ? 3 : 6));
     if (ncb > 6) return SL_OK;
     pk.ncb = ncb_t;
     pk.rowlen = 16 * ncb_t;
@@ -490,7 +686,10 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
         toff += (int64_t)M.m.grid.num_points[k] * hh.n_pad;
     }
     if (toff + 4 * (int64_t)hh.n_pad * M.m.grid.num_points[d - 1] > 0x7fffffffll) return SL_OK;
-    const size_t lds = sizeof(double) * (size_t)SL_BM_WAVES * SL_BM_SUB_OF(ncb_t) * (pk.rowlen + SL_MAX_ACTIONS);
+    const size_t lds = policy_mode
+        ? sizeof(double) * (size_t)SL_BM_WAVES * (hh.n_pad + 64 * 16 + SL_BP_MAXG)
+        : sizeof(double) * (size_t)SL_BM_WAVES * SL_BM_SUB_OF(ncb_t) * (pk.rowlen + SL_MAX_ACTIONS);
+    if (lds > 158 * 1024) return SL_OK;
     const size_t need = sizeof(double) * (size_t)(pk.tab0 + toff);
     if (need > ctx->scratch_bytes) {
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -507,6 +706,22 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
     const int64_t ntiles = (hi - lo + wg_cells - 1) / wg_cells;
     const int blocks = (int)(ntiles < ctx->num_cu ? ntiles : ctx->num_cu);
     SlAux aux{ctx->d_tri, ctx->d_net};
+    if (policy_mode) {
+#define SL_BP_LAUNCH(D_)                                                                          \
+        do {                                                                                      \
+            auto kern = k_bellman_policy_mfma<D_>;                                                \
+            SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),            \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                                  (int)lds));                                     \
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * SL_BM_WAVES), lds, ctx->stream,      \
+                               ctx->h_model, ctx->h_gp, aux, pk, lo, hi, pack, d_v_new, d_stats); \
+        } while (0)
+        if (variant == 4) SL_BP_LAUNCH(4); else SL_BP_LAUNCH(2);
+#undef SL_BP_LAUNCH
+        SL_HIP_CHECK(ctx, hipGetLastError());
+        *done = 1;
+        return SL_OK;
+    }
 #define SL_BM_LAUNCH(D_, N_)                                                                      \
     do {                                                                                          \
         auto kern = k_bellman_mfma<D_, N_>;                                                       \
@@ -579,7 +794,7 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
             return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_bellman_sweep: action-factor table needs %zu "
                                                     "bytes of LDS", lds);
     }
-    if (n_actions > 0 && is_gp) {                 // dense K_nm @ alpha contraction on the matrix cores
+    if (is_gp) {                                  // dense K_nm @ alpha contraction on the matrix cores
         int done = 0;
         int rc = bellman_mfma(ctx, lo, hi, n_actions, d_v_new, d_argmax, d_q, d_stats, &done);
         if (rc) return rc;

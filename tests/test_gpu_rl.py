@@ -130,6 +130,11 @@ def test_value_iteration(sl, name, kw, nv):
     ("cartpole", dict(n_gp=90), 5, 9),              # 3 column blocks, ragged tiles
     ("cartpole", dict(n_gp=130), [3, 4, 4, 16], 16),  # 4 column blocks (of 6), n_pad > n
     ("cartpole", dict(n_gp=60, stack=True), 4, 9),  # one head per output: VALU kernel
+    # last axis = whole wavefronts: the policy-evaluation sweep that follows runs on the matrix
+    # cores (random value table => noisy greedy policy: several GEMM rounds and the scalar tail)
+    ("pendulum", dict(n_gp=70), [12, 64], 9),
+    ("pendulum", dict(n_gp=70), [5, 128], 2),       # at most two distinct actions per row
+    ("cartpole", dict(n_gp=90), [3, 4, 3, 64], 16),
 ])
 def test_discrete_policy_optimization(sl, name, kw, nv, na):
     case = cases.make_case(name, num_points=nv, **kw)

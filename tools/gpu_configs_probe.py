@@ -91,8 +91,22 @@ r = {"config": "C5 cart-pole 64^4 x 9 actions, 1024-pt GP mean, Bellman max swee
      "ms_per_sweep": sec * 1e3, "vertex_action_pairs_per_s": grid.nindex * 9 / sec}
 print(r, flush=True); results.append(r)
 sec = timed(rl.value_iteration, 3)
-r = {"config": "C5p cart-pole 64^4, policy evaluation sweep (value_iteration)", "cells": grid.nindex,
-     "ms_per_sweep": sec * 1e3}
+r = {"config": "C5p cart-pole 64^4, policy evaluation sweep (value_iteration), saturated linear policy",
+     "cells": grid.nindex, "ms_per_sweep": sec * 1e3}
+print(r, flush=True); results.append(r)
+for _ in range(3):
+    bellman_max()
+rl.discrete_policy_optimization(actions)
+best = np.sort(rl.policy._host_parameters().reshape(64 ** 3, 64), axis=1)
+distinct = float(((np.diff(best, axis=1) != 0).sum(axis=1) + 1).mean())
+sec = timed(rl.value_iteration, 3)
+r = {"config": "C5g cart-pole 64^4, policy evaluation sweep, greedy 9-action table policy",
+     "cells": grid.nindex, "ms_per_sweep": sec * 1e3, "distinct_actions_per_row": distinct}
+print(r, flush=True); results.append(r)
+rl.policy = sl.Triangulation(grid, np.zeros((grid.nindex, 1)))
+sec = timed(rl.value_iteration, 3)
+r = {"config": "C5z cart-pole 64^4, policy evaluation sweep, constant table policy",
+     "cells": grid.nindex, "ms_per_sweep": sec * 1e3, "distinct_actions_per_row": 1.0}
 print(r, flush=True); results.append(r)
 if os.environ.get("SL_C5_SHORT"):
     sys.exit(0)
