@@ -371,13 +371,56 @@ extern "C" int sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values) 
 // =============================================================================================
 // deterministic-dynamics decrease check                    (lyapunov.py:436-441, 524-535)
 // =============================================================================================
+// The model constants of the closed-form path outnumber the scalar registers (the compiler spills
+// them into VGPR lanes and reads every use back with v_readlane); holding each one in its own
+// VGPR - same value in all lanes, opaque to the optimiser - makes them plain vector operands.
+template <int DT, int MT, int DYN>
+__device__ __forceinline__ void sl_constants_to_vgprs(SlDevModel& L) {
+#define SL_TO_VGPR(x) asm volatile("" : "+v"(x))
+    if (DYN != SL_DYN_LINEAR) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) SL_TO_VGPR(L.m.dynamics.coef[q]);
+#pragma unroll
+        for (int k = 0; k < DT; ++k) { SL_TO_VGPR(L.m.dynamics.tx[k]); SL_TO_VGPR(L.m.dynamics.tx_inv[k]); }
+#pragma unroll
+        for (int a = 0; a < MT; ++a) SL_TO_VGPR(L.m.dynamics.tu[a]);
+    }
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+        SL_TO_VGPR(L.m.grid.unit_maxes[k]);
+        SL_TO_VGPR(L.m.grid.offset[k]);
+        if (DYN == SL_DYN_LINEAR) {
+#pragma unroll
+            for (int q = 0; q < DT + MT; ++q) SL_TO_VGPR(L.m.dynamics.matrix[k][q]);
+        }
+#pragma unroll
+        for (int q = 0; q < DT; ++q) {
+            SL_TO_VGPR(L.m.value.matrix[k][q]);
+            SL_TO_VGPR(L.m.lipschitz.lv_matrix[k][q]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+#pragma unroll
+        for (int k = 0; k < DT; ++k) SL_TO_VGPR(L.m.policy.matrix[a][k]);
+        SL_TO_VGPR(L.m.policy.lower[a]);
+        SL_TO_VGPR(L.m.policy.upper[a]);
+    }
+    SL_TO_VGPR(L.m.lipschitz.lv_const);
+    SL_TO_VGPR(L.m.lipschitz.lf_const);
+    SL_TO_VGPR(L.m.lipschitz.tau);
+#undef SL_TO_VGPR
+}
+
 template <bool GENERAL, int DT, int MT, int DYN>
 __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
-    const SlDevModel M, SlAux aux, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
+    const SlDevModel M_arg, SlAux aux, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
     const double* __restrict__ values, uint64_t* __restrict__ neg_bits,
     sl_key* __restrict__ partials, double* __restrict__ dbg, const double* __restrict__ points) {
     __shared__ uint64_t sv[SL_BLOCK / 64];
     __shared__ int64_t si[SL_BLOCK / 64];
+    SlDevModel M = M_arg;
+    if (!GENERAL && DT > 0 && DYN != 0) sl_constants_to_vgprs<DT, MT, DYN>(M);
     const SlDims n = sl_dims<DT, MT>(M);
     const int d = n.d;
     const int lane = threadIdx.x & 63;
