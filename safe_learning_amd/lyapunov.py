@@ -289,20 +289,24 @@ class Lyapunov(object):
         run with each cell's refined threshold ``threshold(x, tau / N(x))`` (the refined points
         themselves are never evaluated), see DESIGN.md."""
         import torch
-        if self._world != 1:
-            raise NotImplementedError('adaptive refinement runs on a single rank')
         grid, n, d = self.discretization, self.discretization.nindex, self.discretization.ndim
         batch = int(config.gp_batch_size)
         safety_factor = max(float(safety_factor), 1.)
         self._upload_model()
         self._refresh_init_bits()
-        # one sweep: negative mask and the per-cell [decrease, threshold] records
-        records = torch.empty((n, 2 + 2 * d), dtype=torch.float64, device=self._ctx.torch_device)
-        self._ctx.lyap_sweep(0, n, self._d_init, self._d_values, self._d_neg, self._d_result, records)
-        rec = records[:, :2].cpu().numpy()
-        decrease, threshold = rec[:, 0], rec[:, 1]
-        negative = np.unpackbits(self._d_neg.cpu().numpy().view(np.uint8),
-                                 bitorder='little')[:n].astype(bool)
+        # one sweep of this rank's shard: negative mask and the per-cell [decrease, threshold]
+        # records; every rank then gathers them and runs the same (sequential) refinement pass
+        lo, hi = self._lo, self._hi
+        count = hi - lo
+        sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
+        records = torch.empty((max(count, 1), 2 + 2 * d), dtype=torch.float64,
+                              device=self._ctx.torch_device)
+        self._ctx.lyap_sweep(lo, hi, self._d_init, self._d_values, self._d_neg, self._d_result, records)
+        decrease = dist_utils.allgather_concat(records[:count, 0].contiguous(), sizes).cpu().numpy()
+        threshold = dist_utils.allgather_concat(records[:count, 1].contiguous(), sizes).cpu().numpy()
+        d_bytes = torch.empty(max(-(-count // 8) * 8, 8), dtype=torch.uint8, device=self._ctx.torch_device)
+        self._ctx.bits_to_bytes(count, self._d_neg, d_bytes)
+        negative = dist_utils.allgather_concat(d_bytes[:count], sizes).cpu().numpy().astype(bool)
         values = self.values
         # -|L_v(x)|_1 (1 + L_f): the refined threshold is this times tau / N(x)
         base = self.threshold(grid.index_to_state(np.arange(n)), tau=1.0)

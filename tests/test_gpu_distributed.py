@@ -63,6 +63,23 @@ def _worker(rank, world, port, results, backend="gloo"):
             if not np.array_equal(lyap.safe_set, olyap.safe_set) or lyap.c_max != olyap.c_max:
                 failures.append((name, step, int((lyap.safe_set != olyap.safe_set).sum()),
                                  lyap.c_max, olyap.c_max))
+    # adaptive branch: shards swept by their owners, the sequential refinement pass replicated
+    from safe_learning_amd.benchmarks import build_specs
+    case = cases.make_case("pendulum", num_points=45, dynamics="linear", tau_scale=0.02)
+    init = np.zeros(int(np.prod(case["num_points"])), dtype=bool)
+    init[cases.initial_safe_mask(case)] = True
+    policy, dynamics, value, lv = build_specs(case)
+    lyap = sl.Lyapunov(sl.GridWorld(case["limits"], case["num_points"]), value, dynamics, case["lf"],
+                       lv, case["tau"], policy, initial_set=init, adaptive=True)
+    opolicy, odynamics, ovalue, olv = cases.oracle_specs(case)
+    olyap = oracle.Lyapunov(oracle.GridWorld(case["limits"], case["num_points"]), ovalue, odynamics,
+                            case["lf"], olv, case["tau"], opolicy, initial_set=init, adaptive=True)
+    for shrink, factor in ((True, 1.0), (False, 1.5)):
+        lyap.update_safe_set(can_shrink=shrink, max_refinement=16, safety_factor=factor)
+        olyap.update_safe_set(can_shrink=shrink, max_refinement=16, safety_factor=factor)
+        if (not np.array_equal(lyap.safe_set, olyap.safe_set) or lyap.c_max != olyap.c_max
+                or not np.array_equal(lyap._refinement, olyap._refinement)):
+            failures.append(("adaptive", shrink))
     results[rank] = failures
     dist.barrier()
     dist.destroy_process_group()
