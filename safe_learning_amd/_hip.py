@@ -85,7 +85,7 @@ EXPORTS = [
     "sl_model_set", "sl_gp_set_head", "sl_gp_configure", "sl_tri_set", "sl_tri_set_table",
     "sl_network_set", "sl_values", "sl_lyap_sweep", "sl_lyap_finalize", "sl_select_pass",
     "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_eval_points",
-    "sl_debug_mfma", "sl_debug_fp64_rate",
+    "sl_debug_mfma", "sl_debug_mfma4", "sl_debug_fp64_rate",
 ]
 
 _lib = None
@@ -135,6 +135,8 @@ def load_library():
     lib.sl_eval_points.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sl_debug_mfma.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
     lib.sl_debug_fp64_rate.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p]
+    lib.sl_debug_mfma4.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int,
+                                   c_double_p]
     for name in EXPORTS:
         if name not in ("sl_last_error",):
             getattr(lib, name).restype = C.c_int
@@ -283,6 +285,16 @@ class Context(object):
         out = np.zeros((16, 16))
         self.check(self.lib.sl_debug_mfma(self.handle, pa, pb, out.ctypes.data_as(c_double_p)),
                    "sl_debug_mfma")
+        return out
+
+    def debug_mfma4(self, a, b, c, mode=0):
+        """v_mfma_f64_4x4x4_4b_f64 on per-lane operands of shape (nwaves, 64)."""
+        a, pa = _as_c(np.atleast_2d(a))
+        b, pb = _as_c(np.atleast_2d(b))
+        c, pc = _as_c(np.atleast_2d(c))
+        out = np.zeros_like(a)
+        self.check(self.lib.sl_debug_mfma4(self.handle, a.shape[0], pa, pb, pc, mode,
+                                           out.ctypes.data_as(c_double_p)), "sl_debug_mfma4")
         return out
 
     def debug_fp64_rate(self, which, iters=20000):

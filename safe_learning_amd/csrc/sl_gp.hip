@@ -44,6 +44,14 @@ static const int kCfgCB[3] = {1, 2, 4};
 
 static inline int cfg_panel_rows(int cfg) { return 16 * kCfgR[cfg] * kCfgW[cfg]; }
 
+// Experimental: issue the matrix work as v_mfma_f64_4x4x4_4b_f64.  The instruction sustains
+// 76 TFLOP/s in isolation (sl_debug_fp64_rate) against 47 for v_mfma_f64_16x16x4_f64, but a 4-pass
+// MFMA leaves the vector issue port no slack: FP64 VALU work (the k_x exponentials) and every
+// stall add to its time instead of hiding in the 16x16x4 issue gaps, and this kernel comes out
+// 3-20 % slower with it (profiles/r01_summary.md).  Results are identical either way.
+#ifndef SL_GP_MFMA4
+#define SL_GP_MFMA4 0
+#endif
 template <int W, int R, int CB, bool GENERAL, int DT, int MT>
 __global__ __launch_bounds__(W * 64) void k_gp_sweep(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
@@ -75,6 +83,11 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform
     const int gcb = wave % CB;                     // cell block this wavefront generates k_x for
     const int lcol = lane & 15, lk = lane >> 4;
+    // offsets (doubles) of this lane's element pair in a k_x fragment whose rows of 16 lanes are
+    // rotated by 0, 4, 8, 12: the four B operands of the 4x4x4 instructions
+    int rot2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) rot2[m] = ((((lane + 4 * m) & 15) | (lane & 48)) << 1);
 
     uint64_t best_v = ~0ull;
     int64_t best_i = INT64_MAX;
@@ -184,6 +197,77 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                         cnt[r] = c > 0 ? c : 0;
                         if (cnt[r] > 0 && r0 == R) r0 = r;
                     }
+#if SL_GP_MFMA4
+                    // The matrix work is issued as v_mfma_f64_4x4x4_4b_f64 (one per 16-18 cycles,
+                    // ~75 TFLOP/s sustained, against one v_mfma_f64_16x16x4_f64 per ~100 cycles,
+                    // 47 TFLOP/s: profiles/).  Block b of the instruction multiplies rows 4b..4b+3
+                    // of the A fragment with columns 4b..4b+3 of the B fragment; reading the B
+                    // fragment from LDS with its lanes rotated by 0, 4, 8, 12 inside each row of
+                    // 16 pairs every row group with every column group, and the lanes of every
+                    // accumulator still belong to column (lane & 15) - all the sum of squares
+                    // needs.  No VALU instruction in this phase: the 4-pass MFMAs leave the
+                    // vector issue port no slack.  Loop order: slab pair, then row block, so that
+                    // the rotated B fragments are read once per slab pair; the A fragments of the
+                    // next slab pair are requested one whole iteration ahead.
+                    const int cmax = cnt[R - 1];
+                    sl_d2 a_cur[R], a_nxt[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        a_cur[r] = (sl_d2){0.0, 0.0};
+                        a_nxt[r] = (sl_d2){0.0, 0.0};
+                        if (cnt[r] > 0) a_cur[r] = load_a(rowblk[r], 8 * ch);
+                    }
+                    const bool gen_first = (W < 8) || ((wave & 4) == 0) || !SL_GP_STAGGER;
+                    if (gen_first && ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
+                    const double* kxb = kx_l + buf * KXBUF;
+                    // rotated B fragments of step (s2, cb), requested one step ahead
+                    auto load_b = [&](int step, sl_d2* dst) {
+                        const double* src = kxb + (size_t)step * 128;
+                        dst[0] = *reinterpret_cast<const sl_d2*>(src + rot2[0]);
+                        dst[1] = *reinterpret_cast<const sl_d2*>(src + rot2[1]);
+                        dst[2] = *reinterpret_cast<const sl_d2*>(src + rot2[2]);
+                        dst[3] = *reinterpret_cast<const sl_d2*>(src + rot2[3]);
+                    };
+                    sl_d2 b_cur[4], b_nxt[4];
+                    if (cmax > 0) load_b(0, b_cur);
+                    const int nsteps = cmax * CB;
+                    for (int s2 = 0; s2 < cmax; ++s2) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (s2 + 1 < cnt[r]) a_nxt[r] = load_a(rowblk[r], 8 * ch + s2 + 1);
+#pragma unroll
+                        for (int cb = 0; cb < CB; ++cb) {
+                            const int step = s2 * CB + cb;
+                            load_b(step + 1 < nsteps ? step + 1 : step, b_nxt);
+                            // even slab of the pair for every row block, then the odd slab: 16
+                            // instructions between two updates of the same accumulator
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                if (s2 < cnt[r]) {
+                                    sl_d4& t = acc[r][cb];
+                                    t.x = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].x, b_cur[0].x, t.x, 0, 0, 0);
+                                    t.y = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].x, b_cur[1].x, t.y, 0, 0, 0);
+                                    t.z = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].x, b_cur[2].x, t.z, 0, 0, 0);
+                                    t.w = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].x, b_cur[3].x, t.w, 0, 0, 0);
+                                }
+                            }
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                if (s2 < cnt[r]) {
+                                    sl_d4& t = acc[r][cb];
+                                    t.x = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].y, b_cur[0].y, t.x, 0, 0, 0);
+                                    t.y = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].y, b_cur[1].y, t.y, 0, 0, 0);
+                                    t.z = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].y, b_cur[2].y, t.z, 0, 0, 0);
+                                    t.w = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].y, b_cur[3].y, t.w, 0, 0, 0);
+                                }
+                            }
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) b_cur[m] = b_nxt[m];
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; ++r) a_cur[r] = a_nxt[r];
+                    }
+#else
                     // two-deep register queue of A fragments, primed before k_x generation so
                     // that the first loads fly while the next chunk's exponentials are computed
                     sl_d2 q0 = {0.0, 0.0}, q1 = {0.0, 0.0};
@@ -228,10 +312,31 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                             q1 = q2;
                         }
                     }
+#endif
                     if (!gen_first && ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
                     __syncthreads();
                 }
                 // |a|^2 of this panel's rows (row order inside a tile does not matter)
+#if SL_GP_MFMA4
+                // accumulator m of a lane belongs to column ((lane & 15) + 4 m) & 15: sum the
+                // squares per rotation and hand each sum to the lane that owns the column
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    double sm[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const sl_d4 t = acc[r][cb];
+                        sm[0] = fma(t.x, t.x, sm[0]);
+                        sm[1] = fma(t.y, t.y, sm[1]);
+                        sm[2] = fma(t.z, t.z, sm[2]);
+                        sm[3] = fma(t.w, t.w, sm[3]);
+                    }
+                    ss[cb] += sm[0];
+#pragma unroll
+                    for (int m = 1; m < 4; ++m)
+                        ss[cb] += __shfl(sm[m], ((lane - 4 * m) & 15) | (lane & 48), 64);
+                }
+#else
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -242,6 +347,7 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                         ss[cb] = fma(t.z, t.z, ss[cb]);
                         ss[cb] = fma(t.w, t.w, ss[cb]);
                     }
+#endif
             }
             // ---- reduce over the 4 lane groups, then over wavefronts through LDS ---------------
 #pragma unroll
@@ -540,21 +646,86 @@ extern "C" int sl_debug_mfma(sl_ctx* ctx, const double* h_a, const double* h_b, 
     return SL_OK;
 }
 
+// v_mfma_f64_4x4x4_4b_f64 with per-lane operands; mode 0: no broadcast, 1..4: cbsz = 2, abid = mode - 1
+__global__ void k_debug_mfma4(const double* a, const double* b, const double* c, int mode, double* d) {
+    const int l = threadIdx.x + 64 * blockIdx.x;
+    const double av = a[l], bv = b[l], cv = c[l];
+    double r;
+    switch (mode) {
+    case 1: r = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, cv, 2, 0, 0); break;
+    case 2: r = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, cv, 2, 1, 0); break;
+    case 3: r = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, cv, 2, 2, 0); break;
+    case 4: r = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, cv, 2, 3, 0); break;
+    default: r = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, cv, 0, 0, 0); break;
+    }
+    d[l] = r;
+}
+
+// nwaves independent problems of 64 lanes each
+extern "C" int sl_debug_mfma4(sl_ctx* ctx, int nwaves, const double* h_a, const double* h_b,
+                              const double* h_c, int mode, double* h_d) {
+    if (!ctx || !h_a || !h_b || !h_c || !h_d || nwaves < 1)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_debug_mfma4: bad argument");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(double) * 64 * (size_t)nwaves;
+    double* buf;
+    SL_HIP_CHECK(ctx, hipMalloc(&buf, 4 * bytes));
+    SL_HIP_CHECK(ctx, hipMemcpy(buf, h_a, bytes, hipMemcpyHostToDevice));
+    SL_HIP_CHECK(ctx, hipMemcpy(buf + 64 * nwaves, h_b, bytes, hipMemcpyHostToDevice));
+    SL_HIP_CHECK(ctx, hipMemcpy(buf + 128 * nwaves, h_c, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_mfma4, dim3(nwaves), dim3(64), 0, ctx->stream, buf, buf + 64 * nwaves,
+                       buf + 128 * nwaves, mode, buf + 192 * nwaves);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SL_HIP_CHECK(ctx, hipMemcpy(h_d, buf + 192 * nwaves, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(buf);
+    return SL_OK;
+}
+
 // FP64 rate probes: which = 0 MFMA only, 1 VALU FMA only, 2 both in the same wavefront.
 // Also reports the shader clock actually sustained (s_memtime ticks / s_memrealtime ticks).
 template <int WHICH>
 __global__ __launch_bounds__(256) void k_fp64_rate(int iters, double* sink, long long* clocks) {
     sl_d4 acc[8];
-    double v[8];
+    double v[8], w16[16], w64[(WHICH == 6 || WHICH == 7) ? 64 : 1];
+#pragma unroll
+    for (int k = 0; k < ((WHICH == 6 || WHICH == 7) ? 64 : 1); ++k) w64[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { acc[k] = (sl_d4){0.0, 0.0, 0.0, 0.0}; v[k] = threadIdx.x * 1e-3 + k; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w16[k] = 0.0;
     const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
     const long long c0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (WHICH != 1) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
-            if (WHICH != 0) {
+            if (WHICH == 0 || WHICH == 2) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
+            if (WHICH == 3)               // accumulators pinned to the AccVGPR half of the file
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[k]) : "v"(a), "v"(b));
+            if (WHICH == 4)               // 4 blocks of 4x4x4: 512 flops per instruction
+                v[k] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, v[k], 0, 0, 0);
+            if (WHICH == 5) {             // 4x4x4 with four distinct A and B operands, 16 accumulators
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    w16[(2 * k + q) & 15] = __builtin_amdgcn_mfma_f64_4x4x4f64(
+                        v[(k + q) & 3], v[4 + ((k >> 1) & 3)], w16[(2 * k + q) & 15], 0, 0, 0);
+            }
+            if (WHICH == 7) {             // 4x4x4 MFMAs with FP64 VALU work between them (same wavefront)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    w64[8 * k + q] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[k & 3], w16[q + 8 * (k >> 2)],
+                                                                          w64[8 * k + q], 0, 0, 0);
+                    acc[q].x = fma(acc[q].x, b, a);
+                    acc[q].y = fma(acc[q].y, b, a);
+                }
+            }
+            if (WHICH == 6) {             // the GP kernel's register shape: 64 accumulators, 4 A x 8 B operands
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    w64[8 * k + q] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[k & 3], w16[q + 8 * (k >> 2)],
+                                                                          w64[8 * k + q], 0, 0, 0);
+            }
+            if (WHICH == 1 || WHICH == 2) {
 #pragma unroll
                 for (int rep = 0; rep < 16; ++rep) v[(k + rep) & 7] = fma(v[(k + rep) & 7], b, a);
             }
@@ -562,14 +733,16 @@ __global__ __launch_bounds__(256) void k_fp64_rate(int iters, double* sink, long
     }
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += acc[k].x + acc[k].y + acc[k].z + acc[k].w + v[k];
+    for (int k = 0; k < 8; ++k) s += acc[k].x + acc[k].y + acc[k].z + acc[k].w + v[k] + w16[k] + w16[k + 8];
+#pragma unroll
+    for (int k = 0; k < ((WHICH == 6 || WHICH == 7) ? 64 : 1); ++k) s += w64[k];
     const long long c1 = clock64(), w1 = wall_clock64();
     if (s == 12345.678) sink[0] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
 }
 
 extern "C" int sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_out) {
-    if (!ctx || !h_out || which < 0 || which > 2 || iters < 1)
+    if (!ctx || !h_out || which < 0 || which > 7 || iters < 1)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_debug_fp64_rate: bad argument");
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const char* env = getenv("SL_PROBE_BLOCKS_PER_CU");
@@ -586,7 +759,12 @@ extern "C" int sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_o
         SL_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
         if (which == 0) hipLaunchKernelGGL(k_fp64_rate<0>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
         else if (which == 1) hipLaunchKernelGGL(k_fp64_rate<1>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
-        else hipLaunchKernelGGL(k_fp64_rate<2>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
+        else if (which == 2) hipLaunchKernelGGL(k_fp64_rate<2>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
+        else if (which == 3) hipLaunchKernelGGL(k_fp64_rate<3>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
+        else if (which == 4) hipLaunchKernelGGL(k_fp64_rate<4>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
+        else if (which == 5) hipLaunchKernelGGL(k_fp64_rate<5>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
+        else if (which == 6) hipLaunchKernelGGL(k_fp64_rate<6>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
+        else hipLaunchKernelGGL(k_fp64_rate<7>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
         SL_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
         SL_HIP_CHECK(ctx, hipEventSynchronize(e1));
     }
@@ -596,8 +774,12 @@ extern "C" int sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_o
     SL_HIP_CHECK(ctx, hipMemcpy(hc, clocks, sizeof(hc), hipMemcpyDeviceToHost));
     const double waves = (double)blocks * 4.0;
     double flops = 0.0;
-    if (which != 1) flops += waves * (double)iters * 8.0 * (2.0 * 16 * 16 * 4);
-    if (which != 0) flops += waves * (double)iters * 8.0 * 16.0 * 64.0 * 2.0;
+    if (which == 0 || which == 2 || which == 3) flops += waves * (double)iters * 8.0 * (2.0 * 16 * 16 * 4);
+    if (which == 4) flops += waves * (double)iters * 8.0 * (4 * 2.0 * 4 * 4 * 4);
+    if (which == 5) flops += waves * (double)iters * 16.0 * (4 * 2.0 * 4 * 4 * 4);
+    if (which == 6 || which == 7) flops += waves * (double)iters * 64.0 * (4 * 2.0 * 4 * 4 * 4);
+    if (which == 7) flops += waves * (double)iters * 64.0 * 2.0 * 64.0 * 2.0;
+    if (which == 1 || which == 2) flops += waves * (double)iters * 8.0 * 16.0 * 64.0 * 2.0;
     h_out[0] = flops / (ms * 1e-3) / 1e12;                       // TFLOP/s
     h_out[1] = hc[1] > 0 ? 100.0 * (double)hc[0] / (double)hc[1] : 0.0;   // shader MHz (100 MHz ref)
     h_out[2] = (double)hc[0] / ((double)iters * 8.0 * per_cu);   // shader cycles per MFMA (or per 16 FMA) slot per SIMD
