@@ -231,7 +231,8 @@ int  sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_points /* 
 /* D = A(16x4) * B(4x16) through v_mfma_f64_16x16x4_f64 with this library's fragment maps. */
 int  sl_debug_mfma(sl_ctx* ctx, const double* h_a, const double* h_b, double* h_d);
 /* v_mfma_f64_4x4x4_4b_f64 on per-lane operands (nwaves x 64 values each); mode 0: plain, 1..4:
-   A-block broadcast (cbsz = 2) of block mode - 1.  Pins the fragment layout in the tests. */
+   cbsz = 2, abid = mode - 1 (not a block broadcast for FP64).  Pins the fragment layout in the
+   tests. */
 int  sl_debug_mfma4(sl_ctx* ctx, int nwaves, const double* h_a, const double* h_b,
                     const double* h_c, int mode, double* h_d);
 /* Sustained FP64 rate probes: which = 0 MFMA, 1 VALU FMA, 2 both interleaved.

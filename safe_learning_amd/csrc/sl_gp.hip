@@ -44,14 +44,6 @@ static const int kCfgCB[3] = {1, 2, 4};
 
 static inline int cfg_panel_rows(int cfg) { return 16 * kCfgR[cfg] * kCfgW[cfg]; }
 
-// Experimental: issue the matrix work as v_mfma_f64_4x4x4_4b_f64.  The instruction sustains
-// 76 TFLOP/s in isolation (sl_debug_fp64_rate) against 47 for v_mfma_f64_16x16x4_f64, but a 4-pass
-// MFMA leaves the vector issue port no slack: FP64 VALU work (the k_x exponentials) and every
-// stall add to its time instead of hiding in the 16x16x4 issue gaps, and this kernel comes out
-// 3-20 % slower with it (profiles/r01_summary.md).  Results are identical either way.
-#ifndef SL_GP_MFMA4
-#define SL_GP_MFMA4 0
-#endif
 template <int W, int R, int CB, bool GENERAL, int DT, int MT>
 __global__ __launch_bounds__(W * 64) void k_gp_sweep(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
@@ -83,12 +75,6 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform
     const int gcb = wave % CB;                     // cell block this wavefront generates k_x for
     const int lcol = lane & 15, lk = lane >> 4;
-    // offsets (doubles) of this lane's element pair in a k_x fragment whose rows of 16 lanes are
-    // rotated by 0, 4, 8, 12: the four B operands of the 4x4x4 instructions
-    int rot2[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) rot2[m] = ((((lane + 4 * m) & 15) | (lane & 48)) << 1);
-
     uint64_t best_v = ~0ull;
     int64_t best_i = INT64_MAX;
     int staged_head = -1;
@@ -197,77 +183,6 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                         cnt[r] = c > 0 ? c : 0;
                         if (cnt[r] > 0 && r0 == R) r0 = r;
                     }
-#if SL_GP_MFMA4
-                    // The matrix work is issued as v_mfma_f64_4x4x4_4b_f64 (one per 16-18 cycles,
-                    // ~75 TFLOP/s sustained, against one v_mfma_f64_16x16x4_f64 per ~100 cycles,
-                    // 47 TFLOP/s: profiles/).  Block b of the instruction multiplies rows 4b..4b+3
-                    // of the A fragment with columns 4b..4b+3 of the B fragment; reading the B
-                    // fragment from LDS with its lanes rotated by 0, 4, 8, 12 inside each row of
-                    // 16 pairs every row group with every column group, and the lanes of every
-                    // accumulator still belong to column (lane & 15) - all the sum of squares
-                    // needs.  No VALU instruction in this phase: the 4-pass MFMAs leave the
-                    // vector issue port no slack.  Loop order: slab pair, then row block, so that
-                    // the rotated B fragments are read once per slab pair; the A fragments of the
-                    // next slab pair are requested one whole iteration ahead.
-                    const int cmax = cnt[R - 1];
-                    sl_d2 a_cur[R], a_nxt[R];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        a_cur[r] = (sl_d2){0.0, 0.0};
-                        a_nxt[r] = (sl_d2){0.0, 0.0};
-                        if (cnt[r] > 0) a_cur[r] = load_a(rowblk[r], 8 * ch);
-                    }
-                    const bool gen_first = (W < 8) || ((wave & 4) == 0) || !SL_GP_STAGGER;
-                    if (gen_first && ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
-                    const double* kxb = kx_l + buf * KXBUF;
-                    // rotated B fragments of step (s2, cb), requested one step ahead
-                    auto load_b = [&](int step, sl_d2* dst) {
-                        const double* src = kxb + (size_t)step * 128;
-                        dst[0] = *reinterpret_cast<const sl_d2*>(src + rot2[0]);
-                        dst[1] = *reinterpret_cast<const sl_d2*>(src + rot2[1]);
-                        dst[2] = *reinterpret_cast<const sl_d2*>(src + rot2[2]);
-                        dst[3] = *reinterpret_cast<const sl_d2*>(src + rot2[3]);
-                    };
-                    sl_d2 b_cur[4], b_nxt[4];
-                    if (cmax > 0) load_b(0, b_cur);
-                    const int nsteps = cmax * CB;
-                    for (int s2 = 0; s2 < cmax; ++s2) {
-#pragma unroll
-                        for (int r = 0; r < R; ++r)
-                            if (s2 + 1 < cnt[r]) a_nxt[r] = load_a(rowblk[r], 8 * ch + s2 + 1);
-#pragma unroll
-                        for (int cb = 0; cb < CB; ++cb) {
-                            const int step = s2 * CB + cb;
-                            load_b(step + 1 < nsteps ? step + 1 : step, b_nxt);
-                            // even slab of the pair for every row block, then the odd slab: 16
-                            // instructions between two updates of the same accumulator
-#pragma unroll
-                            for (int r = 0; r < R; ++r) {
-                                if (s2 < cnt[r]) {
-                                    sl_d4& t = acc[r][cb];
-                                    t.x = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].x, b_cur[0].x, t.x, 0, 0, 0);
-                                    t.y = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].x, b_cur[1].x, t.y, 0, 0, 0);
-                                    t.z = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].x, b_cur[2].x, t.z, 0, 0, 0);
-                                    t.w = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].x, b_cur[3].x, t.w, 0, 0, 0);
-                                }
-                            }
-#pragma unroll
-                            for (int r = 0; r < R; ++r) {
-                                if (s2 < cnt[r]) {
-                                    sl_d4& t = acc[r][cb];
-                                    t.x = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].y, b_cur[0].y, t.x, 0, 0, 0);
-                                    t.y = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].y, b_cur[1].y, t.y, 0, 0, 0);
-                                    t.z = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].y, b_cur[2].y, t.z, 0, 0, 0);
-                                    t.w = __builtin_amdgcn_mfma_f64_4x4x4f64(a_cur[r].y, b_cur[3].y, t.w, 0, 0, 0);
-                                }
-                            }
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) b_cur[m] = b_nxt[m];
-                        }
-#pragma unroll
-                        for (int r = 0; r < R; ++r) a_cur[r] = a_nxt[r];
-                    }
-#else
                     // two-deep register queue of A fragments, primed before k_x generation so
                     // that the first loads fly while the next chunk's exponentials are computed
                     sl_d2 q0 = {0.0, 0.0}, q1 = {0.0, 0.0};
@@ -312,31 +227,10 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                             q1 = q2;
                         }
                     }
-#endif
                     if (!gen_first && ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
                     __syncthreads();
                 }
                 // |a|^2 of this panel's rows (row order inside a tile does not matter)
-#if SL_GP_MFMA4
-                // accumulator m of a lane belongs to column ((lane & 15) + 4 m) & 15: sum the
-                // squares per rotation and hand each sum to the lane that owns the column
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    double sm[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const sl_d4 t = acc[r][cb];
-                        sm[0] = fma(t.x, t.x, sm[0]);
-                        sm[1] = fma(t.y, t.y, sm[1]);
-                        sm[2] = fma(t.z, t.z, sm[2]);
-                        sm[3] = fma(t.w, t.w, sm[3]);
-                    }
-                    ss[cb] += sm[0];
-#pragma unroll
-                    for (int m = 1; m < 4; ++m)
-                        ss[cb] += __shfl(sm[m], ((lane - 4 * m) & 15) | (lane & 48), 64);
-                }
-#else
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -347,7 +241,6 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                         ss[cb] = fma(t.z, t.z, ss[cb]);
                         ss[cb] = fma(t.w, t.w, ss[cb]);
                     }
-#endif
             }
             // ---- reduce over the 4 lane groups, then over wavefronts through LDS ---------------
 #pragma unroll
@@ -646,7 +539,7 @@ extern "C" int sl_debug_mfma(sl_ctx* ctx, const double* h_a, const double* h_b, 
     return SL_OK;
 }
 
-// v_mfma_f64_4x4x4_4b_f64 with per-lane operands; mode 0: no broadcast, 1..4: cbsz = 2, abid = mode - 1
+// v_mfma_f64_4x4x4_4b_f64 with per-lane operands; mode 0: plain, 1..4: cbsz = 2, abid = mode - 1
 __global__ void k_debug_mfma4(const double* a, const double* b, const double* c, int mode, double* d) {
     const int l = threadIdx.x + 64 * blockIdx.x;
     const double av = a[l], bv = b[l], cv = c[l];

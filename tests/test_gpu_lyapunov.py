@@ -107,6 +107,31 @@ def test_mfma_fragment_layout(sl):
     assert_allclose(ctx.debug_mfma(eye, b)[:4], b, rtol=0, atol=0)
 
 
+def test_mfma_4x4x4_block_layout(sl):
+    """v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products; block b owns lanes 4b..4b+3 of
+    every row of 16 lanes (A: row i = lane % 4, k = lane // 16; B: column j = lane % 4, k = lane // 16;
+    D: column j = lane % 4, row i = lane // 16).  The cbsz / abid bits do not give an A-block
+    broadcast for FP64 (the result then matches none of the four block broadcasts)."""
+    from safe_learning_amd import _hip
+    ctx = _hip.Context()
+    rng = np.random.default_rng(1)
+    a, b, c = rng.normal(size=(3, 64))
+    lanes = np.arange(64)
+    blk, low, high = (lanes // 4) % 4, lanes % 4, lanes // 16
+    ref = np.zeros(64)
+    for lane in lanes:
+        i, j, bk = high[lane], low[lane], blk[lane]
+        acc = c[lane]
+        for k in range(4):
+            acc += a[i + 4 * bk + 16 * k] * b[j + 4 * bk + 16 * k]
+        ref[lane] = acc
+    assert_allclose(ctx.debug_mfma4(a, b, c, 0)[0], ref, rtol=1e-14, atol=1e-14)
+    for abid in range(4):
+        bcast = [c[l] + sum(a[high[l] + 4 * abid + 16 * k] * b[low[l] + 4 * blk[l] + 16 * k]
+                            for k in range(4)) for l in lanes]
+        assert not np.allclose(ctx.debug_mfma4(a, b, c, 1 + abid)[0], bcast)
+
+
 # ---------------------------------------------------------------------------------------------
 # deterministic dynamics
 # ---------------------------------------------------------------------------------------------
