@@ -580,9 +580,14 @@ extern "C" int sl_debug_mfma4(sl_ctx* ctx, int nwaves, const double* h_a, const 
 template <int WHICH>
 __global__ __launch_bounds__(256) void k_fp64_rate(int iters, double* sink, long long* clocks) {
     sl_d4 acc[8];
-    double v[8], w16[16], w64[(WHICH == 6 || WHICH == 7) ? 64 : 1];
+    __shared__ __attribute__((aligned(16))) double probe_lds[32 * 128];
+    if (WHICH == 8) {
+        for (int k = threadIdx.x; k < 32 * 128; k += blockDim.x) probe_lds[k] = 1.0 + k * 1e-9;
+        __syncthreads();
+    }
+    double v[8], w16[16], w64[(WHICH == 6 || WHICH == 7 || WHICH == 8) ? 64 : 1];
 #pragma unroll
-    for (int k = 0; k < ((WHICH == 6 || WHICH == 7) ? 64 : 1); ++k) w64[k] = 0.0;
+    for (int k = 0; k < ((WHICH == 6 || WHICH == 7 || WHICH == 8) ? 64 : 1); ++k) w64[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { acc[k] = (sl_d4){0.0, 0.0, 0.0, 0.0}; v[k] = threadIdx.x * 1e-3 + k; }
 #pragma unroll
@@ -602,6 +607,13 @@ __global__ __launch_bounds__(256) void k_fp64_rate(int iters, double* sink, long
                 for (int q = 0; q < 2; ++q)
                     w16[(2 * k + q) & 15] = __builtin_amdgcn_mfma_f64_4x4x4f64(
                         v[(k + q) & 3], v[4 + ((k >> 1) & 3)], w16[(2 * k + q) & 15], 0, 0, 0);
+            }
+            if (WHICH == 8) {             // 4x4x4 MFMAs fed by LDS reads: one ds_read_b128 per 8 MFMAs
+                const sl_d2 t = *reinterpret_cast<const sl_d2*>(&probe_lds[((it * 8 + k) & 31) * 128 + 2 * (threadIdx.x & 63)]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    w64[8 * k + q] = __builtin_amdgcn_mfma_f64_4x4x4f64(q & 1 ? t.x : t.y, w16[q + 8 * (k >> 2)],
+                                                                          w64[8 * k + q], 0, 0, 0);
             }
             if (WHICH == 7) {             // 4x4x4 MFMAs with FP64 VALU work between them (same wavefront)
 #pragma unroll
@@ -628,14 +640,14 @@ __global__ __launch_bounds__(256) void k_fp64_rate(int iters, double* sink, long
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += acc[k].x + acc[k].y + acc[k].z + acc[k].w + v[k] + w16[k] + w16[k + 8];
 #pragma unroll
-    for (int k = 0; k < ((WHICH == 6 || WHICH == 7) ? 64 : 1); ++k) s += w64[k];
+    for (int k = 0; k < ((WHICH == 6 || WHICH == 7 || WHICH == 8) ? 64 : 1); ++k) s += w64[k];
     const long long c1 = clock64(), w1 = wall_clock64();
     if (s == 12345.678) sink[0] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
 }
 
 extern "C" int sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_out) {
-    if (!ctx || !h_out || which < 0 || which > 7 || iters < 1)
+    if (!ctx || !h_out || which < 0 || which > 8 || iters < 1)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_debug_fp64_rate: bad argument");
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const char* env = getenv("SL_PROBE_BLOCKS_PER_CU");
@@ -657,7 +669,8 @@ extern "C" int sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_o
         else if (which == 4) hipLaunchKernelGGL(k_fp64_rate<4>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
         else if (which == 5) hipLaunchKernelGGL(k_fp64_rate<5>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
         else if (which == 6) hipLaunchKernelGGL(k_fp64_rate<6>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
-        else hipLaunchKernelGGL(k_fp64_rate<7>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
+        else if (which == 7) hipLaunchKernelGGL(k_fp64_rate<7>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
+        else hipLaunchKernelGGL(k_fp64_rate<8>, dim3(blocks), dim3(256), 0, ctx->stream, iters, sink, clocks);
         SL_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
         SL_HIP_CHECK(ctx, hipEventSynchronize(e1));
     }
@@ -670,7 +683,7 @@ extern "C" int sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_o
     if (which == 0 || which == 2 || which == 3) flops += waves * (double)iters * 8.0 * (2.0 * 16 * 16 * 4);
     if (which == 4) flops += waves * (double)iters * 8.0 * (4 * 2.0 * 4 * 4 * 4);
     if (which == 5) flops += waves * (double)iters * 16.0 * (4 * 2.0 * 4 * 4 * 4);
-    if (which == 6 || which == 7) flops += waves * (double)iters * 64.0 * (4 * 2.0 * 4 * 4 * 4);
+    if (which == 6 || which == 7 || which == 8) flops += waves * (double)iters * 64.0 * (4 * 2.0 * 4 * 4 * 4);
     if (which == 7) flops += waves * (double)iters * 64.0 * 2.0 * 64.0 * 2.0;
     if (which == 1 || which == 2) flops += waves * (double)iters * 8.0 * 16.0 * 64.0 * 2.0;
     h_out[0] = flops / (ms * 1e-3) / 1e12;                       // TFLOP/s
