@@ -49,7 +49,7 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
-    int xs_doubles, const double* __restrict__ points) {
+    int xs_doubles, int alpha_doubles, const double* __restrict__ points) {
     constexpr int C = 16 * CB;
     constexpr int RP = 16 * R * W;                 // rows per panel
     constexpr int RB = R * W;                      // row blocks per panel
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* xs_l = smem;                           // [p][n_pad]
-    double* kx_l = xs_l + xs_doubles;              // [2][KXBUF]
+    double* alpha_l = xs_l + xs_doubles;           // [n_pad][dout] when it fits (alpha_doubles > 0)
+    double* kx_l = alpha_l + alpha_doubles;        // [2][KXBUF]
     double* part_ss = kx_l + 2 * KXBUF;            // [W][C]
     double* part_m = part_ss + W * C;              // [W][16][DOUT_MAX]
     double* cell_mean = part_m + W * 16 * SL_GP_DOUT_MAX;    // [C][SL_D]
@@ -95,11 +96,13 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
             const int n_pad = hd.n_pad, dout = hd.dout;
             const int nslab2 = hd.nslab2;
             const double variance = hd.variance;
-            const double* __restrict__ alphap = hd.alpha;
+            const double* __restrict__ alphap = alpha_doubles > 0 ? alpha_l : hd.alpha;
             const double* __restrict__ mpack = hd.mpack;
             if (staged_head != h) {
                 __syncthreads();
                 for (int k = tid; k < p * n_pad; k += W * 64) xs_l[k] = hd.xs[k];
+                if (alpha_doubles > 0)
+                    for (int k = tid; k < n_pad * dout; k += W * 64) alpha_l[k] = hd.alpha[k];
                 staged_head = h;
                 __syncthreads();
             }
@@ -449,8 +452,18 @@ static int launch_cfg(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t 
         xs_doubles = v > xs_doubles ? v : xs_doubles;
     }
     xs_doubles = (xs_doubles + 1) & ~1;            // keep the k_x buffers 16-byte aligned
-    const size_t lds = sizeof(double) * ((size_t)xs_doubles + 2 * SL_GP_SLABS_PER_CHUNK * CB * 64 +
-                                         W * C + W * 16 * SL_GP_DOUT_MAX + 2 * C * SL_D + 2 * W);
+    size_t lds = sizeof(double) * ((size_t)xs_doubles + 2 * SL_GP_SLABS_PER_CHUNK * CB * 64 +
+                                   W * C + W * 16 * SL_GP_DOUT_MAX + 2 * C * SL_D + 2 * W);
+    // alpha' next to the training inputs when LDS has room (the mean accumulation of the k_x
+    // generation then reads LDS instead of L2)
+    int alpha_doubles = 0;
+    for (int h = 0; h < ctx->h_gp.nheads; ++h) {
+        const int v = ctx->gp_heads[h].n_pad * ctx->gp_heads[h].dout;
+        alpha_doubles = v > alpha_doubles ? v : alpha_doubles;
+    }
+    alpha_doubles = (alpha_doubles + 1) & ~1;
+    if (lds + sizeof(double) * alpha_doubles <= 160 * 1024) lds += sizeof(double) * alpha_doubles;
+    else alpha_doubles = 0;
     if (lds > 160 * 1024)
         return sl_fail(ctx, SL_ERR_UNSUPPORTED, "GP training set too large for LDS staging "
                                                 "(%zu bytes needed)", lds);
@@ -463,7 +476,7 @@ static int launch_cfg(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t 
     SlAux aux{ctx->d_tri, ctx->d_net};
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, ctx->stream, model,
                        ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits, ctx->d_partials, d_dbg,
-                       xs_doubles, d_points);
+                       xs_doubles, alpha_doubles, d_points);
     SL_HIP_CHECK(ctx, hipGetLastError());
     return SL_OK;
 }
