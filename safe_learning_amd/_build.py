@@ -32,16 +32,36 @@ def build(verbose=False, force=False):
     if not force and not _newer(LIB, deps):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-           "-shared", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-o", LIB] + srcs
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+             "-I" + os.path.join(ROOT, "include"), "-I" + csrc]
+    flags += os.environ.get("SL_EXTRA_FLAGS", "").split()         # experiments: -DSL_GP_CFG... etc.
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
+    # one hipcc per translation unit, all at once (the kernels are heavily templated: ~2-4 min of
+    # compile time in total), then one link
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for obj, proc in jobs:
+        out, _ = proc.communicate()
+        if verbose or proc.returncode != 0:
+            sys.stderr.write(out)
+        failed = failed or proc.returncode != 0
+    if failed:
+        raise RuntimeError("hipcc failed")
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [obj for obj, _ in jobs]
+    res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         sys.stderr.write(res.stdout)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed (exit %d)" % res.returncode)
+        raise RuntimeError("hipcc link failed (exit %d)" % res.returncode)
     return LIB
 
 
