@@ -104,6 +104,9 @@ def load_library():
         raise HipEngineError(
             "libslhip.so is missing (%s). Build it with `python -m safe_learning_amd._build`; "
             "safe_learning_amd has no CPU fallback." % LIB_PATH)
+    # torch first: libslhip.so must bind the HIP runtime that torch ships (loading the system
+    # libamdhip64 before torch's copy leaves the process with two runtimes, one without devices)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.sl_version.restype = C.c_int
     lib.sl_last_error.restype = C.c_char_p
