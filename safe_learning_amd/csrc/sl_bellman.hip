@@ -44,7 +44,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
                                            actions[a * m + c] * hd.inv_ls[d + c];
                         z = fma(dlt, dlt, z);
                     }
-                    e = exp(-0.5 * z);
+                    e = sl_exp_nonpos(-0.5 * z);
                 }
                 smem[off + t] = e;
             }
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
                                     z = fma(dlt, dlt, z);
                                 }
                             }
-                            const double kx = hd.variance * exp(-0.5 * z);
+                            const double kx = hd.variance * sl_exp_nonpos(-0.5 * z);
 #pragma unroll
                             for (int k = 0; k < SL_D; ++k) {
                                 const int dd = k - hd.col0;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
                             z = fma(dlt, dlt, z);
                         }
                     }
-                    const double s = hd.variance * exp(-0.5 * z);
+                    const double s = hd.variance * sl_exp_nonpos(-0.5 * z);
                     // s * alpha'[j][.] once per training point, then one FMA per (action, column)
                     double sa[DT > 0 ? DT : SL_D];
 #pragma unroll
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_bellman_pack(const SlDevModel M, const 
                 const double dlt = hd.xs[(d + c) * n_pad + j] - actions[a * m + c] * hd.inv_ls[d + c];
                 z = fma(dlt, dlt, z);
             }
-            v = hd.variance * exp(-0.5 * z) * hd.alpha[j * hd.dout + dd];
+            v = hd.variance * sl_exp_nonpos(-0.5 * z) * hd.alpha[j * hd.dout + dd];
         }
         pack[t] = v;
     }
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_bellman_pack(const SlDevModel M, const 
             double v = 0.0;
             if (j < hd.n) {
                 const double dlt = hd.xs[k * n_pad + j] - x[k] * hd.inv_ls[k];
-                v = exp(-0.5 * (dlt * dlt));
+                v = sl_exp_nonpos(-0.5 * (dlt * dlt));
             }
             tab[t] = v;
         }
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
 #pragma unroll
                 for (int k = 0; k < SL_D; ++k) if (k < d - 1) v *= trow[k][j];
                 const double dlt = xs_u[j] - ug;
-                v *= exp(-0.5 * (dlt * dlt));
+                v *= sl_exp_nonpos(-0.5 * (dlt * dlt));
 #pragma unroll
                 for (int k = 0; k < SL_D; ++k)
                     if (k < dout) mean[k] = fma(v, hd.alpha[(size_t)j * dout + k], mean[k]);

@@ -389,6 +389,31 @@ SL_HD double sl_tri_eval(const SlTri& t, const double* x, int col, double* grad)
     return value;
 }
 
+// exp(x) for x <= 0: 2^k * p(r), k = rint(x log2 e), r = x - k ln 2 in two pieces, p the degree-13
+// Taylor polynomial on |r| <= ln 2 / 2 (truncation 4e-18 relative, result within 2 ulp): 20
+// instructions and no branches where the library routine takes about twice that.  Used by the
+// FP64-VALU-bound Bellman kernels; deep underflow goes through ldexp to 0.
+SL_HD double sl_exp_nonpos(double x) {
+    const double k = rint(x * 1.4426950408889634);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double q = 1.6059043836821613e-10;                      // 1/13!
+    q = fma(q, r, 2.08767569878681e-09);
+    q = fma(q, r, 2.505210838544172e-08);
+    q = fma(q, r, 2.755731922398589e-07);
+    q = fma(q, r, 2.7557319223985893e-06);
+    q = fma(q, r, 2.48015873015873e-05);
+    q = fma(q, r, 1.984126984126984e-04);
+    q = fma(q, r, 1.3888888888888889e-03);
+    q = fma(q, r, 8.333333333333333e-03);
+    q = fma(q, r, 4.1666666666666664e-02);
+    q = fma(q, r, 1.6666666666666666e-01);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return ldexp(q, (int)k);
+}
+
 // Derived constants of a triangulation; call after filling simplices / hyper / grid.
 inline void sl_tri_finish(SlTri& t) {
     const int d = t.grid.d;

@@ -222,3 +222,20 @@ def test_triangulation_golden_cases(hostsim, golden):
     tri = F.Triangulation(grid, values)
     _, grad = _tri_eval(hostsim, tri, np.array(g["test_points"]), want_grad=True)
     assert_allclose(grad, g["expected_gradient"])
+
+
+def test_exp_nonpos(hostsim):
+    """sl_exp_nonpos (the 20-instruction exp of the Bellman kernels) within 2 ulp of numpy on the
+    range the RBF kernel uses, exact at 0, monotone into the underflow."""
+    hostsim.hs_exp_nonpos.restype = C.c_double
+    hostsim.hs_exp_nonpos.argtypes = [C.c_double]
+    rng = np.random.default_rng(7)
+    x = -np.concatenate([rng.uniform(0, 50, 4000), rng.uniform(0, 1e-3, 500), rng.uniform(50, 745, 500),
+                         [0.0, np.log(2) / 2, np.log(2), 700.0]])
+    got = np.array([hostsim.hs_exp_nonpos(float(v)) for v in x])
+    ref = np.exp(x)
+    normal = ref > 1e-300
+    assert np.max(np.abs(got[normal] - ref[normal]) / ref[normal]) < 4.5e-16
+    assert_allclose(got[~normal], ref[~normal], rtol=1e-12, atol=5e-324)
+    assert hostsim.hs_exp_nonpos(0.0) == 1.0
+    assert hostsim.hs_exp_nonpos(-800.0) == 0.0
