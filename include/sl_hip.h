@@ -212,7 +212,9 @@ int  sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uint64_t* 
  * n_actions  > 0: u_a = h_actions[a] (row-major [n_actions][m]); writes max_a q and the first
  *                 arg-max (discrete_policy_optimization, :266-279); d_q (may be NULL) gets all q.
  *   d_v_new [hi-lo], d_argmax [hi-lo] (may be NULL), d_stats[2] = {max_i |v_new_i - table_i|,
- *   sum_i (v_new_i - V(x_i))^2} with V(x_i) interpolated as in reinforcement_learning.py:130-133. */
+ *   sum_i (v_new_i - V(x_i))^2} with V(x_i) interpolated as in reinforcement_learning.py:130-133;
+ *   the sum (the Bellman error of the current policy, :116-133) is produced for n_actions == 0
+ *   only and is 0 otherwise. */
 int  sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const double* h_actions,
                       double* d_v_new, int32_t* d_argmax, double* d_q, double* d_stats);
 

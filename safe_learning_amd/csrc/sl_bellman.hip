@@ -180,12 +180,16 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
         // stats[0]: max |V_new - V_old| on the vertex table (convergence test of the examples);
         // stats[1]: sum (target - V(x))^2 with V(x) interpolated like the reference does
         //           (reinforcement_learning.py:130-133)
+        //           - the Bellman error of the current policy, n_actions == 0 only
         double v_old = vt.table[idx * vt.ncols];
-        double v_int = sl_tri_value_fast<DT>(vt, x);
-        if (M.m.value.negate) { v_old = v_old * -1.0; v_int = v_int * -1.0; }
+        if (M.m.value.negate) v_old = v_old * -1.0;
         lmax = fmax(lmax, fabs(best_q - v_old));
-        const double diff = best_q - v_int;
-        lsum = fma(diff, diff, lsum);
+        if (!ACTIONS) {
+            double v_int = sl_tri_value_fast<DT>(vt, x);
+            if (M.m.value.negate) v_int = v_int * -1.0;
+            const double diff = best_q - v_int;
+            lsum = fma(diff, diff, lsum);
+        }
     }
     // ---- residual statistics ----------------------------------------------------------------------
     for (int off = 32; off >= 1; off >>= 1) {
@@ -436,14 +440,9 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
                     }
                     v_new[idx - lo] = best_q;
                     if (argmax) argmax[idx - lo] = best_a;
-                    double x[SL_P];
-                    sl_index_to_state(M.m.grid, M.gf, d, idx, x);
-                    double v_old = vt.table[idx * vt.ncols];
-                    double v_int = sl_tri_value_fast<DT>(vt, x);
-                    if (M.m.value.negate) { v_old = v_old * -1.0; v_int = v_int * -1.0; }
+                    double v_old = vt.table[idx * vt.ncols];         // stats[1] is policy-mode only
+                    if (M.m.value.negate) v_old = v_old * -1.0;
                     lmax = fmax(lmax, fabs(best_q - v_old));
-                    const double diff = best_q - v_int;
-                    lsum = fma(diff, diff, lsum);
                 }
             }
             __syncthreads();
