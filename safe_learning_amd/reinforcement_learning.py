@@ -118,8 +118,10 @@ class PolicyIteration(object):
             self.policy._adopt_device_table(table.contiguous())
         else:
             self.policy = Triangulation(self.discretization, table.cpu().numpy())
-        return self._gather(q.reshape(-1)[:(self._hi - self._lo) * action_space.shape[0]]
-                            ).reshape(-1, action_space.shape[0]) if self._world == 1 else None
+        n_act = action_space.shape[0]
+        sizes = [(self._bounds[r + 1] - self._bounds[r]) * n_act for r in range(self._world)]
+        flat = q.reshape(-1)[:(self._hi - self._lo) * n_act]
+        return dist_utils.allgather_concat(flat, sizes).reshape(-1, n_act)
 
     def optimize_value_function(self, **solver_options):
         """The cvxpy linear program of ``:142-211`` is outside the accelerated path."""

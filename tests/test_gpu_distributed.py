@@ -80,6 +80,40 @@ def _worker(rank, world, port, results, backend="gloo"):
         if (not np.array_equal(lyap.safe_set, olyap.safe_set) or lyap.c_max != olyap.c_max
                 or not np.array_equal(lyap._refinement, olyap._refinement)):
             failures.append(("adaptive", shrink))
+    # PolicyIteration across ranks: each rank sweeps its shard of the vertices (matrix-core
+    # kernels: the last axis is a whole number of wavefronts), the new table is all-gathered
+    import test_gpu_rl
+    case = cases.make_case("pendulum", num_points=[12, 64], n_gp=70)
+    rl, orl, vf, ovf = test_gpu_rl._rl_pair(sl, case, [12, 64])
+    assert rl._world == world
+    actions = np.linspace(-1, 1, 9)[:, None]
+    grid, ogrid = vf.discretization, ovf.discretization
+    rl.policy = sl.Triangulation(grid, np.zeros((grid.nindex, 1)))
+    orl.policy = oracle.Triangulation(ogrid, np.zeros((ogrid.nindex, 1)))
+    rl.discrete_policy_optimization(actions)
+    oq, _ = orl.discrete_policy_optimization(actions)
+    x = orl.state_space
+    ok_q = np.ones_like(oq, dtype=bool)
+    for a, action in enumerate(actions):
+        nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))
+        ok_q[:, a] = ~test_gpu_rl.ambiguous_points(ovf, nxt[0] if isinstance(nxt, tuple) else nxt)
+    top2 = np.sort(oq, axis=1)[:, -2:]
+    tie = np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1])
+    best, obest = rl.policy._host_parameters()[:, 0], orl.policy.parameters[:, 0]
+    if np.any((best != obest) & ok_q.all(axis=1) & ~tie):
+        failures.append(("rl", "greedy policy"))
+    rl.policy.parameters = orl.policy.parameters.copy()
+    for sweep in range(2):
+        vf.parameters = ovf.parameters.copy()
+        nxt = orl.dynamics(x, orl.policy(x))
+        nxt = nxt[0] if isinstance(nxt, tuple) else nxt
+        ok = ~test_gpu_rl.ambiguous_points(orl.policy, x) & ~test_gpu_rl.ambiguous_points(ovf, nxt)
+        res = rl.value_iteration()
+        orl.value_iteration()
+        if not np.allclose(vf._host_parameters()[ok], ovf.parameters[ok], rtol=1e-9, atol=1e-12):
+            failures.append(("rl", "value_iteration", sweep))
+        if not res >= 0.0:
+            failures.append(("rl", "residual", res))
     results[rank] = failures
     dist.barrier()
     dist.destroy_process_group()
