@@ -179,7 +179,7 @@ class Context(object):
         if rc != 0:
             raise HipEngineError("sl_ctx_create failed: %s" % self.lib.sl_last_error(None).decode())
         self.handle = handle
-        self._keepalive = []
+        self._keepalive = {}        # slot -> the device table the engine currently points at
 
     def close(self):
         if getattr(self, "handle", None):
@@ -218,13 +218,13 @@ class Context(object):
         simplices = np.ascontiguousarray(simplices, dtype=np.int32)
         hyper, ph = _as_c(hyperplanes)
         pts, pp = _as_c(np.concatenate(discrete_points))
-        self._keepalive.append(table)
+        self._keepalive[slot] = table
         self.check(self.lib.sl_tri_set(self.handle, slot, C.byref(grid_desc), len(simplices),
                                        simplices.ctypes.data_as(C.POINTER(C.c_int32)), ph, pp,
                                        int(bool(project)), ncols, _ptr(table)), "sl_tri_set")
 
     def tri_set_table(self, slot, table):
-        self._keepalive.append(table)
+        self._keepalive[slot] = table
         self.check(self.lib.sl_tri_set_table(self.handle, slot, _ptr(table)), "sl_tri_set_table")
 
     def network_set(self, dims, activations, kernels):
