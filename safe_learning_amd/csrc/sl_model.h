@@ -198,13 +198,46 @@ SL_HD void sl_saturate(const sl_policy_desc& p, int m, double* u) {
 // ---------------------------------------------------------------------------------------------
 // analytic dynamics
 // ---------------------------------------------------------------------------------------------
+// sin and cos of one angle with a shared argument reduction: k = rint(x 2/pi), r = x - k pi/2 in
+// three pieces (exact products for |k| < 2^20), fdlibm's kernel polynomials on |r| <= pi/4,
+// quadrant fix-up.  About 35 instructions for the pair (the library calls take ~60 each) and
+// within 1.5 ulp; the Euler integrators below call it 10 times per cell.
+SL_HD void sl_sincos(double x, double* sn, double* cs) {
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(k, -1.57079632673412561417e+00, x);
+    r = fma(k, -6.07710050630396597660e-11, r);
+    r = fma(k, -2.02226624871116645580e-21, r);
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double s_out = (q & 1) ? c : s;
+    const double c_out = (q & 1) ? s : c;
+    *sn = (q & 2) ? -s_out : s_out;
+    *cs = ((q + 1) & 2) ? -c_out : c_out;
+}
+
 // coef: [0]=dt/10 [1]=g/l [2]=inertia [3]=friction/inertia [4]=(friction>0)
 SL_HD void sl_pendulum(const sl_dynamics_desc& f, const double* x, const double* u, double* nxt) {
     double th = x[0], om = x[1], act = u[0];
     if (f.normalize) { th = th * f.tx[0]; om = om * f.tx[1]; act = act * f.tu[0]; }
     const double dt = f.coef[0];
     for (int it = 0; it < 10; ++it) {
-        double acc = f.coef[1] * sin(th);
+        double sth, cth;
+        sl_sincos(th, &sth, &cth);
+        double acc = f.coef[1] * sth;
         double t2 = act / f.coef[2];
         acc = acc + t2;
         if (f.coef[4] != 0.0) {
@@ -230,7 +263,9 @@ SL_HD void sl_cartpole(const sl_dynamics_desc& f, const double* x, const double*
     }
     const double dt = f.coef[0], m = f.coef[1], M = f.coef[2], L = f.coef[3], b = f.coef[4];
     for (int it = 0; it < 10; ++it) {
-        double s = sin(th), c = cos(th), s2 = sin(2.0 * th);
+        double s, c;
+        sl_sincos(th, &s, &c);
+        double s2 = 2.0 * (s * c);                   // sin(2 theta)
         double om2 = om * om;
         double det = m * (s * s);
         det = M + det;

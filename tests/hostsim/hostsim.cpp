@@ -94,6 +94,7 @@ int hs_tri_eval(const sl_grid_desc* grid, int nsimplex, const int32_t* simplices
 
 double hs_fmod_exact(double a, double b) { return sl_fmod_exact(a, b); }
 double hs_exp_nonpos(double x) { return sl_exp_nonpos(x); }
+void hs_sincos(double x, double* s, double* c) { sl_sincos(x, s, c); }
 
 uint64_t hs_vbits(double v) { return sl_vbits(v); }
 double hs_vbits_to_double(uint64_t b) { return sl_vbits_to_double(b); }
