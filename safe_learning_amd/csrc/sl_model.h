@@ -429,6 +429,7 @@ SL_HD double sl_tri_eval(const SlTri& t, const double* x, int col, double* grad)
 // instructions and no branches where the library routine takes about twice that.  Used by the
 // FP64-VALU-bound Bellman kernels; deep underflow goes through ldexp to 0.
 SL_HD double sl_exp_nonpos(double x) {
+    x = x < -800.0 ? -800.0 : x;                             // -inf -> 0 (NaN stays NaN)
     const double k = rint(x * 1.4426950408889634);
     double r = fma(k, -6.93147180369123816490e-01, x);
     r = fma(k, -1.90821492927058770002e-10, r);

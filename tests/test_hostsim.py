@@ -239,6 +239,8 @@ def test_exp_nonpos(hostsim):
     assert_allclose(got[~normal], ref[~normal], rtol=1e-12, atol=5e-324)
     assert hostsim.hs_exp_nonpos(0.0) == 1.0
     assert hostsim.hs_exp_nonpos(-800.0) == 0.0
+    assert hostsim.hs_exp_nonpos(-np.inf) == 0.0
+    assert np.isnan(hostsim.hs_exp_nonpos(np.nan))
 
 
 def test_sincos(hostsim):
