@@ -44,7 +44,9 @@ static const int kCfgCB[3] = {1, 2, 4};
 
 static inline int cfg_panel_rows(int cfg) { return 16 * kCfgR[cfg] * kCfgW[cfg]; }
 
-template <int W, int R, int CB, bool GENERAL, int DT, int MT>
+// XSG: the scaled training inputs do not fit LDS next to the k_x buffers and are read from L2
+// during generation (instantiated for the 64-cell-tile configuration only).
+template <int W, int R, int CB, bool GENERAL, int DT, int MT, bool XSG = false>
 __global__ __launch_bounds__(W * 64) void k_gp_sweep(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
@@ -98,9 +100,11 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
             const double variance = hd.variance;
             const double* __restrict__ alphap = alpha_doubles > 0 ? alpha_l : hd.alpha;
             const double* __restrict__ mpack = hd.mpack;
+            const double* __restrict__ xs_glob = hd.xs;
             if (staged_head != h) {
                 __syncthreads();
-                for (int k = tid; k < p * n_pad; k += W * 64) xs_l[k] = hd.xs[k];
+                if (!XSG)
+                    for (int k = tid; k < p * n_pad; k += W * 64) xs_l[k] = hd.xs[k];
                 if (alpha_doubles > 0)
                     for (int k = tid; k < n_pad * dout; k += W * 64) alpha_l[k] = hd.alpha[k];
                 staged_head = h;
@@ -149,7 +153,8 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
 #pragma unroll
                         for (int q = 0; q < SL_P; ++q) {
                             if (q < p) {
-                                const double dlt = xs_l[q * n_pad + j] - xg[q];
+                                const double xv = XSG ? xs_glob[q * n_pad + j] : xs_l[q * n_pad + j];
+                                const double dlt = xv - xg[q];
                                 z = fma(dlt, dlt, z);
                             }
                         }
@@ -435,7 +440,7 @@ extern "C" int sl_gp_configure(sl_ctx* ctx, int nheads, double beta) {
     return SL_OK;
 }
 
-template <int W, int R, int CB, bool GENERAL, int DT, int MT>
+template <int W, int R, int CB, bool GENERAL, int DT, int MT, bool XSG = false>
 static int launch_cfg(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
                       const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits, int* nblocks, double* d_dbg,
                       const double* d_points) {
@@ -452,6 +457,7 @@ static int launch_cfg(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t 
         xs_doubles = v > xs_doubles ? v : xs_doubles;
     }
     xs_doubles = (xs_doubles + 1) & ~1;            // keep the k_x buffers 16-byte aligned
+    if (XSG) xs_doubles = 0;                       // training inputs stay in global memory / L2
     size_t lds = sizeof(double) * ((size_t)xs_doubles + 2 * SL_GP_SLABS_PER_CHUNK * CB * 64 +
                                    W * C + W * 16 * SL_GP_DOUT_MAX + 2 * C * SL_D + 2 * W);
     // alpha' next to the training inputs when LDS has room (the mean accumulation of the k_x
@@ -467,7 +473,7 @@ static int launch_cfg(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t 
     if (lds > 160 * 1024)
         return sl_fail(ctx, SL_ERR_UNSUPPORTED, "GP training set too large for LDS staging "
                                                 "(%zu bytes needed)", lds);
-    auto kern = k_gp_sweep<W, R, CB, GENERAL, DT, MT>;
+    auto kern = k_gp_sweep<W, R, CB, GENERAL, DT, MT, XSG>;
     SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t blocks = ntiles < ctx->num_cu ? ntiles : ctx->num_cu;
@@ -493,6 +499,27 @@ int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
                        covered, model.m.grid.d);
     const bool general = sl_model_is_general(model);
     const int variant = sl_dim_variant_of(model);
+    // training inputs too large to sit in LDS beside the k_x buffers: 64-cell-tile configuration
+    // with the inputs read from L2 (fast-path models with 2 or 4 state dimensions)
+    {
+        int xs_max = 0;
+        for (int h = 0; h < ctx->h_gp.nheads; ++h) {
+            const int v = model.in_dim * ctx->gp_heads[h].n_pad;
+            xs_max = v > xs_max ? v : xs_max;
+        }
+        const size_t fixed = sizeof(double) * (2 * SL_GP_SLABS_PER_CHUNK * 4 * 64 + 8 * 64 +
+                                               8 * 16 * SL_GP_DOUT_MAX + 2 * 64 * SL_D + 2 * 8);
+        if (ctx->gp_cfg == 2 && fixed + sizeof(double) * xs_max > 160 * 1024) {
+            if (!general && variant == 4)
+                return launch_cfg<8, 4, 4, false, 4, 1, true>(ctx, model, lo, hi, d_init_bits, d_values,
+                                                              d_neg_bits, nblocks, d_dbg, d_points);
+            if (!general && variant == 2)
+                return launch_cfg<8, 4, 4, false, 2, 1, true>(ctx, model, lo, hi, d_init_bits, d_values,
+                                                              d_neg_bits, nblocks, d_dbg, d_points);
+            return launch_cfg<8, 4, 4, true, 0, 0, true>(ctx, model, lo, hi, d_init_bits, d_values,
+                                                         d_neg_bits, nblocks, d_dbg, d_points);
+        }
+    }
 #define SL_GP_LAUNCH(W_, R_, CB_, G, D_, M_)                                                      \
     return launch_cfg<W_, R_, CB_, G, D_, M_>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,     \
                                               nblocks, d_dbg, d_points)

@@ -82,12 +82,3 @@ def test_host_class_argument_checks(sl):
     with pytest.raises(Exception):
         sl.Triangulation(grid, np.zeros(7))               # wrong number of vertex values
 
-
-def test_training_set_too_large_for_lds(sl):
-    """2000 training points with 5 inputs do not fit the LDS staging of k_gp_sweep: the sweep
-    refuses with an error instead of running a slower or wrong path."""
-    from safe_learning_amd import _hip
-    from safe_learning_amd.benchmarks import build_lyapunov
-    with pytest.raises(_hip.HipEngineError, match="too large for LDS"):
-        lyap = build_lyapunov(cases.make_case("cartpole", num_points=4, n_gp=2000, tau_scale=0.0))
-        lyap.update_safe_set()

@@ -193,8 +193,11 @@ GP_CASES = [
     ("pendulum", dict(num_points=48, n_gp=600, tau_scale=0.0), "2"),        # cfg 2, 2 panels
     ("cartpole", dict(num_points=7, n_gp=1100, tau_scale=0.0), "1"),        # cfg 1, 2 panels
     ("cartpole", dict(num_points=7, n_gp=520, tau_scale=0.0), "2"),         # cfg 2, 2 panels
-    # largest panel count the LDS staging takes at p = 5 (alpha' stays in global memory)
+    # largest training set whose inputs fit LDS at p = 5 (alpha' stays in global memory) ...
     ("cartpole", dict(num_points=5, n_gp=1500, tau_scale=0.0), None),
+    # ... and beyond it: the generation phase reads the training inputs from L2
+    ("cartpole", dict(num_points=4, n_gp=2000, tau_scale=0.0), None),
+    ("pendulum", dict(num_points=12, n_gp=2600, tau_scale=0.0), None),
 ]
 
 
