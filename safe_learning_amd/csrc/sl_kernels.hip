@@ -338,8 +338,19 @@ static inline int sl_dim_variant(const SlDevModel& M) {
 // values: V(x_i)                                             (lyapunov.py:305-322)
 // =============================================================================================
 template <bool GENERAL, int DT, int MT>
-__global__ __launch_bounds__(SL_BLOCK) void k_values(const SlDevModel M, SlAux aux, int64_t lo,
+__global__ __launch_bounds__(SL_BLOCK) void k_values(const SlDevModel M_arg, SlAux aux, int64_t lo,
                                                      int64_t hi, double* __restrict__ values) {
+    SlDevModel M = M_arg;
+    if (!GENERAL && DT > 0) {            // quadratic form and grid constants as vector operands
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+            asm volatile("" : "+v"(M.m.grid.unit_maxes[k]));
+            asm volatile("" : "+v"(M.m.grid.offset[k]));
+            asm volatile("" : "+v"(M.m.grid.upper[k]));
+#pragma unroll
+            for (int q = 0; q < DT; ++q) asm volatile("" : "+v"(M.m.value.matrix[k][q]));
+        }
+    }
     const SlDims n = sl_dims<DT, MT>(M);
     for (int64_t idx = lo + (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; idx < hi;
          idx += (int64_t)gridDim.x * SL_BLOCK) {
