@@ -498,14 +498,24 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
     const int G = 16 / dout;                                               // actions per GEMM
     const int cg = lc / dout, cdd = lc - cg * dout;                        // this lane's B column
     double lmax = 0.0, lsum = 0.0;
-    const int64_t wg_cells = 64 * SL_BM_WAVES;
-    const int64_t nsteps = (hi - lo + wg_cells - 1) / wg_cells;
+    // work item = one segment of at most 64 consecutive cells of one row of the last grid axis
+    // (the cells of a segment share the leading-axis indices); rows that straddle [lo, hi) and
+    // the ragged last segment of a row are masked
+    const int64_t segs = (n_last + 63) / 64;
+    const int64_t row_lo = lo / n_last, row_hi = (hi + n_last - 1) / n_last;
+    const int64_t nitems = (row_hi - row_lo) * segs;
+    const int64_t nsteps = (nitems + SL_BM_WAVES - 1) / SL_BM_WAVES;
     for (int64_t step = blockIdx.x; step < nsteps; step += gridDim.x) {
-        const int64_t wbase = lo + step * wg_cells + 64 * wave;            // lo and the rows are 64-aligned
-        if (wbase >= hi) continue;
+        const int64_t item = step * SL_BM_WAVES + wave;
+        if (item >= nitems) continue;
+        const int64_t row = row_lo + item / segs;
+        const int seg0 = (int)(item % segs) * 64;                          // first last-axis index
+        const int64_t wbase = row * n_last + seg0;
         const int64_t idx = wbase + lane;
-        const bool valid = idx < hi;
-        const int64_t cidx = valid ? idx : hi - 1;
+        const bool valid = seg0 + lane < n_last && idx >= lo && idx < hi;
+        int64_t cidx = row * n_last + (seg0 + lane < n_last ? seg0 + lane : n_last - 1);
+        cidx = cidx < lo ? lo : (cidx < hi ? cidx : hi - 1);
+        if (__ballot(valid) == 0ull) continue;
         double x[SL_P], u[SL_M];
         sl_index_to_state(M.m.grid, M.gf, d, cidx, x);
         sl_policy_any<true>(M, nd, aux.tri, cidx, x, u);
@@ -541,7 +551,13 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const double* ap = tabs + pk.toff[d - 1] + (int64_t)lk * n_last + ijk[d - 1] + lc;
+            const double* ap = tabs + pk.toff[d - 1] + (int64_t)lk * n_last;
+            int acol[4];                                     // last-axis index of this lane per tile
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = seg0 + 16 * t + lc;
+                acol[t] = c < n_last ? c : n_last - 1;
+            }
             const size_t astep = (size_t)4 * n_last;
             for (int g0 = 0; g0 < ng; g0 += G) {
                 const bool col_on = cg < G && g0 + cg < ng;
@@ -558,18 +574,18 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
                 for (int t = 0; t < 4; ++t) acc[t] = (sl_bd4){0.0, 0.0, 0.0, 0.0};
                 double a_cur[4], a_nxt[4], b_cur, b_nxt;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) a_cur[t] = ap[16 * t];
+                for (int t = 0; t < 4; ++t) a_cur[t] = ap[acol[t]];
                 b_cur = b_elem(0);
                 for (int s = 0; s < nslab; s += 2) {
                     const int s1 = s + 1, s2 = s + 2 < nslab ? s + 2 : 0;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) a_nxt[t] = ap[s1 * astep + 16 * t];
+                    for (int t = 0; t < 4; ++t) a_nxt[t] = ap[s1 * astep + acol[t]];
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[t], b_cur, acc[t], 0, 0, 0);
                     b_nxt = b_elem(s1);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) a_cur[t] = ap[s2 * astep + 16 * t];
+                    for (int t = 0; t < 4; ++t) a_cur[t] = ap[s2 * astep + acol[t]];
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_nxt[t], b_nxt, acc[t], 0, 0, 0);
@@ -597,7 +613,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
         } else if (valid) {
             // smooth policy: one exponential per (cell, training point)
             const double ug = u[0] * inv_ls_u;
-            const double* tl = tabs + pk.toff[d - 1] + ijk[d - 1] + lane;
+            const double* tl = tabs + pk.toff[d - 1] + (seg0 + lane < n_last ? seg0 + lane : n_last - 1);
             for (int j = 0; j < hd.n; ++j) {
                 double v = hd.variance * tl[(size_t)j * n_last];
 #pragma unroll
@@ -668,10 +684,10 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
     memset(&pk, 0, sizeof(pk));
     const bool policy_mode = n_actions == 0;
     if (policy_mode) {
-        // worthwhile for piecewise-constant policies; rows of the last axis must be whole wavefronts
+        // worthwhile for piecewise-constant policies
         const int pkind = M.m.policy.kind;
         if (pkind != SL_POLICY_TRI && pkind != SL_POLICY_TABLE && pkind != SL_POLICY_CONST) return SL_OK;
-        if (M.m.grid.num_points[d - 1] % 64 != 0 || lo % 64 != 0 || hh.dout > SL_D) return SL_OK;
+        if (hh.dout > SL_D) return SL_OK;
     }
     const int ncb = (n_actions * hh.dout + 15) / 16;
     const int ncb_t = policy_mode ? 0 : (ncb <= 1 ? 1 : (ncb <= 3 ? 3 : 6));

@@ -135,6 +135,10 @@ def test_value_iteration(sl, name, kw, nv):
     ("pendulum", dict(n_gp=70), [12, 64], 9),
     ("pendulum", dict(n_gp=70), [5, 128], 2),       # at most two distinct actions per row
     ("cartpole", dict(n_gp=90), [3, 4, 3, 64], 16),
+    # rows that are not whole wavefronts: ragged last segment, rows straddling the wavefronts
+    ("pendulum", dict(n_gp=70), [9, 65], 5),
+    ("pendulum", dict(n_gp=70), [6, 101], 3),
+    ("cartpole", dict(n_gp=90), [3, 3, 2, 70], 9),
 ])
 def test_discrete_policy_optimization(sl, name, kw, nv, na):
     case = cases.make_case(name, num_points=nv, **kw)
