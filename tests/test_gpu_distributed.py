@@ -81,10 +81,10 @@ def _worker(rank, world, port, results, backend="gloo"):
                 or not np.array_equal(lyap._refinement, olyap._refinement)):
             failures.append(("adaptive", shrink))
     # PolicyIteration across ranks: each rank sweeps its shard of the vertices (matrix-core
-    # kernels: the last axis is a whole number of wavefronts), the new table is all-gathered
+    # kernels; the shard boundary cuts a row of the last axis), the new table is all-gathered
     import test_gpu_rl
-    case = cases.make_case("pendulum", num_points=[12, 64], n_gp=70)
-    rl, orl, vf, ovf = test_gpu_rl._rl_pair(sl, case, [12, 64])
+    case = cases.make_case("pendulum", num_points=[11, 65], n_gp=70)
+    rl, orl, vf, ovf = test_gpu_rl._rl_pair(sl, case, [11, 65])
     assert rl._world == world
     actions = np.linspace(-1, 1, 9)[:, None]
     grid, ogrid = vf.discretization, ovf.discretization
