@@ -224,63 +224,70 @@ typedef double sl_bd4 __attribute__((ext_vector_type(4)));
 #define SL_BM_WAVES 8
 #define SL_BM_T 4                         // cell tiles per wavefront
 // cells per epilogue step of a wavefront (bounded by the LDS the staged means need)
-#define SL_BM_SUB_OF(NCB) ((NCB) > 3 ? 16 : 32)
+#define SL_BM_SUB_OF(COLBLOCKS) ((COLBLOCKS) > 3 ? 16 : 32)
+#define SL_BM_HEADS 4                     // GP heads (FunctionStack members) on the matrix-core path
 
 struct SlBellmanPack {
-    int32_t ncb, rowlen;                  // column blocks, padded (action, output) columns
-    int64_t toff[SL_D];                   // offset (doubles) of axis k's table after the B pack
-    int64_t tab0;                         // start of the tables in the pack buffer
+    int32_t ncb, rowlen, nheads, reserved; // column blocks per head, padded columns of all heads
+    int64_t boff[SL_BM_HEADS];            // start of head h's packed action factors
+    int64_t tab0[SL_BM_HEADS];            // start of head h's tables in the pack buffer
+    int64_t toff[SL_BM_HEADS][SL_D];      // offset (doubles) of axis k's table inside them
 };
 
 __global__ __launch_bounds__(256) void k_bellman_pack(const SlDevModel M, const SlGpDev gp,
                                                       SlBellmanPack pk, int n_actions,
                                                       const double* __restrict__ actions,
                                                       double* __restrict__ pack) {
-    const SlGpHeadDev& hd = gp.head[0];
     const int d = M.m.grid.d, m = M.m.policy.m;
-    const int nslab = hd.n_pad / 4, ncb = pk.ncb, n_pad = hd.n_pad;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-    const int64_t total = (int64_t)nslab * ncb * 64;
-    for (int64_t t = tid; t < total; t += nthreads) {
-        const int lane = (int)(t & 63);
-        const int cb = (int)((t >> 6) % ncb);
-        const int s = (int)((t >> 6) / ncb);
-        const int j = 4 * s + (lane >> 4), col = 16 * cb + (lane & 15);
-        const int a = col / hd.dout, dd = col - a * hd.dout;
-        double v = 0.0;
-        if (a < n_actions && j < hd.n) {
-            double z = 0.0;
-            for (int c = 0; c < m; ++c) {
-                const double dlt = hd.xs[(d + c) * n_pad + j] - actions[a * m + c] * hd.inv_ls[d + c];
-                z = fma(dlt, dlt, z);
-            }
-            v = hd.variance * sl_exp_nonpos(-0.5 * z) * hd.alpha[j * hd.dout + dd];
-        }
-        pack[t] = v;
-    }
-    int64_t stride = 1;                    // flat-index stride of axis k (last axis fastest)
-    for (int k = d - 1; k >= 0; --k) {
-        const int nk = M.m.grid.num_points[k];
-        double* tab = pack + pk.tab0 + pk.toff[k];
-        for (int64_t t = tid; t < (int64_t)nk * n_pad; t += nthreads) {
-            // axis d-1: [j][i] (16 consecutive cells read one line); other axes: [i][j]
-            const int i = (k == d - 1) ? (int)(t % nk) : (int)(t / n_pad);
-            const int j = (k == d - 1) ? (int)(t / nk) : (int)(t % n_pad);
-            double x[SL_P];
-            sl_index_to_state(M.m.grid, M.gf, d, (int64_t)i * stride, x);
+    for (int h = 0; h < pk.nheads; ++h) {
+        const SlGpHeadDev& hd = gp.head[h];
+        const int nslab = hd.n_pad / 4, ncb = pk.ncb, n_pad = hd.n_pad;
+        const int64_t total = (int64_t)nslab * ncb * 64;
+        double* bdst = pack + pk.boff[h];
+        for (int64_t t = tid; t < total; t += nthreads) {
+            const int lane = (int)(t & 63);
+            const int cb = (int)((t >> 6) % ncb);
+            const int s = (int)((t >> 6) / ncb);
+            const int j = 4 * s + (lane >> 4), col = 16 * cb + (lane & 15);
+            const int a = col / hd.dout, dd = col - a * hd.dout;
             double v = 0.0;
-            if (j < hd.n) {
-                const double dlt = hd.xs[k * n_pad + j] - x[k] * hd.inv_ls[k];
-                v = sl_exp_nonpos(-0.5 * (dlt * dlt));
+            if (a < n_actions && j < hd.n) {
+                double z = 0.0;
+                for (int c = 0; c < m; ++c) {
+                    const double dlt = hd.xs[(d + c) * n_pad + j] - actions[a * m + c] * hd.inv_ls[d + c];
+                    z = fma(dlt, dlt, z);
+                }
+                v = hd.variance * sl_exp_nonpos(-0.5 * z) * hd.alpha[j * hd.dout + dd];
             }
-            tab[t] = v;
+            bdst[t] = v;
         }
-        stride *= nk;
+        int64_t stride = 1;                // flat-index stride of axis k (last axis fastest)
+        for (int k = d - 1; k >= 0; --k) {
+            const int nk = M.m.grid.num_points[k];
+            double* tab = pack + pk.tab0[h] + pk.toff[h][k];
+            for (int64_t t = tid; t < (int64_t)nk * n_pad; t += nthreads) {
+                // axis d-1: [j][i] (16 consecutive cells read one line); other axes: [i][j]
+                const int i = (k == d - 1) ? (int)(t % nk) : (int)(t / n_pad);
+                const int j = (k == d - 1) ? (int)(t / nk) : (int)(t % n_pad);
+                double x[SL_P];
+                sl_index_to_state(M.m.grid, M.gf, d, (int64_t)i * stride, x);
+                double v = 0.0;
+                if (j < hd.n) {
+                    const double dlt = hd.xs[k * n_pad + j] - x[k] * hd.inv_ls[k];
+                    v = sl_exp_nonpos(-0.5 * (dlt * dlt));
+                }
+                tab[t] = v;
+            }
+            stride *= nk;
+        }
     }
 }
 
-template <int DT, int NCB>
+// NH GP heads (one shared-input head with D outputs, or the members of a FunctionStack with one
+// output each), NCB column blocks of (action, output) pairs per head.
+template <int DT, int NCB, int NH>
 __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
     const SlDevModel M, const SlGpDev gp, SlAux aux, SlBellmanPack pk, int64_t lo, int64_t hi,
     int n_actions, const double* __restrict__ actions, const double* __restrict__ pack,
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
     double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red_max[SL_BM_WAVES], red_sum[SL_BM_WAVES];
-    constexpr int SL_BM_SUB = SL_BM_SUB_OF(NCB);
+    constexpr int SL_BM_SUB = SL_BM_SUB_OF(NCB * NH);
     const SlDims nd = sl_dims<DT, 1>(M);
     const int d = nd.d, p = nd.p, A = n_actions;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -298,15 +305,18 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
     double* my_mean = smem + (size_t)wave * SL_BM_SUB * rowlen;                 // [32 cells][rowlen]
     double* my_q = smem + (size_t)SL_BM_WAVES * SL_BM_SUB * rowlen + wave * SL_BM_SUB * SL_MAX_ACTIONS;
     const SlTri& vt = aux.tri[0];
-    const SlGpHeadDev& hd = gp.head[0];
-    const int n_pad = hd.n_pad, nslab = n_pad / 4, dout = hd.dout;
     const int n_last = M.m.grid.num_points[d - 1];
-    const double* tabs = pack + pk.tab0;
     double lmax = 0.0, lsum = 0.0;
     const int64_t wg_cells = 16 * SL_BM_T * SL_BM_WAVES;
     const int64_t ntiles = (hi - lo + wg_cells - 1) / wg_cells;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t wbase = lo + tile * wg_cells + 16 * SL_BM_T * wave;   // first cell of the wavefront
+        sl_bd4 acc[NH][SL_BM_T][NCB];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+        const SlGpHeadDev& hd = gp.head[h];
+        const int n_pad = hd.n_pad, nslab = n_pad / 4;
+        const double* tabs = pack + pk.tab0[h];
         // byte offsets into the tables of this lane's cell in each of the SL_BM_T tiles (element
         // 4s + lk of slab s): 32-bit so that the loads use the scalar-base + vector-offset form
         uint32_t off[SL_BM_T][SL_D];
@@ -318,18 +328,17 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
             sl_unravel(M.m.grid, M.gf, d, gidx, ijk);
 #pragma unroll
             for (int k = 0; k < SL_D; ++k) {
-                if (k < d - 1) off[t][k] = 8u * (uint32_t)(pk.toff[k] + ijk[k] * n_pad + lk);
-                else if (k == d - 1) off[t][k] = 8u * (uint32_t)(pk.toff[k] + (int64_t)lk * n_last + ijk[k]);
+                if (k < d - 1) off[t][k] = 8u * (uint32_t)(pk.toff[h][k] + ijk[k] * n_pad + lk);
+                else if (k == d - 1) off[t][k] = 8u * (uint32_t)(pk.toff[h][k] + (int64_t)lk * n_last + ijk[k]);
             }
         }
         const uint32_t step_last = 32u * (uint32_t)n_last;       // bytes per slab, axis d-1 ([j][i])
         const char* tabs_b = reinterpret_cast<const char*>(tabs);
-        sl_bd4 acc[SL_BM_T][NCB];
 #pragma unroll
         for (int t = 0; t < SL_BM_T; ++t)
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = (sl_bd4){0.0, 0.0, 0.0, 0.0};
-        const double* bp = pack + lane;
+            for (int cb = 0; cb < NCB; ++cb) acc[h][t][cb] = (sl_bd4){0.0, 0.0, 0.0, 0.0};
+        const double* bp = pack + pk.boff[h] + lane;
         double s_cur[SL_BM_T], b_cur[NCB];
 #pragma unroll
         for (int t = 0; t < SL_BM_T; ++t) {
@@ -370,8 +379,8 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
         do {                                                                                    \
             _Pragma("unroll") for (int t = 0; t < SL_BM_T; ++t)                                 \
                 _Pragma("unroll") for (int cb = 0; cb < NCB; ++cb)                              \
-                    acc[t][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(SSRC[t], BSRC[cb],        \
-                                                                      acc[t][cb], 0, 0, 0);     \
+                    acc[h][t][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(SSRC[t], BSRC[cb],     \
+                                                                         acc[h][t][cb], 0, 0, 0); \
         } while (0)
         for (int s = 0; s < nslab; s += 2) {
             double raw_a[SL_BM_T][SL_D], raw_b[SL_BM_T][SL_D];
@@ -385,6 +394,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
 #undef SL_BM_REQUEST
 #undef SL_BM_COMBINE
 #undef SL_BM_MFMAS
+        }
 #pragma unroll
         for (int sub = 0; sub < 16 * SL_BM_T / SL_BM_SUB; ++sub) {
             const int64_t sbase = wbase + SL_BM_SUB * sub;
@@ -393,12 +403,15 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
             for (int tt = 0; tt < SL_BM_SUB / 16; ++tt) {
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
-                    const sl_bd4 v = acc[sub * (SL_BM_SUB / 16) + tt][cb];
-                    double* dst = my_mean + (16 * tt + lk) * rowlen + 16 * cb + lc;
-                    dst[0] = v.x;
-                    dst[4 * rowlen] = v.y;
-                    dst[8 * rowlen] = v.z;
-                    dst[12 * rowlen] = v.w;
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        const sl_bd4 v = acc[h][sub * (SL_BM_SUB / 16) + tt][cb];
+                        double* dst = my_mean + (16 * tt + lk) * rowlen + 16 * (h * NCB + cb) + lc;
+                        dst[0] = v.x;
+                        dst[4 * rowlen] = v.y;
+                        dst[8 * rowlen] = v.z;
+                        dst[12 * rowlen] = v.w;
+                    }
                 }
             }
             __syncthreads();
@@ -416,8 +429,13 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
 #pragma unroll
                 for (int k = 0; k < SL_D; ++k) {
                     if (k < d) {
-                        const int dd = k - hd.col0;
-                        const double mu = (dd >= 0 && dd < dout) ? my_mean[cell * rowlen + a * dout + dd] : 0.0;
+                        double mu = 0.0;
+#pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            const int dd = k - gp.head[h].col0, dout = gp.head[h].dout;
+                            if (dd >= 0 && dd < dout)
+                                mu = my_mean[cell * rowlen + 16 * NCB * h + a * dout + dd];
+                        }
                         nxt[k] = mu + prior[k];
                     }
                 }
@@ -489,7 +507,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
     const SlGpHeadDev& hd = gp.head[0];
     const int n_pad = hd.n_pad, nslab = n_pad / 4, dout = hd.dout;
     const int n_last = M.m.grid.num_points[d - 1];
-    const double* tabs = pack + pk.tab0;
+    const double* tabs = pack + pk.tab0[0];
     double* p_l = smem + (size_t)wave * (n_pad + 64 * 16 + SL_BP_MAXG);   // [n_pad]
     double* mean_l = p_l + n_pad;                                          // [64 cells][16 columns]
     double* dist_l = mean_l + 64 * 16;                                     // distinct actions of the row
@@ -538,7 +556,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
         sl_unravel(M.m.grid, M.gf, d, wbase, ijk);
         const double* trow[SL_D];
 #pragma unroll
-        for (int k = 0; k < SL_D; ++k) if (k < d - 1) trow[k] = tabs + pk.toff[k] + ijk[k] * n_pad;
+        for (int k = 0; k < SL_D; ++k) if (k < d - 1) trow[k] = tabs + pk.toff[0][k] + ijk[k] * n_pad;
         double mean[SL_D];
 #pragma unroll
         for (int k = 0; k < SL_D; ++k) mean[k] = 0.0;
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const double* ap = tabs + pk.toff[d - 1] + (int64_t)lk * n_last;
+            const double* ap = tabs + pk.toff[0][d - 1] + (int64_t)lk * n_last;
             int acol[4];                                     // last-axis index of this lane per tile
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -613,7 +631,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
         } else if (valid) {
             // smooth policy: one exponential per (cell, training point)
             const double ug = u[0] * inv_ls_u;
-            const double* tl = tabs + pk.toff[d - 1] + (seg0 + lane < n_last ? seg0 + lane : n_last - 1);
+            const double* tl = tabs + pk.toff[0][d - 1] + (seg0 + lane < n_last ? seg0 + lane : n_last - 1);
             for (int j = 0; j < hd.n; ++j) {
                 double v = hd.variance * tl[(size_t)j * n_last];
 #pragma unroll
@@ -675,7 +693,8 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
     const SlDevModel& M = ctx->h_model;
     const char* env = getenv("SL_BELLMAN_MFMA");
     if (env && env[0] == '0') return SL_OK;
-    if (M.m.policy.m != 1 || ctx->h_gp.nheads != 1) return SL_OK;
+    const int nheads = ctx->h_gp.nheads;
+    if (M.m.policy.m != 1 || nheads < 1 || nheads > SL_BM_HEADS) return SL_OK;
     const int variant = sl_dim_variant_of(M);
     if (variant != 4 && variant != 2) return SL_OK;        // compiled for 2 and 4 state dimensions
     const SlGpHeadHost& hh = ctx->gp_heads[0];
@@ -684,28 +703,44 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
     memset(&pk, 0, sizeof(pk));
     const bool policy_mode = n_actions == 0;
     if (policy_mode) {
-        // worthwhile for piecewise-constant policies
+        // worthwhile for piecewise-constant policies; one shared-input head
         const int pkind = M.m.policy.kind;
         if (pkind != SL_POLICY_TRI && pkind != SL_POLICY_TABLE && pkind != SL_POLICY_CONST) return SL_OK;
-        if (hh.dout > SL_D) return SL_OK;
+        if (hh.dout > SL_D || nheads != 1) return SL_OK;
     }
-    const int ncb = (n_actions * hh.dout + 15) / 16;
-    const int ncb_t = policy_mode ? 0 : (ncb <= 1 ? 1 : (ncb <= 3 ? 3 : 6));
+    // one head with D outputs (1, 3 or 6 column blocks), or a FunctionStack of 2 (d = 2) / 4 (d = 4)
+    // single-output heads with one column block each
+    int ncb = 0, n_pad_max = 0;
+    for (int h = 0; h < nheads; ++h) {
+        const int c = (n_actions * ctx->gp_heads[h].dout + 15) / 16;
+        ncb = c > ncb ? c : ncb;
+        n_pad_max = ctx->gp_heads[h].n_pad > n_pad_max ? ctx->gp_heads[h].n_pad : n_pad_max;
+    }
     if (ncb > 6) return SL_OK;
+    if (nheads > 1 && (ncb > 1 || nheads != d)) return SL_OK;
+    const int ncb_t = policy_mode ? 0 : (ncb <= 1 ? 1 : (ncb <= 3 ? 3 : 6));
     pk.ncb = ncb_t;
-    pk.rowlen = 16 * ncb_t;
-    pk.tab0 = (int64_t)(hh.n_pad / 4) * ncb_t * 64;
-    int64_t toff = 0;
-    for (int k = 0; k < d; ++k) {
-        pk.toff[k] = toff;
-        toff += (int64_t)M.m.grid.num_points[k] * hh.n_pad;
+    pk.nheads = nheads;
+    pk.rowlen = 16 * ncb_t * nheads;
+    int64_t cursor = 0;
+    for (int h = 0; h < nheads; ++h) {
+        const int n_pad = ctx->gp_heads[h].n_pad;
+        pk.boff[h] = cursor;
+        cursor += (int64_t)(n_pad / 4) * ncb_t * 64;
+        pk.tab0[h] = cursor;
+        int64_t toff = 0;
+        for (int k = 0; k < d; ++k) {
+            pk.toff[h][k] = toff;
+            toff += (int64_t)M.m.grid.num_points[k] * n_pad;
+        }
+        if (toff + 4 * (int64_t)n_pad * M.m.grid.num_points[d - 1] > 0x0fffffffll) return SL_OK;
+        cursor += toff;
     }
-    if (toff + 4 * (int64_t)hh.n_pad * M.m.grid.num_points[d - 1] > 0x7fffffffll) return SL_OK;
     const size_t lds = policy_mode
         ? sizeof(double) * (size_t)SL_BM_WAVES * (hh.n_pad + 64 * 16 + SL_BP_MAXG)
-        : sizeof(double) * (size_t)SL_BM_WAVES * SL_BM_SUB_OF(ncb_t) * (pk.rowlen + SL_MAX_ACTIONS);
+        : sizeof(double) * (size_t)SL_BM_WAVES * SL_BM_SUB_OF(ncb_t * nheads) * (pk.rowlen + SL_MAX_ACTIONS);
     if (lds > 158 * 1024) return SL_OK;
-    const size_t need = sizeof(double) * (size_t)(pk.tab0 + toff);
+    const size_t need = sizeof(double) * (size_t)cursor;
     if (need > ctx->scratch_bytes) {
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
         ctx->d_scratch = nullptr;
@@ -737,9 +772,9 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
         *done = 1;
         return SL_OK;
     }
-#define SL_BM_LAUNCH(D_, N_)                                                                      \
+#define SL_BM_LAUNCH(D_, N_, H_)                                                                  \
     do {                                                                                          \
-        auto kern = k_bellman_mfma<D_, N_>;                                                       \
+        auto kern = k_bellman_mfma<D_, N_, H_>;                                                   \
         SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                               (int)lds));                                         \
@@ -749,10 +784,13 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
     } while (0)
 #define SL_BM_DIMS(N_)                                  \
     do {                                                \
-        if (variant == 4) SL_BM_LAUNCH(4, N_);          \
-        else SL_BM_LAUNCH(2, N_);                       \
+        if (variant == 4) SL_BM_LAUNCH(4, N_, 1);       \
+        else SL_BM_LAUNCH(2, N_, 1);                    \
     } while (0)
-    if (ncb_t == 1) SL_BM_DIMS(1);
+    if (nheads > 1) {
+        if (variant == 4) SL_BM_LAUNCH(4, 1, 4);
+        else SL_BM_LAUNCH(2, 1, 2);
+    } else if (ncb_t == 1) SL_BM_DIMS(1);
     else if (ncb_t == 3) SL_BM_DIMS(3);
     else SL_BM_DIMS(6);
 #undef SL_BM_DIMS
@@ -805,9 +843,6 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
         if (is_gp)
             for (int h = 0; h < ctx->h_gp.nheads; ++h)
                 lds += sizeof(double) * (size_t)ctx->gp_heads[h].n_pad * amax;
-        if (lds > 150 * 1024)
-            return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_bellman_sweep: action-factor table needs %zu "
-                                                    "bytes of LDS", lds);
     }
     if (is_gp) {                                  // dense K_nm @ alpha contraction on the matrix cores
         int done = 0;
@@ -815,6 +850,9 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
         if (rc) return rc;
         if (done) return SL_OK;
     }
+    if (lds > 150 * 1024)
+        return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_bellman_sweep: action-factor table needs %zu "
+                                                "bytes of LDS", lds);
     int64_t blocks64 = (hi - lo + SL_BLOCK - 1) / SL_BLOCK;
     const int cap = ctx->num_cu * 4;
     const int blocks = (int)(blocks64 < cap ? blocks64 : cap);

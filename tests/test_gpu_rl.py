@@ -129,7 +129,9 @@ def test_value_iteration(sl, name, kw, nv):
     ("pendulum", dict(n_gp=70), [16, 32], 3),       # 1 column block, tiles aligned with the rows
     ("cartpole", dict(n_gp=90), 5, 9),              # 3 column blocks, ragged tiles
     ("cartpole", dict(n_gp=130), [3, 4, 4, 16], 16),  # 4 column blocks (of 6), n_pad > n
-    ("cartpole", dict(n_gp=60, stack=True), 4, 9),  # one head per output: VALU kernel
+    ("cartpole", dict(n_gp=60, stack=True), 4, 9),  # FunctionStack: one GEMM per head
+    ("pendulum", dict(n_gp=70, stack=True), [9, 65], 9),   # the reference's RL example shape
+    ("pendulum", dict(n_gp=50, stack=True), 12, 16),
     # last axis = whole wavefronts: the policy-evaluation sweep that follows runs on the matrix
     # cores (random value table => noisy greedy policy: several GEMM rounds and the scalar tail)
     ("pendulum", dict(n_gp=70), [12, 64], 9),
