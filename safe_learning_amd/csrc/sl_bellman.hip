@@ -228,7 +228,7 @@ typedef double sl_bd4 __attribute__((ext_vector_type(4)));
 #define SL_BM_HEADS 4                     // GP heads (FunctionStack members) on the matrix-core path
 
 struct SlBellmanPack {
-    int32_t ncb, rowlen, nheads, reserved; // column blocks per head, padded columns of all heads
+    int32_t ncb, rowlen, nheads, npad_max; // column blocks per head, padded columns of all heads
     int64_t boff[SL_BM_HEADS];            // start of head h's packed action factors
     int64_t tab0[SL_BM_HEADS];            // start of head h's tables in the pack buffer
     int64_t toff[SL_BM_HEADS][SL_D];      // offset (doubles) of axis k's table inside them
@@ -504,17 +504,11 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, lk = lane >> 4;
     const SlTri& vt = aux.tri[0];
-    const SlGpHeadDev& hd = gp.head[0];
-    const int n_pad = hd.n_pad, nslab = n_pad / 4, dout = hd.dout;
     const int n_last = M.m.grid.num_points[d - 1];
-    const double* tabs = pack + pk.tab0[0];
-    double* p_l = smem + (size_t)wave * (n_pad + 64 * 16 + SL_BP_MAXG);   // [n_pad]
-    double* mean_l = p_l + n_pad;                                          // [64 cells][16 columns]
+    const int npad_max = pk.npad_max;
+    double* p_l = smem + (size_t)wave * (npad_max + 64 * 16 + SL_BP_MAXG); // [n_pad] of the current head
+    double* mean_l = p_l + npad_max;                                       // [64 cells][16 columns]
     double* dist_l = mean_l + 64 * 16;                                     // distinct actions of the row
-    const double inv_ls_u = hd.inv_ls[d];
-    const double* __restrict__ xs_u = hd.xs + (size_t)d * n_pad;           // action inputs / l
-    const int G = 16 / dout;                                               // actions per GEMM
-    const int cg = lc / dout, cdd = lc - cg * dout;                        // this lane's B column
     double lmax = 0.0, lsum = 0.0;
     // work item = one segment of at most 64 consecutive cells of one row of the last grid axis
     // (the cells of a segment share the leading-axis indices); rows that straddle [lo, hi) and
@@ -551,12 +545,23 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
             ++ng;
         }
         const bool use_gemm = remaining == 0ull;
-        // leading-axis table rows of this wavefront's grid row
+        // leading-axis indices of this wavefront's grid row
         int64_t ijk[SL_D];
         sl_unravel(M.m.grid, M.gf, d, wbase, ijk);
+        double mean_state[SL_D];                         // posterior mean per state dimension
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) mean_state[k] = 0.0;
+        for (int h = 0; h < pk.nheads; ++h) {            // FunctionStack: one pass per head
+        const SlGpHeadDev& hd = gp.head[h];
+        const int n_pad = hd.n_pad, nslab = n_pad / 4, dout = hd.dout;
+        const double* tabs = pack + pk.tab0[h];
+        const double inv_ls_u = hd.inv_ls[d];
+        const double* __restrict__ xs_u = hd.xs + (size_t)d * n_pad;       // action inputs / l
+        const int G = 16 / dout;                                           // actions per GEMM
+        const int cg = lc / dout, cdd = lc - cg * dout;                    // this lane's B column
         const double* trow[SL_D];
 #pragma unroll
-        for (int k = 0; k < SL_D; ++k) if (k < d - 1) trow[k] = tabs + pk.toff[0][k] + ijk[k] * n_pad;
+        for (int k = 0; k < SL_D; ++k) if (k < d - 1) trow[k] = tabs + pk.toff[h][k] + ijk[k] * n_pad;
         double mean[SL_D];
 #pragma unroll
         for (int k = 0; k < SL_D; ++k) mean[k] = 0.0;
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const double* ap = tabs + pk.toff[0][d - 1] + (int64_t)lk * n_last;
+            const double* ap = tabs + pk.toff[h][d - 1] + (int64_t)lk * n_last;
             int acol[4];                                     // last-axis index of this lane per tile
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
         } else if (valid) {
             // smooth policy: one exponential per (cell, training point)
             const double ug = u[0] * inv_ls_u;
-            const double* tl = tabs + pk.toff[0][d - 1] + (seg0 + lane < n_last ? seg0 + lane : n_last - 1);
+            const double* tl = tabs + pk.toff[h][d - 1] + (seg0 + lane < n_last ? seg0 + lane : n_last - 1);
             for (int j = 0; j < hd.n; ++j) {
                 double v = hd.variance * tl[(size_t)j * n_last];
 #pragma unroll
@@ -643,20 +648,23 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
                     if (k < dout) mean[k] = fma(v, hd.alpha[(size_t)j * dout + k], mean[k]);
             }
         }
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) {
+            const int dd = k - hd.col0;
+#pragma unroll
+            for (int q = 0; q < SL_D; ++q)
+                if (q == dd && q < dout) mean_state[k] = mean[q];
+        }
+        // (p_l and mean_l are rewritten by the next head only after this wavefront's reads)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        }
         if (valid) {
             double prior[SL_D], nxt[SL_D];
             sl_append_action(nd, u, x);
             sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
 #pragma unroll
-            for (int k = 0; k < SL_D; ++k) {
-                if (k < d) {
-                    const int dd = k - hd.col0;
-                    double mu = 0.0;
-#pragma unroll
-                    for (int q = 0; q < SL_D; ++q) mu = (q == dd) ? mean[q] : mu;
-                    nxt[k] = mu + prior[k];
-                }
-            }
+            for (int k = 0; k < SL_D; ++k) if (k < d) nxt[k] = mean_state[k] + prior[k];
             const double r = sl_quadratic(M.m.reward, p, x);
             double v = sl_tri_value_fast<DT>(vt, nxt);
             if (M.m.value.negate) v = v * -1.0;
@@ -706,7 +714,8 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
         // worthwhile for piecewise-constant policies; one shared-input head
         const int pkind = M.m.policy.kind;
         if (pkind != SL_POLICY_TRI && pkind != SL_POLICY_TABLE && pkind != SL_POLICY_CONST) return SL_OK;
-        if (hh.dout > SL_D || nheads != 1) return SL_OK;
+        for (int h = 0; h < nheads; ++h)
+            if (ctx->gp_heads[h].dout > SL_D) return SL_OK;
     }
     // one head with D outputs (1, 3 or 6 column blocks), or a FunctionStack of 2 (d = 2) / 4 (d = 4)
     // single-output heads with one column block each
@@ -717,10 +726,11 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
         n_pad_max = ctx->gp_heads[h].n_pad > n_pad_max ? ctx->gp_heads[h].n_pad : n_pad_max;
     }
     if (ncb > 6) return SL_OK;
-    if (nheads > 1 && (ncb > 1 || nheads != d)) return SL_OK;
+    if (!policy_mode && nheads > 1 && (ncb > 1 || nheads != d)) return SL_OK;
     const int ncb_t = policy_mode ? 0 : (ncb <= 1 ? 1 : (ncb <= 3 ? 3 : 6));
     pk.ncb = ncb_t;
     pk.nheads = nheads;
+    pk.npad_max = n_pad_max;
     pk.rowlen = 16 * ncb_t * nheads;
     int64_t cursor = 0;
     for (int h = 0; h < nheads; ++h) {
@@ -737,7 +747,7 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
         cursor += toff;
     }
     const size_t lds = policy_mode
-        ? sizeof(double) * (size_t)SL_BM_WAVES * (hh.n_pad + 64 * 16 + SL_BP_MAXG)
+        ? sizeof(double) * (size_t)SL_BM_WAVES * (n_pad_max + 64 * 16 + SL_BP_MAXG)
         : sizeof(double) * (size_t)SL_BM_WAVES * SL_BM_SUB_OF(ncb_t * nheads) * (pk.rowlen + SL_MAX_ACTIONS);
     if (lds > 158 * 1024) return SL_OK;
     const size_t need = sizeof(double) * (size_t)cursor;
