@@ -121,7 +121,7 @@ def _worker(rank, world, port, results, backend="gloo"):
 
 def test_two_ranks_one_gpu():
     port = _free_port()
-    results = mp.Manager().dict()
+    results = mp.get_context("spawn").Manager().dict()    # never fork a process that holds a HIP context
     mp.spawn(_worker, args=(2, port, results), nprocs=2, join=True)
     for rank in range(2):
         assert results[rank] == [], results[rank]
@@ -131,6 +131,6 @@ def test_rccl_collectives_world_one():
     """The same scenarios over the `nccl` backend (RCCL) with one rank: every reduction, the key
     all-gather and the mask gather are issued as RCCL calls on device tensors."""
     port = _free_port()
-    results = mp.Manager().dict()
+    results = mp.get_context("spawn").Manager().dict()    # never fork a process that holds a HIP context
     mp.spawn(_worker, args=(1, port, results, "nccl"), nprocs=1, join=True)
     assert results[0] == [], results[0]
