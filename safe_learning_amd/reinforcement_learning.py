@@ -77,8 +77,6 @@ class PolicyIteration(object):
                       lagrange_multiplier=1.):
         """``r(x,u) + gamma V(f(x,u))`` at every grid vertex (``:65-114``).  ``states`` must be the
         grid itself (``None`` or ``state_space``); ``actions`` may be one constant action row."""
-        if lyapunov is not None:
-            raise NotImplementedError('the Lyapunov penalty term (:107-112) is not accelerated')
         if states is not None and states is not self.state_space:
             if np.shape(states) != (self.discretization.nindex, self.discretization.ndim):
                 raise NotImplementedError('future_values is evaluated on the grid vertices')
@@ -88,7 +86,21 @@ class PolicyIteration(object):
         elif policy is None:
             policy = self.policy
         v_new, _, _, _ = self._sweep(policy, None)
-        return self._gather(v_new).cpu().numpy()[:, None]
+        updated = self._gather(v_new).cpu().numpy()[:, None]
+        if lyapunov is not None:
+            # Lyapunov decrease as a soft constraint (:107-112): the sweep above already holds
+            # r + gamma V(mean); the penalty needs the posterior (mean, error) of the same
+            # dynamics at the vertices, V_lyap and L_v - all through the point-evaluation kernels
+            from . import _evaluate
+            x = self.state_space
+            next_states = _evaluate.dynamics(self.dynamics, x, _evaluate.policy(policy, x))
+            if not isinstance(next_states, tuple):
+                raise TypeError('the Lyapunov penalty needs uncertain dynamics (mean, error): the '
+                                'reference reads the error bound of the GP (:97-108)')
+            decrease = lyapunov.v_decrease_bound(x, next_states)
+            constraint = decrease - lyapunov.threshold(x)
+            updated = updated - lagrange_multiplier * constraint
+        return updated
 
     def value_iteration(self):
         """One Jacobi sweep ``V <- r + gamma V(f)`` (``:135-140``); returns ``max |dV|``."""
