@@ -120,20 +120,31 @@ class PolicyIteration(object):
     def discrete_policy_optimization(self, action_space, constraint=None):
         """Greedy policy over a finite action set (``:213-279``); the first maximiser wins."""
         import torch
-        if constraint is not None:
-            raise NotImplementedError('constraint callbacks are not accelerated')
         action_space = np.atleast_2d(np.asarray(action_space, dtype=np.float64))
+        n_act = action_space.shape[0]
         _, argmax, q, _ = self._sweep(self.policy, action_space)
-        best = self._gather(argmax[:self._hi - self._lo].to(torch.int64))
+        sizes = [(self._bounds[r + 1] - self._bounds[r]) * n_act for r in range(self._world)]
+        flat = q.reshape(-1)[:(self._hi - self._lo) * n_act]
+        q_all = dist_utils.allgather_concat(flat, sizes).reshape(-1, n_act)
+        if constraint is None:
+            best = self._gather(argmax[:self._hi - self._lo].to(torch.int64))
+        else:
+            # actions whose safety slack is negative at a vertex are ruled out there (:272-275);
+            # the callback is the caller's Python, so this part runs on the host like the reference
+            n = self.discretization.nindex
+            unsafe = np.zeros((n, n_act), dtype=bool)
+            for i, action in enumerate(action_space):
+                slack = constraint(np.broadcast_to(action, (n, action_space.shape[1])))
+                unsafe[:, i] = np.asarray(slack).reshape(-1) < 0
+            q_all = torch.where(torch.from_numpy(unsafe).to(q_all.device),
+                                torch.full_like(q_all, -float('inf')), q_all)
+            best = torch.from_numpy(np.argmax(q_all.cpu().numpy(), axis=1)).to(q_all.device)
         table = torch.from_numpy(action_space).to(best.device)[best]
         if isinstance(self.policy, Triangulation):
             self.policy._adopt_device_table(table.contiguous())
         else:
             self.policy = Triangulation(self.discretization, table.cpu().numpy())
-        n_act = action_space.shape[0]
-        sizes = [(self._bounds[r + 1] - self._bounds[r]) * n_act for r in range(self._world)]
-        flat = q.reshape(-1)[:(self._hi - self._lo) * n_act]
-        return dist_utils.allgather_concat(flat, sizes).reshape(-1, n_act)
+        return q_all
 
     def optimize_value_function(self, **solver_options):
         """The cvxpy linear program of ``:142-211`` is outside the accelerated path."""

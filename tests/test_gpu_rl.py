@@ -198,3 +198,34 @@ def test_future_values_with_lyapunov_penalty(sl):
         assert_allclose(got[ok], ref[ok], rtol=1e-8, atol=1e-11)
         plain = rl.future_values(None, **kwargs)
         assert np.max(np.abs(plain - got)) > 1e-6          # the penalty is actually there
+
+
+def test_discrete_policy_optimization_with_constraint(sl):
+    """Safety constraint callback of discrete_policy_optimization (:272-275): actions with
+    negative slack are ruled out vertex by vertex."""
+    case = cases.make_case("pendulum", num_points=15, n_gp=70)
+    rl, orl, vf, ovf = _rl_pair(sl, case, 15)
+    actions = np.linspace(-1, 1, 7)[:, None]
+    grid, ogrid = vf.discretization, ovf.discretization
+    rl.policy = sl.Triangulation(grid, np.zeros((grid.nindex, 1)))
+    orl.policy = oracle.Triangulation(ogrid, np.zeros((ogrid.nindex, 1)))
+    x = orl.state_space
+
+    def constraint(action_array):                       # rules out pushing "outwards"
+        return -(action_array[:, 0] * x[:, 0]) + 0.05
+
+    q = rl.discrete_policy_optimization(actions, constraint=constraint).cpu().numpy()
+    oq, obest = orl.discrete_policy_optimization(actions, constraint=constraint)
+    assert np.isinf(oq).any() and not np.isinf(oq).all(axis=1).all()
+    assert_array_equal(np.isinf(q), np.isinf(oq))
+    ok_q = np.ones_like(oq, dtype=bool)
+    for a, action in enumerate(actions):
+        nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))[0]
+        ok_q[:, a] = ~ambiguous_points(ovf, nxt)
+    finite = np.isfinite(oq) & ok_q
+    assert_allclose(q[finite], oq[finite], rtol=1e-9, atol=1e-12)
+    best = rl.policy._host_parameters()[:, 0]
+    masked = np.where(np.isfinite(oq), oq, -np.inf)
+    top2 = np.sort(masked, axis=1)[:, -2:]
+    tie = ~np.isfinite(top2[:, 0]) | (np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1]))
+    assert not np.any((best != orl.policy.parameters[:, 0]) & ok_q.all(axis=1) & ~tie)
