@@ -75,11 +75,13 @@ class PolicyIteration(object):
 
     def future_values(self, states=None, policy=None, actions=None, lyapunov=None,
                       lagrange_multiplier=1.):
-        """``r(x,u) + gamma V(f(x,u))`` at every grid vertex (``:65-114``).  ``states`` must be the
-        grid itself (``None`` or ``state_space``); ``actions`` may be one constant action row."""
+        """``r(x,u) + gamma V(f(x,u))`` (``:65-114``): one sweep kernel when ``states`` is the grid
+        (``None`` or ``state_space``; ``actions`` then is one constant action row), otherwise the
+        point-evaluation kernels at the given states."""
         if states is not None and states is not self.state_space:
-            if np.shape(states) != (self.discretization.nindex, self.discretization.ndim):
-                raise NotImplementedError('future_values is evaluated on the grid vertices')
+            states = np.atleast_2d(np.asarray(states, dtype=np.float64))
+            if states.shape != self.state_space.shape or not np.array_equal(states, self.state_space):
+                return self._future_values_at(states, policy, actions, lyapunov, lagrange_multiplier)
         if actions is not None:
             policy = ConstantFunction(np.asarray(actions, dtype=np.float64).reshape(-1)[
                 :np.shape(actions)[-1]])
@@ -102,6 +104,26 @@ class PolicyIteration(object):
             updated = updated - lagrange_multiplier * constraint
         return updated
 
+    def _future_values_at(self, states, policy, actions, lyapunov, lagrange_multiplier):
+        """``future_values`` at arbitrary states (``:65-114``) composed from the point-evaluation
+        kernels: policy, dynamics (posterior mean), reward, value table."""
+        from . import _evaluate
+        if actions is not None:
+            u = np.array(np.broadcast_to(np.atleast_2d(np.asarray(actions, dtype=np.float64)),
+                                         (len(states), np.shape(actions)[-1])))
+        else:
+            u = _evaluate.policy(self.policy if policy is None else policy, states)
+        next_states = _evaluate.dynamics(self.dynamics, states, u)
+        mean = next_states[0] if isinstance(next_states, tuple) else next_states
+        rewards = _evaluate.value(self.reward_function, np.hstack((states, u)))
+        updated = rewards + self.gamma * _evaluate.value(self.value_function, mean)
+        if lyapunov is not None:
+            if not isinstance(next_states, tuple):
+                raise TypeError('the Lyapunov penalty needs uncertain dynamics (mean, error)')
+            constraint = lyapunov.v_decrease_bound(states, next_states) - lyapunov.threshold(states)
+            updated = updated - lagrange_multiplier * constraint
+        return updated
+
     def value_iteration(self):
         """One Jacobi sweep ``V <- r + gamma V(f)`` (``:135-140``); returns ``max |dV|``."""
         v_new, _, _, stats = self._sweep(self.policy, None)
@@ -112,7 +134,14 @@ class PolicyIteration(object):
         return self.last_residual
 
     def bellmann_error(self, states=None):
-        """``sum (future_values - V)^2`` over the grid (``:116-133``)."""
+        """``sum (future_values - V)^2`` (``:116-133``): over the grid in one sweep, or at the given
+        states through the point-evaluation kernels."""
+        if states is not None and states is not self.state_space:
+            states = np.atleast_2d(np.asarray(states, dtype=np.float64))
+            if states.shape != self.state_space.shape or not np.array_equal(states, self.state_space):
+                from . import _evaluate
+                target = self._future_values_at(states, None, None, None, 1.)
+                return float(np.sum(np.square(target - _evaluate.value(self.value_function, states))))
         _, _, _, stats = self._sweep(self.policy, None)
         dist_utils.allreduce_sum_(stats[1:])
         return float(stats[1])

@@ -229,3 +229,22 @@ def test_discrete_policy_optimization_with_constraint(sl):
     top2 = np.sort(masked, axis=1)[:, -2:]
     tie = ~np.isfinite(top2[:, 0]) | (np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1]))
     assert not np.any((best != orl.policy.parameters[:, 0]) & ok_q.all(axis=1) & ~tie)
+
+
+def test_future_values_at_arbitrary_states(sl):
+    """future_values / bellmann_error away from the grid vertices."""
+    case = cases.make_case("pendulum", num_points=15, n_gp=70)
+    rl, orl, vf, ovf = _rl_pair(sl, case, 15)
+    rng = np.random.default_rng(3)
+    lim = np.asarray(case["limits"], dtype=float)
+    x = rng.uniform(0.1, 0.9, (300, 2)) * (lim[:, 1] - lim[:, 0]) + lim[:, 0]
+    nxt = orl.dynamics(x, orl.policy(x))[0]
+    ok = ~ambiguous_points(ovf, nxt) & ~ambiguous_points(ovf, x)
+    assert ok.mean() > 0.5
+    assert_allclose(rl.future_values(x)[ok], orl.future_values(x)[ok], rtol=1e-9, atol=1e-12)
+    u = rng.uniform(-1, 1, (300, 1))
+    nxt = orl.dynamics(x, u)[0]
+    ok2 = ~ambiguous_points(ovf, nxt)
+    assert_allclose(rl.future_values(x, actions=u)[ok2], orl.future_values(x, actions=u)[ok2],
+                    rtol=1e-9, atol=1e-12)
+    assert_allclose(rl.bellmann_error(x[ok]), orl.bellmann_error(x[ok]), rtol=1e-8)
