@@ -219,6 +219,34 @@ class Lyapunov(object):
         """``lyapunov.py:290-303``."""
         return self.safe_set[self.discretization.state_to_index(state)]
 
+    def safety_constraint(self, policy, include_initial=True):
+        """``bool[nindex]``: where the decrease condition holds under ``policy`` - a per-vertex
+        action array ``[nindex, m]`` or a policy spec (``lyapunov.py:378-406``).  The reference
+        method cannot run as written (it compares with the bound method ``self.threshold`` and
+        hands the discretization object to the dynamics); this is what its docstring describes,
+        evaluated by the same sweep kernel as ``update_safe_set``."""
+        import torch
+        own_policy = self.policy
+        self.policy = policy
+        try:
+            self._upload_model()
+            self._refresh_init_bits()
+            d_neg = torch.zeros_like(self._d_neg)
+            self._ctx.lyap_sweep(self._lo, self._hi, self._d_init, self._d_values, d_neg,
+                                 self._d_result)
+        finally:
+            self.policy = own_policy
+            self._upload_model()
+        count = self._hi - self._lo
+        d_bytes = torch.empty(max(-(-count // 8) * 8, 8), dtype=torch.uint8,
+                              device=self._ctx.torch_device)
+        self._ctx.bits_to_bytes(count, d_neg, d_bytes)
+        sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
+        mask = dist_utils.allgather_concat(d_bytes[:count], sizes).cpu().numpy().astype(bool)
+        if include_initial and self._initial_safe_set is not None:
+            mask[self._initial_safe_set] = True
+        return mask
+
     # ---- device helpers ------------------------------------------------------------------
     def _upload_mask(self, host_mask, d_bits):
         """bool[nindex] host mask -> this rank's bit words."""

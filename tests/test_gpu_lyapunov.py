@@ -538,3 +538,34 @@ def test_get_lyapunov_region(sl):
     ref = oracle.get_lyapunov_region(oracle.Triangulation(ogrid, vals), ogrid, (8, 16))
     assert ref.sum() > 20
     assert_array_equal(region, ref)
+
+
+def test_safety_constraint(sl):
+    """Lyapunov.safety_constraint(policy) (lyapunov.py:378-406, as documented there): the decrease
+    mask under another policy, given per vertex or as a spec; the object's own policy and safe
+    set are left alone."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case("pendulum", num_points=40, n_gp=120, tau_scale=0.0)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    lyap.update_safe_set()
+    safe_before, c_before = lyap.safe_set.copy(), lyap.c_max
+    x = olyap.discretization.index_to_state(np.arange(olyap.discretization.nindex))
+    init = np.zeros(len(x), dtype=bool)
+    init[cases.initial_safe_mask(case)] = True
+    # the own policy, handed over as a per-vertex table
+    own = olyap.policy(x)
+    ref = olyap.negative(x)
+    assert ref.any()
+    assert_array_equal(lyap.safety_constraint(own, include_initial=False), ref)
+    assert_array_equal(lyap.safety_constraint(own), ref | init)
+    # a different one: no control at all
+    zero = sl.ConstantFunction(np.zeros(1))
+    opolicy = olyap.policy
+    olyap.policy = lambda states: np.zeros((len(states), 1))
+    ref0 = olyap.negative(x)
+    olyap.policy = opolicy
+    assert_array_equal(lyap.safety_constraint(zero, include_initial=False), ref0)
+    assert not np.array_equal(ref0, ref)
+    lyap.update_safe_set()
+    assert_array_equal(lyap.safe_set, safe_before)
+    assert lyap.c_max == c_before
