@@ -101,7 +101,8 @@ class ModelBuilder(object):
             raise TypeError('unsupported dynamics spec %r' % (dynamics,))
 
     def _upload_gp(self, heads, beta, p):
-        signature = tuple((id(gp), gp._version, col0) for gp, _, col0 in heads) + (beta,)
+        # _version / _table_version are process-wide unique tokens (functions._TOKENS), never reused
+        signature = tuple((gp._version, col0) for gp, _, col0 in heads) + (beta,)
         if signature == self._gp_signature:
             return
         for h, (gp, _, col0) in enumerate(heads):
@@ -114,7 +115,7 @@ class ModelBuilder(object):
         self._gp_signature = signature
 
     def _upload_tri(self, slot, tri):
-        signature = (id(tri), tri._table_version, tri.project)
+        signature = (tri._table_version, tri.project)
         if signature != self._tri_signature[slot]:
             tri._upload(self.ctx, slot)
             self._tri_signature[slot] = signature
@@ -129,7 +130,8 @@ class ModelBuilder(object):
         elif isinstance(fun, LyapunovNetwork):
             vd.kind = _hip.V_NETWORK
             vd.negate = int(fun.negate)
-            signature = (id(fun), tuple(w.tobytes() for w in fun.weights))
+            signature = (fun.eps, tuple(fun.activations), tuple(fun.output_dims),
+                         tuple(w.tobytes() for w in fun.weights))
             if signature != self._net_signature:
                 fun._upload(self.ctx)
                 self._net_signature = signature

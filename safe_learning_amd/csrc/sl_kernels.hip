@@ -492,7 +492,8 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
                  double* d_dbg, const double* d_points) {
     int rc = sl_check_ready(ctx, "sl_lyap_sweep");
     if (rc) return rc;
-    if (lo < 0 || hi < lo || (!d_points && hi > ctx->h_model.gf.nindex) || (lo & 63))
+    if (lo < 0 || hi < lo || (!d_points && hi > ctx->h_model.gf.nindex) ||
+        ((lo & 63) && hi != lo))      // an empty shard may start anywhere (tail ranks of a small grid)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_lyap_sweep: bad range (lo must be a multiple of 64)");
     // with explicit points a TABLE policy is indexed by the point number (one action per point)
     if (!d_neg_bits || !d_result) return sl_fail(ctx, SL_ERR_INVALID, "sl_lyap_sweep: NULL output");
@@ -657,7 +658,7 @@ extern "C" int sl_lyap_finalize(sl_ctx* ctx, int64_t lo, int64_t hi, const doubl
                                 sl_key key_star, sl_key key_keep, uint64_t* d_safe_bits,
                                 sl_sweep_result* d_result) {
     if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_lyap_finalize: NULL context");
-    if (lo < 0 || hi < lo || (lo & 63) || !d_values || !d_safe_bits || !d_result)
+    if (lo < 0 || hi < lo || ((lo & 63) && hi != lo) || !d_values || !d_safe_bits || !d_result)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_lyap_finalize: bad argument");
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int blocks = (hi == lo) ? 0 : sl_grid_blocks(hi - lo);

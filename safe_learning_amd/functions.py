@@ -19,10 +19,16 @@ from itertools import product as _cartesian
 
 import numpy as np
 import scipy.linalg
-from scipy import signal, spatial
+from scipy import spatial
+
+import itertools
 
 from . import _hip
 from .configuration import config
+
+# Upload caches (``_model.ModelBuilder``) are keyed on these process-wide, never reused tokens:
+# ``id()`` values can be recycled by CPython once an object is collected.
+_TOKENS = itertools.count(1)
 
 __all__ = ['GridWorld', 'DimensionError', 'DeterministicFunction', 'UncertainFunction',
            'QuadraticFunction', 'LinearSystem', 'Saturation', 'AbsFunction', 'Norm1Function',
@@ -344,7 +350,7 @@ class GPRCached(object):
         self.alpha = scipy.linalg.solve_triangular(self.cholesky, resid, lower=True)
         self.cholesky_inverse = scipy.linalg.solve_triangular(self.cholesky, np.eye(n), lower=True)
         self.cholesky_inverse = np.tril(self.cholesky_inverse)
-        self._version = getattr(self, '_version', 0) + 1
+        self._version = next(_TOKENS)
 
     def append_data(self, x, y):
         """Add observations with a rank-one extension of the cached factors, O(n^2) per point
@@ -375,7 +381,7 @@ class GPRCached(object):
             self.cholesky, self.cholesky_inverse = chol, inv
             self.X = np.vstack((self.X, xi))
             self.Y = np.vstack((self.Y, yi))
-        self._version += 1
+        self._version = next(_TOKENS)
 
 
 class GaussianProcess(UncertainFunction):
@@ -457,7 +463,7 @@ class Triangulation(DeterministicFunction):
         self.name = name
         self._parameters = None
         self._device_table = None
-        self._table_version = 0
+        self._table_version = next(_TOKENS)
         if vertex_values is not None:
             self.parameters = vertex_values
         d = disc.ndim
@@ -484,31 +490,37 @@ class Triangulation(DeterministicFunction):
 
     @property
     def output_dim(self):
-        return None if self._parameters is None else self._parameters.shape[1]
+        if self._parameters is not None:
+            return self._parameters.shape[1]
+        if self._device_table is not None:
+            return int(self._device_table.shape[1])
+        return None
 
     @property
     def parameters(self):
-        return self._parameters
+        """``[nindex, k]`` vertex table on the host; after a sweep that left the table on the GPU
+        (value iteration, policy improvement) it is copied back on first access."""
+        return self._host_parameters()
 
     @parameters.setter
     def parameters(self, values):
         self._parameters = np.ascontiguousarray(
             np.asarray(values, dtype=config.np_dtype).reshape(self.nindex, -1))
         self._device_table = None
-        self._table_version += 1
+        self._table_version = next(_TOKENS)
 
     def _device(self, ctx):
         """Device copy of the vertex table (uploaded lazily)."""
         import torch
         if self._device_table is None or self._device_table.device != ctx.torch_device:
-            self._device_table = torch.from_numpy(self._parameters).to(ctx.torch_device)
+            self._device_table = torch.from_numpy(self._host_parameters()).to(ctx.torch_device)
         return self._device_table
 
     def _adopt_device_table(self, tensor):
         """Make a device tensor the truth (value iteration keeps V on the GPU)."""
-        self._device_table = tensor
+        self._device_table = tensor.reshape(self.nindex, -1)
         self._parameters = None
-        self._table_version += 1
+        self._table_version = next(_TOKENS)
 
     def _host_parameters(self):
         if self._parameters is None and self._device_table is not None:
@@ -548,17 +560,12 @@ class InvertedPendulum(DeterministicFunction):
         return self.mass * self.length ** 2
 
     def linearize(self):
-        """Discretised linearisation around the upright position (``:207-240``)."""
-        A = np.array([[0, 1], [self.gravity / self.length, -self.friction / self.inertia]],
-                     dtype=config.np_dtype)
-        B = np.array([[0], [1 / self.inertia]], dtype=config.np_dtype)
-        if self.normalization is not None:
-            Tx, Tu = map(np.diag, self.normalization)
-            Tx_inv, Tu_inv = map(np.diag, self.inv_norm)
-            A = np.linalg.multi_dot((Tx_inv, A, Tx))
-            B = np.linalg.multi_dot((Tx_inv, B, Tu))
-        sysd = signal.StateSpace(A, B, np.eye(2), np.zeros((2, 1))).to_discrete(self.dt)
-        return sysd.A, sysd.B
+        """``(A, B)`` of the discretised linearisation about the upright rest position, in
+        normalised coordinates when a normalisation is set (same result as
+        ``examples/utilities.py:207-240``)."""
+        from .benchmarks import _pendulum_linearize
+        norm = self.normalization if self.normalization is not None else [np.ones(2), np.ones(1)]
+        return _pendulum_linearize(self.mass, self.length, self.friction, self.dt, norm)
 
     def _write_dynamics(self, desc):
         desc.kind = _hip.DYN_PENDULUM
@@ -584,22 +591,13 @@ class CartPole(DeterministicFunction):
         self.normalization, self.inv_norm = _normalization(normalization)
 
     def linearize(self):
-        """Discretised (zero-order hold) linearisation (``:352-385``)."""
-        m, M, L, b, g = (self.pendulum_mass, self.cart_mass, self.length, self.rot_friction,
-                         self.gravity)
-        A = np.array([[0, 0, 1, 0],
-                      [0, 0, 0, 1],
-                      [0, g * m / M, 0, -b / (M * L)],
-                      [0, g * (m + M) / (L * M), 0, -b * (m + M) / (m * M * L ** 2)]],
-                     dtype=config.np_dtype)
-        B = np.array([0, 0, 1 / M, 1 / (M * L)]).reshape((-1, self.action_dim))
-        if self.normalization is not None:
-            Tx, Tu = map(np.diag, self.normalization)
-            Tx_inv, Tu_inv = map(np.diag, self.inv_norm)
-            A = np.linalg.multi_dot((Tx_inv, A, Tx))
-            B = np.linalg.multi_dot((Tx_inv, B, Tu))
-        Ad, Bd, _, _, _ = signal.cont2discrete((A, B, 0, 0), self.dt, method='zoh')
-        return Ad, Bd
+        """``(A, B)`` of the zero-order-hold discretisation of the linearised cart-pole, in
+        normalised coordinates when a normalisation is set (same result as
+        ``examples/utilities.py:352-385``)."""
+        from .benchmarks import _cartpole_linearize
+        norm = self.normalization if self.normalization is not None else [np.ones(4), np.ones(1)]
+        return _cartpole_linearize(self.pendulum_mass, self.cart_mass, self.length,
+                                   self.rot_friction, self.dt, norm)
 
     def _write_dynamics(self, desc):
         m, M, L, b, g = (self.pendulum_mass, self.cart_mass, self.length, self.rot_friction,

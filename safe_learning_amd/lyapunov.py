@@ -101,7 +101,10 @@ class Lyapunov(object):
         self._d_result = torch.zeros(_hip.RESULT_WORDS, dtype=torch.int64, device=dev)
         self._d_hist = torch.zeros(256, dtype=torch.int64, device=dev)
         self._values_host = None
+        self._d_values_full = None      # all shards, gathered by update_values when world > 1
+        self._d_safe_full = None        # all shards' mask words, gathered by update_safe_set
         self._init_version = None
+        self._init_object = None
 
     def _bare_init(self, discretization, fun):
         """Value-only instance used by ``smallest_boundary_value``."""
@@ -176,26 +179,31 @@ class Lyapunov(object):
 
     @property
     def values(self):
-        """V at every grid point, ``float64[nindex]`` (``lyapunov.py:305-322``); gathered from all
-        ranks and copied to the host on first access after ``update_values``."""
+        """V at every grid point, ``float64[nindex]`` (``lyapunov.py:305-322``).  A local read on
+        every rank: ``update_values`` (collective) has already gathered the shards on the device;
+        the copy to the host happens on first access."""
         if self._values_host is None:
-            sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
-            full = dist_utils.allgather_concat(self._d_values[:self._hi - self._lo], sizes)
+            full = self._d_values_full
+            if full is None:
+                full = self._d_values[:self._hi - self._lo]
             self._values_host = full.cpu().numpy()
         return self._values_host
 
+    def _word_sizes(self):
+        return [-(-(self._bounds[r + 1] - self._bounds[r]) // 64) for r in range(self._world)]
+
     @property
     def safe_set(self):
-        """``bool[nindex]`` mask, the same array object across calls (``lyapunov.py:187, 598-606``)."""
+        """``bool[nindex]`` mask, the same array object across calls (``lyapunov.py:187, 598-606``).
+        A local read on every rank (``update_safe_set`` gathers the shards' mask words)."""
         if not self._safe_host_valid:
             import torch
-            count = self._hi - self._lo
-            d_bytes = torch.empty(max(-(-count // 8) * 8, 8), dtype=torch.uint8,
+            n = self.discretization.nindex
+            words = self._d_safe_full if self._d_safe_full is not None else self._d_safe
+            d_bytes = torch.empty(max(-(-n // 8) * 8, 8), dtype=torch.uint8,
                                   device=self._ctx.torch_device)
-            self._ctx.bits_to_bytes(count, self._d_safe, d_bytes)
-            sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
-            full = dist_utils.allgather_concat(d_bytes[:count], sizes)
-            self._safe_host[:] = full.cpu().numpy().astype(bool)
+            self._ctx.bits_to_bytes(n, words, d_bytes)
+            self._safe_host[:] = d_bytes[:n].cpu().numpy().astype(bool)
             self._safe_host_valid = True
             # the host array may now be edited by the caller: it becomes the truth again
             self._safe_dev_valid = False
@@ -267,8 +275,9 @@ class Lyapunov(object):
             # large masks are identified by object identity (re-assign ``initial_safe_set`` after
             # editing one in place); small ones also by content
             checksum = int(np.count_nonzero(arr)) if arr.size <= (1 << 20) else -1
-            version = (id(init), arr.shape, arr.dtype.str, checksum)
-        if version == self._init_version:
+            version = (arr.shape, arr.dtype.str, checksum)
+        # the cached object is held strongly and compared by identity: an id() could be recycled
+        if version == self._init_version and init is self._init_object:
             return
         if init is None:
             self._d_init.zero_()
@@ -281,6 +290,7 @@ class Lyapunov(object):
                 mask[init] = True
             self._upload_mask(mask, self._d_init)
         self._init_version = version
+        self._init_object = init
 
     def _read_result(self):
         return [int(v) for v in self._d_result.cpu().numpy().view(np.int64)]
@@ -291,6 +301,10 @@ class Lyapunov(object):
         self._upload_model()
         self._ctx.values(self._lo, self._hi, self._d_values)
         self._values_host = None
+        if self._world > 1:
+            sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
+            self._d_values_full = dist_utils.allgather_concat(
+                self._d_values[:self._hi - self._lo], sizes)
 
     def update_safe_set(self, can_shrink=True, max_refinement=1, safety_factor=1.,
                         parallel_iterations=1):
@@ -309,6 +323,11 @@ class Lyapunov(object):
                                  can_shrink, self._ctx.torch_device)
         self._safe_host_valid = False
         self._safe_dev_valid = True
+        if self._world > 1:
+            # shards start at multiples of 64 cells, so their mask words concatenate (4 MB per
+            # rank at 128^4 over 8 GPUs); afterwards ``safe_set`` is a local read on every rank
+            sizes = self._word_sizes()
+            self._d_safe_full = dist_utils.allgather_concat(self._d_safe[:sizes[self._rank]], sizes)
 
 
     def _update_safe_set_adaptive(self, can_shrink, max_refinement, safety_factor):

@@ -83,8 +83,16 @@ class PolicyIteration(object):
             if states.shape != self.state_space.shape or not np.array_equal(states, self.state_space):
                 return self._future_values_at(states, policy, actions, lyapunov, lagrange_multiplier)
         if actions is not None:
-            policy = ConstantFunction(np.asarray(actions, dtype=np.float64).reshape(-1)[
-                :np.shape(actions)[-1]])
+            # the reference evaluates dynamics(states, actions) row by row (:89-104): one row is
+            # a constant policy, one row per vertex is a per-vertex action table
+            rows = np.atleast_2d(np.asarray(actions, dtype=np.float64))
+            if len(rows) == 1 or np.all(rows == rows[0]):
+                policy = ConstantFunction(rows[0])
+            elif len(rows) == self.discretization.nindex:
+                policy = np.ascontiguousarray(rows)
+            else:
+                raise ValueError('actions must be one row or one row per grid vertex (%d), got %d'
+                                 % (self.discretization.nindex, len(rows)))
         elif policy is None:
             policy = self.policy
         v_new, _, _, _ = self._sweep(policy, None)
@@ -95,7 +103,8 @@ class PolicyIteration(object):
             # dynamics at the vertices, V_lyap and L_v - all through the point-evaluation kernels
             from . import _evaluate
             x = self.state_space
-            next_states = _evaluate.dynamics(self.dynamics, x, _evaluate.policy(policy, x))
+            u = policy if isinstance(policy, np.ndarray) else _evaluate.policy(policy, x)
+            next_states = _evaluate.dynamics(self.dynamics, x, u)
             if not isinstance(next_states, tuple):
                 raise TypeError('the Lyapunov penalty needs uncertain dynamics (mean, error): the '
                                 'reference reads the error bound of the GP (:97-108)')

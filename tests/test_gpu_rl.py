@@ -248,3 +248,51 @@ def test_future_values_at_arbitrary_states(sl):
     assert_allclose(rl.future_values(x, actions=u)[ok2], orl.future_values(x, actions=u)[ok2],
                     rtol=1e-9, atol=1e-12)
     assert_allclose(rl.bellmann_error(x[ok]), orl.bellmann_error(x[ok]), rtol=1e-8)
+
+
+def test_policy_iteration_loop_keeps_tables_on_device(sl):
+    """The canonical loop discrete_policy_optimization() -> value_iteration() back to back without
+    reading a host table in between (both leave their result on the GPU): `output_dim` and
+    `parameters` of a Triangulation must follow the device table."""
+    case = cases.make_case("pendulum", num_points=15, n_gp=70)
+    rl, orl, vf, ovf = _rl_pair(sl, case, 15)
+    actions = np.linspace(-1, 1, 9)[:, None]
+    for _ in range(3):
+        rl.discrete_policy_optimization(actions)
+        assert rl.policy.output_dim == 1
+        res = rl.value_iteration()
+        assert np.isfinite(res)
+        assert vf.output_dim == 1
+    # the host views appear on demand and agree with the device tables
+    assert rl.policy.parameters.shape == (vf.nindex, 1)
+    assert vf.parameters.shape == (vf.nindex, 1)
+    assert np.isin(rl.policy.parameters, actions).all()
+    assert_array_equal(vf.parameters, vf._device_table.cpu().numpy())
+    # point evaluation of the (device-resident) greedy policy
+    x = orl.state_space[:7]
+    assert rl.policy(x).shape == (7, 1)
+
+
+def test_future_values_per_vertex_actions(sl):
+    """future_values(actions=[nindex, m]) pairs row i with vertex i
+    (reinforcement_learning.py:89-104); a single row is a constant action."""
+    case = cases.make_case("pendulum", num_points=13, dynamics="analytic")
+    rl, orl, vf, ovf = _rl_pair(sl, case, 13)
+    x = orl.state_space
+    rng = np.random.default_rng(8)
+    per_vertex = rng.uniform(-1, 1, (len(x), 1))
+    nxt = orl.dynamics(x, per_vertex)
+    ok = ~ambiguous_points(ovf, nxt)
+    got = rl.future_values(actions=per_vertex)
+    ref = orl.future_values(x, actions=per_vertex)
+    assert_allclose(got[ok], ref[ok], rtol=1e-9, atol=1e-12)
+    const = np.array([[0.3]])
+    nxt = orl.dynamics(x, np.broadcast_to(const, (len(x), 1)))
+    ok = ~ambiguous_points(ovf, nxt)
+    got = rl.future_values(actions=const)
+    ref = orl.future_values(x, actions=np.broadcast_to(const, (len(x), 1)))
+    assert_allclose(got[ok], ref[ok], rtol=1e-9, atol=1e-12)
+    assert_allclose(rl.future_values(actions=np.broadcast_to(const, (len(x), 1)))[ok], ref[ok],
+                    rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):
+        rl.future_values(actions=per_vertex[:5])

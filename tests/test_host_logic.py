@@ -1,0 +1,49 @@
+"""Host-side logic of the product that needs no GPU: spec helpers, sharding arithmetic."""
+
+import numpy as np
+from numpy.testing import assert_allclose
+
+import oracle
+
+
+def test_linearize_matches_the_oracle():
+    """InvertedPendulum / CartPole.linearize (examples/utilities.py:207-240, 352-385) with and
+    without normalisation."""
+    import safe_learning_amd as sl
+    norm2 = [(np.deg2rad(30), 4.4), (0.36,)]
+    for norm in (None, norm2):
+        a, b = sl.InvertedPendulum(0.15, 0.5, 0.1, 0.01, norm).linearize()
+        oa, ob = oracle.InvertedPendulum(0.15, 0.5, 0.1, 0.01, norm).linearize()
+        assert_allclose(a, oa, rtol=1e-13, atol=1e-15)
+        assert_allclose(b, ob, rtol=1e-13, atol=1e-15)
+    norm4 = [(0.5, np.deg2rad(30), 2., np.deg2rad(30)), (15.,)]
+    for norm in (None, norm4):
+        a, b = sl.CartPole(0.175, 1.732, 0.28, 0.01, 0.01, norm).linearize()
+        oa, ob = oracle.CartPole(0.175, 1.732, 0.28, 0.01, 0.01, norm).linearize()
+        assert_allclose(a, oa, rtol=1e-13, atol=1e-15)
+        assert_allclose(b, ob, rtol=1e-13, atol=1e-15)
+
+
+def test_shard_bounds_cover_the_grid():
+    from safe_learning_amd.distributed import shard_bounds
+    for n, world in [(625, 8), (1001, 3), (64, 4), (128 ** 4, 8), (7, 2), (4096, 8)]:
+        b = shard_bounds(n, world)
+        assert b[0] == 0 and b[-1] == n and len(b) == world + 1
+        assert all(x <= y for x, y in zip(b, b[1:]))
+        # every non-empty shard starts at a multiple of 64 cells (one mask word per 64 cells)
+        assert all(lo % 64 == 0 for lo, hi in zip(b, b[1:]) if hi > lo)
+
+
+def test_upload_cache_tokens_are_unique():
+    """Upload caches are keyed on process-wide tokens, not on id() (which CPython recycles)."""
+    import safe_learning_amd as sl
+    grid = sl.GridWorld([[-1, 1]], 5)
+    seen = set()
+    for _ in range(50):
+        tri = sl.Triangulation(grid, np.zeros(5))
+        assert tri._table_version not in seen
+        seen.add(tri._table_version)
+        tri.parameters = np.ones(5)
+        assert tri._table_version not in seen
+        seen.add(tri._table_version)
+        del tri
