@@ -48,36 +48,28 @@ def shard_range(n, rank=None, world=None, align=64):
     return bounds[rank], bounds[rank + 1]
 
 
-def _split_u64(value):
-    """uint64 -> two non-negative int64 halves (RCCL / gloo min and max work on signed ints)."""
-    return (value >> 32) & 0xffffffff, value & 0xffffffff
+def gather_words(tensor):
+    """Every rank's copy of a small packed int64 record as ONE host array ``[world, len]``.
 
-
-def allreduce_key(vbits, index, op, device):
-    """Lexicographic min / max of ``(vbits, index)`` keys across ranks.
-
-    One all-gather of three int64 words per rank (24 bytes): the keys are compared on the host,
-    which keeps the unsigned 64-bit ordering exact (no float round trip)."""
-    if not is_distributed():
-        return vbits, index
+    This is the only communication pattern of ``update_safe_set``'s reductions: the kernels leave
+    their per-shard result (failing key, last safe key, largest key, counters: 64 bytes) in
+    device memory, one all-gather moves the packed records device to device (RCCL over xGMI) and
+    one copy brings all of them to the host, where the lexicographic (unsigned 64-bit) comparisons
+    are exact.  No per-scalar round trips."""
     import torch
+    if not is_distributed():
+        return tensor.detach().cpu().numpy().reshape(1, -1)
     import torch.distributed as dist
-    hi, lo = _split_u64(vbits)
-    mine = torch.tensor([hi, lo, index], dtype=torch.int64, device=device)
-    gathered = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(gathered, mine)
-    keys = [((int(g[0]) << 32) | int(g[1]), int(g[2])) for g in gathered]
-    return min(keys) if op == 'min' else max(keys)
+    world = dist.get_world_size()
+    flat = tensor.detach().reshape(-1).contiguous()
+    out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(out, flat)
+    return out.cpu().numpy().reshape(world, -1)
 
 
-def allreduce_int(value, device):
-    """SUM of one Python int across ranks."""
-    if not is_distributed():
-        return value
-    import torch
-    t = torch.tensor([value], dtype=torch.int64, device=device)
-    allreduce_sum_(t)
-    return int(t[0])
+def u64(word):
+    """int64 bit pattern (as stored in the packed records) -> Python int in [0, 2^64)."""
+    return int(word) & 0xFFFFFFFFFFFFFFFF
 
 
 def allreduce_sum_(tensor):

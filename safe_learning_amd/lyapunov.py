@@ -292,9 +292,6 @@ class Lyapunov(object):
         self._init_version = version
         self._init_object = init
 
-    def _read_result(self):
-        return [int(v) for v in self._d_result.cpu().numpy().view(np.int64)]
-
     # ---- reference methods ---------------------------------------------------------------
     def update_values(self):
         """Recompute V on the grid (``lyapunov.py:305-322``)."""
@@ -319,8 +316,10 @@ class Lyapunov(object):
         if not can_shrink and not self._safe_dev_valid:          # lyapunov.py:507-510
             self._upload_mask(self._safe_host, self._d_safe)
         engine = _HipShardEngine(self)
+        stats = {}
         self.c_max = prefix_rule(engine, self.discretization.nindex, int(config.gp_batch_size),
-                                 can_shrink, self._ctx.torch_device)
+                                 can_shrink, self._ctx.torch_device, stats)
+        self.safe_count = stats['safe']       # cells in the safe set (all ranks), no mask copy
         self._safe_host_valid = False
         self._safe_dev_valid = True
         if self._world > 1:
@@ -416,14 +415,18 @@ class Lyapunov(object):
 
 
 class _HipShardEngine(object):
-    """This rank's shard of the grid as the prefix rule sees it (all work in HIP kernels)."""
+    """This rank's shard of the grid as the prefix rule sees it (all work in HIP kernels).
+
+    ``sweep`` / ``finalize`` return the kernels' packed result record (``sl_sweep_result``, eight
+    int64 words) as a DEVICE tensor; ``prefix_rule`` gathers the records of all ranks at once."""
 
     def __init__(self, lyap):
         self.lyap = lyap
         self.prior = None
 
     def sweep(self, can_shrink):
-        """Decrease check of every cell; returns the local lexmin failing ``(vbits, index)``."""
+        """Decrease check of every cell; words R_FAIL_V / R_FAIL_I hold the local lexmin failing
+        ``(vbits, index)``."""
         ly = self.lyap
         self.prior = ly._d_init if can_shrink else ly._d_safe.clone()     # lyapunov.py:500-510
         events = getattr(ly, 'sweep_events', None)
@@ -435,19 +438,16 @@ class _HipShardEngine(object):
         if events is not None:
             stop.record()
             events.append((start, stop))
-        res = ly._read_result()
-        return res[_hip.R_FAIL_V] & _U64_MAX, res[_hip.R_FAIL_I]
+        return ly._d_result
 
     def finalize(self, star, keep, use_prior):
-        """``safe = init | key < star | (prior & key >= keep)``; returns local statistics."""
+        """``safe = init | key < star | (prior & key >= keep)``; words R_BELOW, R_LAST_*, R_MAX_*
+        hold the local statistics."""
         ly = self.lyap
         ly._ctx.lyap_finalize(ly._lo, ly._hi, ly._d_values, ly._d_init,
                               self.prior if use_prior else None, star, keep, ly._d_safe,
                               ly._d_result)
-        res = ly._read_result()
-        return {'below': res[_hip.R_BELOW],
-                'last_safe': (res[_hip.R_LAST_V] & _U64_MAX, res[_hip.R_LAST_I]),
-                'max_key': (res[_hip.R_MAX_V] & _U64_MAX, res[_hip.R_MAX_I])}
+        return ly._d_result
 
     def select_hist(self, which, byte, prefix, vbits_equal):
         """Local 256-bin histogram of one radix-select pass (int64[256])."""
@@ -479,19 +479,26 @@ def select_kth(engine, k, device):
     return vbits, index
 
 
-def prefix_rule(engine, n, batch, can_shrink, device):
+def _reduce_key(rows, col_v, col_i, largest):
+    keys = [(dist_utils.u64(r[col_v]), int(r[col_i])) for r in rows]
+    return max(keys) if largest else min(keys)
+
+
+def prefix_rule(engine, n, batch, can_shrink, device, stats=None):
     """The safe-set rule of ``lyapunov.py:512-606`` over sharded cells; returns ``c_max``.
 
     ``engine`` owns one contiguous shard (the HIP engine in production, a NumPy stand-in in the
-    CPU tests of the multi-rank path).  Collectives: one 24-byte all-gather per key reduction,
-    one 8-byte SUM, and - only for ``can_shrink=False`` or the no-failure ``c_max`` quirk - sixteen
-    2 KiB SUM all-reduces of radix-select histograms.
+    CPU tests of the multi-rank path).  Communication: ONE all-gather of the packed 64-byte result
+    record after the sweep and ONE after the streaming pass (``distributed.gather_words``), each
+    followed by one copy to the host; only ``can_shrink=False`` or the no-failure ``c_max`` quirk
+    add sixteen 2 KiB SUM all-reduces of radix-select histograms.
     """
-    star = dist_utils.allreduce_key(*engine.sweep(can_shrink), op='min', device=device)
-    stats = engine.finalize(star, _KEY_NONE, use_prior=False)
-    below = dist_utils.allreduce_int(stats['below'], device)
-    last_safe = dist_utils.allreduce_key(*stats['last_safe'], op='max', device=device)
-    max_key = dist_utils.allreduce_key(*stats['max_key'], op='max', device=device)
+    rows = dist_utils.gather_words(engine.sweep(can_shrink))
+    star = _reduce_key(rows, _hip.R_FAIL_V, _hip.R_FAIL_I, largest=False)
+    rows = dist_utils.gather_words(engine.finalize(star, _KEY_NONE, use_prior=False))
+    below = int(sum(int(r[_hip.R_BELOW]) for r in rows))
+    last_safe = _reduce_key(rows, _hip.R_LAST_V, _hip.R_LAST_I, largest=True)
+    max_key = _reduce_key(rows, _hip.R_MAX_V, _hip.R_MAX_I, largest=True)
     failed = star != _KEY_NONE
 
     if failed and not can_shrink:
@@ -499,7 +506,12 @@ def prefix_rule(engine, n, batch, can_shrink, device):
         # (lyapunov.py:585-587 never touches later batches)
         end = (below // batch + 1) * batch
         keep = select_kth(engine, end, device) if end < n else _KEY_NONE
-        engine.finalize(star, keep, use_prior=True)
+        record = engine.finalize(star, keep, use_prior=True)
+        if stats is not None:
+            rows = dist_utils.gather_words(record)
+    if stats is not None:
+        stats['safe'] = int(sum(int(r[_hip.R_SAFE]) for r in rows))
+        stats['below'] = below
 
     # c_max = values[order[max_index]], max_index as in lyapunov.py:590
     if failed:

@@ -46,17 +46,25 @@ class NumpyShardEngine(object):
         k = order[-1] if largest else order[0]
         return int(vb[k]), int(idx[k])
 
+    @staticmethod
+    def _record(fail=KEY_NONE, last=(0, -1), largest=(0, -1), below=0):
+        """The kernels' packed result record (sl_sweep_result): eight int64 words."""
+        words = np.array([fail[0], 0, last[0], 0, largest[0], 0, 0, 0], dtype=np.uint64).view(np.int64)
+        words[1], words[3], words[5], words[6] = fail[1], last[1], largest[1], below
+        return torch.from_numpy(words.copy())
+
     def sweep(self, can_shrink):
         self.prior = self.init if can_shrink else self.prev
-        return self._extreme(~(self.negative | self.prior), largest=False)
+        return self._record(fail=self._extreme(~(self.negative | self.prior), largest=False))
 
     def finalize(self, star, keep, use_prior):
         below = _lex_less(self.vb, self.idx, star)
         self.safe = self.init | below
         if use_prior:
             self.safe |= self.prior & ~_lex_less(self.vb, self.idx, keep)
-        return {'below': int(below.sum()), 'last_safe': self._extreme(below, largest=True),
-                'max_key': self._extreme(np.ones_like(below), largest=True)}
+        return self._record(last=self._extreme(below, largest=True),
+                            largest=self._extreme(np.ones_like(below), largest=True),
+                            below=int(below.sum()))
 
     def select_hist(self, which, byte, prefix, vbits_equal):
         key = self.vb if which == 0 else self.idx.astype(np.uint64)

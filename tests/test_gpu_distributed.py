@@ -56,7 +56,8 @@ def _worker(rank, world, port, results, backend="gloo"):
         rng = np.random.default_rng(3)
         for step, shrink in enumerate((True, False, False)):
             if step == 1:
-                extra = rng.choice(lyap.discretization.nindex, 200, replace=False)
+                extra = rng.choice(lyap.discretization.nindex,
+                                   min(200, lyap.discretization.nindex // 4), replace=False)
                 lyap.safe_set[extra] = True
                 olyap.safe_set[extra] = True
                 lyap.tau = olyap.tau = case["tau"] * 3 if case["tau"] else 0.0

@@ -83,44 +83,115 @@ def _grid_points(grid, idx):
     return np.where(last, np.asarray(grid.limits)[:, 1], pts)
 
 
-def test_cartpole_64_gp_dynamics():
-    """64^4 cells with the 1024-point GP of the headline config: sampled parity within 1e-9
-    (required: 1e-5) and the level-set structure of the result."""
-    from safe_learning_amd.benchmarks import build_lyapunov
-    from test_gpu_lyapunov import _engine_records
-    case = cases.make_case("cartpole", num_points=64, n_gp=1024, tau_scale=0.0)
-    lyap = build_lyapunov(case)
-    n = lyap.discretization.nindex
-    values, neg, rec = _engine_records(lyap)
-    olyap = cases.oracle_lyapunov(case, compute_values=False)
-    rng = np.random.default_rng(1)
-    idx = np.unique(rng.integers(0, n, 6000))
-    ref = cases.oracle_cell_records(olyap, idx)
-    assert_allclose(rec[idx], ref, rtol=1e-9, atol=1e-12)
-    ref_neg = olyap.negative(olyap.discretization.index_to_state(idx))
-    margin = np.abs(ref[:, 0] - ref[:, 1]) / np.maximum(np.abs(ref[:, 0]), 1e-300)
-    differs = neg[idx] != ref_neg
-    assert not np.any(differs & (margin > 1e-9))
-    lyap.update_safe_set()
-    _level_set_properties(lyap, _neg_mask(lyap))
+def _subrange_records(lyap, lo, hi):
+    """Per-cell records and mask bits of the grid sweep itself over [lo, hi) (lo 64-aligned)."""
+    import torch
+    d = lyap.discretization.ndim
+    dev = lyap._ctx.torch_device
+    dbg = torch.zeros((hi - lo, 2 + 2 * d), dtype=torch.float64, device=dev)
+    bits = torch.zeros((hi - lo + 63) // 64, dtype=torch.int64, device=dev)
+    result = torch.zeros_like(lyap._d_result)
+    lyap._ctx.lyap_sweep(lo, hi, lyap._d_init[lo // 64:], lyap._d_values[lo:], bits, result, dbg)
+    neg = np.unpackbits(bits.cpu().numpy().view(np.uint8), bitorder="little")[:hi - lo]
+    return dbg.cpu().numpy(), neg.astype(bool)
 
 
-def test_cartpole_128_gp_dynamics():
-    """The headline workload itself (bench.py: 128^4 cells, 1024-point GP): one full
-    update_safe_set, mask parity on 5 000 random cells, level-set structure of the result."""
+def _point_records(lyap, idx):
+    """The same records through the explicit-point entry (sl_eval_points, SL_EVAL_DECREASE)."""
+    import torch
+    from safe_learning_amd import _hip
+    d = lyap.discretization.ndim
+    dev = lyap._ctx.torch_device
+    pts = torch.from_numpy(lyap.discretization.index_to_state(idx)).to(dev)
+    out = torch.zeros((len(idx), 2 + 2 * d), dtype=torch.float64, device=dev)
+    lyap._ctx.eval_points(_hip.EVAL_DECREASE, len(idx), pts, out)
+    return out.cpu().numpy()
+
+
+def _gp_full_size_checks(case, nsample, seed):
+    """Shared body of the 64^4 / 128^4 GP tests: one full update_safe_set, then
+      * the workload is non-degenerate (both mask classes, the level set grows by >= 100 cells),
+      * records AND mask bits of the sweep on sub-ranges around key*, the origin, the corners and
+        random places against the oracle (1e-9 relative; required 1e-5),
+      * records of scattered cells through the explicit-point entry,
+      * the level-set structure of the whole result."""
     from safe_learning_amd.benchmarks import build_lyapunov
-    case = cases.make_case("cartpole", num_points=128, n_gp=1024)
     lyap = build_lyapunov(case)
     n = lyap.discretization.nindex
+    d = case["d"]
     lyap.update_safe_set()
     neg = _neg_mask(lyap)
+    safe = lyap.safe_set
+    init = np.zeros(n, dtype=bool)
+    init[lyap._initial_safe_set] = True
+    assert neg.any() and (~neg).any(), "degenerate workload: one class only"
+    grown = int((safe & ~init).sum())
+    assert grown >= 100, "safe set grew by %d cells only" % grown
+    _level_set_properties(lyap, neg)
+
     olyap = cases.oracle_lyapunov(case, compute_values=False)
-    rng = np.random.default_rng(2)
-    idx = np.unique(np.concatenate([rng.integers(0, n, 5000), np.flatnonzero(lyap.safe_set)[:2000]]))
+    failing = ~(neg | init)
+    values = lyap.values
+    v_star = values[failing].min()
+    i_star = int(np.flatnonzero(failing & (values == v_star))[0])
+    rng = np.random.default_rng(seed)
+    starts = {(i_star // 64) * 64, (n // 2 // 64) * 64, 0, ((n - 1) // 64) * 64 - 1024}
+    starts |= {int(s) * 64 for s in rng.integers(0, n // 64 - 32, 6)}
+    first_passing = int(np.flatnonzero(neg)[0])
+    starts.add((first_passing // 64) * 64)
+    both = 0
+    for lo in sorted(starts):
+        lo = max(0, lo - 512)
+        hi = min(n, lo + 2048)
+        rec, bits = _subrange_records(lyap, lo, hi)
+        idx = np.arange(lo, hi)
+        ref = cases.oracle_cell_records(olyap, idx)
+        assert_allclose(rec, ref, rtol=1e-9, atol=1e-12)
+        ref_neg = ref[:, 0] < ref[:, 1]
+        margin = np.abs(ref[:, 0] - ref[:, 1]) / np.maximum(np.abs(ref[:, 0]), 1e-300)
+        differs = bits != ref_neg
+        assert not np.any(differs & (margin > 1e-9)), "mask differs away from the threshold"
+        assert_array_equal(bits, neg[lo:hi])          # sub-range sweep == whole-grid sweep
+        both += int(ref_neg.any() and (~ref_neg).any())
+    assert both >= 2, "the compared sub-ranges must contain passing and failing cells"
+
+    # scattered cells: half of them inside / at the rim of the level set
+    near = np.flatnonzero(safe)
+    idx = np.unique(np.concatenate([rng.integers(0, n, nsample),
+                                    rng.choice(near, min(len(near), nsample), replace=False),
+                                    [i_star]]))
     ref = cases.oracle_cell_records(olyap, idx)
-    ref_neg = olyap.negative(olyap.discretization.index_to_state(idx))
+    assert_allclose(_point_records(lyap, idx), ref, rtol=1e-9, atol=1e-12)
+    ref_neg = ref[:, 0] < ref[:, 1]
     margin = np.abs(ref[:, 0] - ref[:, 1]) / np.maximum(np.abs(ref[:, 0]), 1e-300)
     differs = neg[idx] != ref_neg
     assert not np.any(differs & (margin > 1e-9))
     assert differs.sum() <= 2
-    _level_set_properties(lyap, neg)
+    assert ref_neg.any() and (~ref_neg).any()
+    assert not ref_neg[np.searchsorted(idx, i_star)] and not init[i_star]   # key* really fails
+    return lyap, grown
+
+
+def test_cartpole_64_gp_dynamics():
+    """64^4 cells with the 1024-point GP of the headline config."""
+    from safe_learning_amd.benchmarks import headline_case
+    _gp_full_size_checks(headline_case(num_points=64), 3000, 1)
+
+
+def test_cartpole_128_gp_dynamics():
+    """The headline workload itself (bench.py: 128^4 cells, 1024-point GP)."""
+    from safe_learning_amd.benchmarks import headline_case
+    lyap, grown = _gp_full_size_checks(headline_case(), 2500, 2)
+    assert lyap.discretization.nindex == 128 ** 4
+    # idempotence; and a second update with can_shrink=False cannot lose cells
+    safe, c_max = lyap.safe_set.copy(), lyap.c_max
+    lyap.update_safe_set(can_shrink=False)
+    assert (lyap.safe_set | ~safe).all() and lyap.c_max >= c_max
+
+
+def test_cartpole_gp_function_stack_full_head_count():
+    """FunctionStack of four single-output 1024-point GPs (the notebooks' style, 4x the work per
+    cell) on 32^4 cells: non-degenerate, records and masks on sub-ranges vs the oracle."""
+    from safe_learning_amd.benchmarks import headline_case
+    case = headline_case(num_points=32, stack=True)
+    _gp_full_size_checks(case, 1500, 3)

@@ -182,27 +182,23 @@ def test_euler_dynamics(sl, name, kw):
 # ---------------------------------------------------------------------------------------------
 # GP dynamics (FP64 MFMA kernel), every kernel configuration
 # ---------------------------------------------------------------------------------------------
-GP_CASES = [
-    # (name, kwargs, SL_GP_CFG)                                  n_pad / panels exercised
-    ("pendulum", dict(num_points=40, n_gp=3, tau_scale=0.0), None),          # tiny n, cfg 0
-    ("pendulum", dict(num_points=64, n_gp=128, tau_scale=0.0), None),        # cfg 0, 2 panels
-    ("pendulum", dict(num_points=[33, 50], n_gp=200, tau_scale=0.02, noise_std=0.001), None),
-    ("cartpole", dict(num_points=8, n_gp=150, tau_scale=0.0), None),
-    ("cartpole", dict(num_points=6, n_gp=100, tau_scale=0.0, stack=True), None),   # FunctionStack
-    ("pendulum", dict(num_points=48, n_gp=600, tau_scale=0.0), "1"),        # cfg 1, 1 panel
-    ("pendulum", dict(num_points=48, n_gp=600, tau_scale=0.0), "2"),        # cfg 2, 2 panels
-    ("cartpole", dict(num_points=7, n_gp=1100, tau_scale=0.0), "1"),        # cfg 1, 2 panels
-    ("cartpole", dict(num_points=7, n_gp=520, tau_scale=0.0), "2"),         # cfg 2, 2 panels
-    # largest training set whose inputs fit LDS at p = 5 (alpha' stays in global memory) ...
-    ("cartpole", dict(num_points=5, n_gp=1500, tau_scale=0.0), None),
-    # ... and beyond it: the generation phase reads the training inputs from L2
-    ("cartpole", dict(num_points=4, n_gp=2000, tau_scale=0.0), None),
-    ("pendulum", dict(num_points=12, n_gp=2600, tau_scale=0.0), None),
-]
+from gp_cases import GP_CASES          # non-degenerate by construction, see tests/gp_cases.py
 
 
-@pytest.mark.parametrize("name,kw,cfg", GP_CASES)
-def test_gp_dynamics(sl, name, kw, cfg, monkeypatch):
+def _assert_non_degenerate(case, ref_neg, olyap, min_growth):
+    """The workload must exercise both outcomes of the decrease check and grow the level set -
+    otherwise mask parity is vacuous (an all-False mask compares equal to anything that writes
+    zeros)."""
+    init = np.zeros(len(ref_neg), dtype=bool)
+    init[cases.initial_safe_mask(case)] = True
+    assert ref_neg.any() and (~ref_neg).any(), "degenerate workload: one class only"
+    grown = int((olyap.safe_set & ~init).sum())
+    assert grown >= min_growth, "safe set grew by %d cells only" % grown
+    return grown
+
+
+@pytest.mark.parametrize("name,kw,cfg,min_growth", GP_CASES)
+def test_gp_dynamics(sl, name, kw, cfg, min_growth, monkeypatch):
     from safe_learning_amd.benchmarks import build_lyapunov
     if cfg is None:
         monkeypatch.delenv("SL_GP_CFG", raising=False)
@@ -221,6 +217,76 @@ def test_gp_dynamics(sl, name, kw, cfg, monkeypatch):
     assert_allclose(rec[:, :2], ref_rec[:, :2], rtol=1e-7, atol=1e-12)
     flips, _ = _check_masks(neg, ref_neg, rec, ref_rec)
     _compare_safe_sets(lyap, olyap, flips)
+    _assert_non_degenerate(case, ref_neg, olyap, min_growth)
+    if flips == 0:
+        # the level set the engine produced really is larger than the initial set
+        init = np.zeros(len(neg), dtype=bool)
+        init[cases.initial_safe_mask(case)] = True
+        assert int((lyap.safe_set & ~init).sum()) >= min_growth
+        assert neg[lyap.safe_set & ~init].all()
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("cartpole", dict(num_points=12, n_gp=300, tau_scale=0.0, stack=False)),
+    ("cartpole", dict(num_points=11, n_gp=120, tau_scale=0.0, stack=True)),
+    ("pendulum", dict(num_points=48, n_gp=300, tau_scale=0.01)),
+])
+def test_gp_can_shrink_false_and_batches(sl, name, kw, small_batches):
+    """The batch-granular quirks of lyapunov.py:507-510, 585-587 under GP dynamics: scattered
+    previously-safe cells, a stricter threshold, then a looser one."""
+    from gp_cases import INFORMED, TIGHT
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case(name, **dict(kw, **(TIGHT if name == "cartpole" else INFORMED)))
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    _, neg, rec = _engine_records(lyap)
+    ref_rec, ref_neg = _oracle_all(olyap)
+    flips, _ = _check_masks(neg, ref_neg, rec, ref_rec)
+    assert flips == 0
+    rng = np.random.default_rng(3)
+    sizes = []
+    for step in range(4):
+        if step == 1:
+            extra = rng.choice(lyap.discretization.nindex, 300, replace=False)
+            lyap.safe_set[extra] = True
+            olyap.safe_set[extra] = True
+        if step == 2:        # more conservative confidence scaling: nothing may be removed
+            lyap.tau = olyap.tau = case["tau"] + 2e-4
+        if step == 3:
+            lyap.tau = olyap.tau = case["tau"]
+        lyap.update_safe_set(can_shrink=(step == 0))
+        olyap.update_safe_set(can_shrink=(step == 0))
+        assert_array_equal(lyap.safe_set, olyap.safe_set)
+        assert lyap.c_max == olyap.c_max
+        sizes.append(int(olyap.safe_set.sum()))
+    init = int(np.count_nonzero(cases.initial_safe_mask(case)))
+    assert sizes[0] >= init + 100 and sizes[1] >= sizes[0] and sizes[2] >= sizes[1]
+
+
+def test_gp_ties_in_values(sl, small_batches):
+    """Equal-valued cells under GP dynamics.  A quadratic V on a symmetric grid is bit-identical
+    at x and -x while the GP (random training inputs) is not symmetric: here the smaller-index
+    twin of the first failing value passes the check and the larger-index one fails, so the
+    prefix is cut INSIDE a run of equal values - the (V, flat index) order decides the mask."""
+    from gp_cases import TIGHT
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case("cartpole", num_points=9, n_gp=150, tau_scale=0.0, seed=0, **TIGHT)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    _, neg, rec = _engine_records(lyap)
+    ref_rec, ref_neg = _oracle_all(olyap)
+    flips, _ = _check_masks(neg, ref_neg, rec, ref_rec)
+    assert flips == 0 and ref_neg.any() and (~ref_neg).any()
+    init = np.zeros(len(neg), dtype=bool)
+    init[cases.initial_safe_mask(case)] = True
+    ok = ref_neg | init
+    order = np.argsort(olyap.values, kind="stable")
+    v_star = olyap.values[order[np.argmin(ok[order])]]           # value of the first failing cell
+    run = olyap.values == v_star
+    for shrink in (True, False):
+        lyap.update_safe_set(can_shrink=shrink); olyap.update_safe_set(can_shrink=shrink)
+        assert_array_equal(lyap.safe_set, olyap.safe_set)
+        assert lyap.c_max == olyap.c_max
+    assert run.sum() >= 2 and olyap.safe_set[run].any() and not olyap.safe_set[run].all()
+    assert olyap.safe_set.sum() >= init.sum() + 100
 
 
 # ---------------------------------------------------------------------------------------------

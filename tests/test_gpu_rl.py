@@ -149,7 +149,7 @@ def test_discrete_policy_optimization(sl, name, kw, nv, na):
     grid, ogrid = vf.discretization, ovf.discretization
     rl.policy = sl.Triangulation(grid, np.zeros((grid.nindex, 1)))
     orl.policy = oracle.Triangulation(ogrid, np.zeros((ogrid.nindex, 1)))
-    q = rl.discrete_policy_optimization(actions)
+    q = rl.discrete_policy_optimization(actions, return_values=True)
     oq, obest = orl.discrete_policy_optimization(actions)
     x = orl.state_space
     ok_q = np.ones_like(oq, dtype=bool)
@@ -214,7 +214,8 @@ def test_discrete_policy_optimization_with_constraint(sl):
     def constraint(action_array):                       # rules out pushing "outwards"
         return -(action_array[:, 0] * x[:, 0]) + 0.05
 
-    q = rl.discrete_policy_optimization(actions, constraint=constraint).cpu().numpy()
+    q = rl.discrete_policy_optimization(actions, constraint=constraint,
+                                        return_values=True).cpu().numpy()
     oq, obest = orl.discrete_policy_optimization(actions, constraint=constraint)
     assert np.isinf(oq).any() and not np.isinf(oq).all(axis=1).all()
     assert_array_equal(np.isinf(q), np.isinf(oq))
@@ -296,3 +297,38 @@ def test_future_values_per_vertex_actions(sl):
                     rtol=1e-9, atol=1e-12)
     with pytest.raises(ValueError):
         rl.future_values(actions=per_vertex[:5])
+
+
+@pytest.mark.parametrize("name,kw,nv,na", [
+    ("pendulum", dict(n_gp=70), [12, 64], 9),
+    ("cartpole", dict(n_gp=90), 5, 9),
+    ("pendulum", dict(dynamics="analytic"), 15, 5),
+])
+def test_bellman_optimality_sweep(sl, name, kw, nv, na):
+    """value_iteration(action_space): V <- max_a [r + gamma V(f(x, a))] in one sweep, greedy policy
+    adopted - against the oracle's table of action values (reinforcement_learning.py:266-279)."""
+    case = cases.make_case(name, num_points=nv, **kw)
+    rl, orl, vf, ovf = _rl_pair(sl, case, nv)
+    actions = np.linspace(-1, 1, na)[:, None]
+    orl.policy = oracle.Triangulation(ovf.discretization, np.zeros((ovf.discretization.nindex, 1)))
+    old = ovf.parameters.copy()
+    oq, obest = orl.discrete_policy_optimization(actions)
+    x = orl.state_space
+    ok = np.ones(len(x), dtype=bool)
+    for action in actions:
+        nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))
+        ok &= ~ambiguous_points(ovf, nxt[0] if isinstance(nxt, tuple) else nxt)
+    assert ok.mean() > 0.3
+    res = rl.value_iteration(actions)
+    got = vf.parameters[:, 0]
+    assert_allclose(got[ok], oq.max(axis=1)[ok], rtol=1e-9, atol=1e-12)
+    top2 = np.sort(oq, axis=1)[:, -2:]
+    tie = np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1])
+    best = rl.policy.parameters[:, 0]
+    assert not np.any((best != actions[obest, 0]) & ok & ~tie)
+    if ok.all():
+        assert_allclose(res, np.max(np.abs(oq.max(axis=1) - old[:, 0])), rtol=1e-9)
+    # repeated sweeps contract: the residual decays
+    r1 = rl.value_iteration(actions)
+    r2 = rl.value_iteration(actions)
+    assert r2 < r1
