@@ -1,21 +1,29 @@
 """Headline benchmark: grid-cell Lyapunov checks per second (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--num-points 128] [--n-gp 1024]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C4] [--num-points P] [--n-gp G]
 
-Workload (BASELINE.json configs[3] / SURVEY 8d "C4"): cart-pole state grid 128^4 (2.68e8 cells),
-1024-point shared-kernel RBF GP over [x, u] (p = 5 inputs, 4 outputs), quadratic LQR Lyapunov
-function, saturated linear policy, per-dimension L_v = |2Px|.  A step is one full
+Default workload (BASELINE.json configs[3] / SURVEY 8d "C4"): cart-pole state grid 128^4 (2.68e8
+cells), 1024-point shared-kernel RBF GP over [x, u] (p = 5 inputs, 4 outputs), quadratic LQR
+Lyapunov function, saturated linear policy, per-dimension L_v = |2Px|.  A step is one full
 ``Lyapunov.update_safe_set()``: the fused GP posterior + decrease-check sweep over every cell, the
 lexicographic-min reduction of the failing cell, and the streaming pass that writes the safe mask.
 All inputs are resident in HBM (the model is uploaded before the timed region); data is synthetic.
 
-With N > 1 (torchrun, one rank per GPU) the grid is sharded by contiguous index ranges: total
-work is fixed, so scaling is "strong".
+``--config`` selects the other BASELINE.json configurations (they are parity-test cases, not the
+headline): C1 (1-D, 1001 cells), C2 (pendulum 256^2, 512-pt GP), C3 (pendulum 2048^2, 2048-pt GP,
+LyapunovNetwork), C4-lin / C4-det (cart-pole 128^4 with linear / Euler dynamics, the HBM-bound
+cases) and C5 (cart-pole 64^4 x 9 actions: Bellman optimality sweeps, also run to convergence).
+
+``--gpus N``: one process per GPU.  Under torchrun (WORLD_SIZE set) this process is one rank;
+otherwise bench.py launches the N ranks itself (``torch.multiprocessing.spawn``), backend ``nccl``
+(= RCCL over xGMI) when every rank has its own GPU, ``gloo`` when ranks have to share a device.
+The grid is sharded by contiguous index ranges: total work is fixed, so scaling is "strong".
 """
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -26,108 +34,303 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6        # MI355X FP64 matrix (= vector) peak, SURVEY 8d / BASELINE.md
+HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+HEADLINE_METRIC = "grid-cell Lyapunov checks/sec + ms/safe_set-update, 4D 128^4 grid, 1k-pt GP"
+CONFIGS = ("C1", "C2", "C3", "C4", "C4-lin", "C4-det", "C5")
 
 
-def flops_per_check(n, p, d_out):
-    """Algorithmic FP64 flops per cell: kernel row + mean + triangular solve."""
-    return n * (4 * p + 2) + 2 * n * d_out + (n * n + 2 * n)
+def flops_per_check(n, p, d_out, heads=1):
+    """Algorithmic FP64 flops per cell: kernel row + mean + triangular solve; a
+    FunctionStack of `heads` single-output GPs repeats the first and third term per head."""
+    return heads * (n * (4 * p + 2) + (n * n + 2 * n)) + 2 * n * d_out
 
 
-def cpu_baseline(case, budget_s=20.0):
-    """The oracle (NumPy float64 restatement of the reference's batch loop) timed on this host:
-    whole 10 000-cell batches of the same grid / GP until ~budget_s of CPU time is spent."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+# ---------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------
+def build_workload(args):
+    """-> (kind, label, case or RL tuple).  kind: 'lyapunov' or 'bellman'."""
+    from safe_learning_amd.benchmarks import GP_VARIANTS, headline_case, make_case, network_weights
+    cfg = args.config
+    informed = GP_VARIANTS["informed"]
+    if cfg == "C4":
+        npts, n_gp = args.num_points or 128, args.n_gp or 1024
+        case = headline_case(num_points=npts, n_gp=n_gp, family=args.family)
+        label = ("%s %d^%d GridWorld (%d cells), %d-point RBF GP dynamics, quadratic Lyapunov "
+                 "function, Lyapunov.update_safe_set()"
+                 % (args.family, npts, case["d"], npts ** case["d"], n_gp))
+    elif cfg == "C1":
+        case = make_case("1d", num_points=args.num_points or 1001)
+        label = "1-D GridWorld (%d cells), linear dynamics, quadratic V" % case["num_points"][0]
+    elif cfg == "C2":
+        npts, n_gp = args.num_points or 256, args.n_gp or 512
+        case = make_case("pendulum", num_points=npts, n_gp=n_gp, tau_scale=0.01, **informed)
+        label = "pendulum %d^2 GridWorld, %d-point RBF GP dynamics, quadratic V" % (npts, n_gp)
+    elif cfg == "C3":
+        npts, n_gp = args.num_points or 2048, args.n_gp or 2048
+        case = make_case("pendulum", num_points=npts, n_gp=n_gp, tau_scale=0.0, **informed)
+        case["V"] = {"kind": "network", "layer_dims": [64, 64, 64], "activations": ["tanh"] * 3,
+                     "eps": 1e-8, "weights": network_weights(2, [64, 64, 64], seed=1)}
+        case["lv"] = ("norm_grad",)
+        label = ("pendulum %d^2 GridWorld, %d-point RBF GP dynamics, LyapunovNetwork [64,64,64], "
+                 "L_v = |grad V|_1" % (npts, n_gp))
+    elif cfg in ("C4-lin", "C4-det"):
+        npts = args.num_points or 128
+        dyn = "linear" if cfg == "C4-lin" else "analytic"
+        case = make_case("cartpole", num_points=npts, dynamics=dyn,
+                         tau_scale=0.004 if cfg == "C4-lin" else 0.0)
+        label = "cartpole %d^4 GridWorld, %s dynamics, quadratic V" % (
+            npts, "linear" if cfg == "C4-lin" else "10-step explicit-Euler cart-pole")
+    elif cfg == "C5":
+        npts, n_gp = args.num_points or 64, args.n_gp or 1024
+        case = headline_case(num_points=npts, n_gp=n_gp)
+        label = ("cartpole %d^4 value table x 9 actions, %d-point RBF GP mean dynamics, "
+                 "PolicyIteration.value_iteration(action_space) Bellman sweeps" % (npts, n_gp))
+        return "bellman", label, case
+    else:
+        raise ValueError(cfg)
+    return "lyapunov", label, case
+
+
+def build_policy_iteration(case):
+    import scipy.linalg
+    import safe_learning_amd as sl
+    from safe_learning_amd.benchmarks import build_specs
+    policy, dynamics, _, _ = build_specs(case)
+    grid = sl.GridWorld(case["limits"], case["num_points"])
+    vf = sl.Triangulation(grid, np.zeros((grid.nindex, 1)), project=True)
+    d = case["d"]
+    reward = sl.QuadraticFunction(-scipy.linalg.block_diag(0.1 * np.eye(d), 0.1 * np.eye(1)))
+    rl = sl.PolicyIteration(policy, dynamics, reward, vf, gamma=0.98)
+    return rl, np.linspace(-1, 1, 9)[:, None]
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the oracle on this host's cores, bounded samples
+# ---------------------------------------------------------------------------------------------
+def _cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    blas = "unknown"
+    try:
+        from threadpoolctl import threadpool_info
+        libs = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        if libs:
+            blas = "%s %s (%s threads)" % (libs[0].get("internal_api"), libs[0].get("version"),
+                                           libs[0].get("num_threads"))
+    except Exception:
+        pass
+    return model, blas
+
+
+def _oracle_batches(case, budget_s, threads=None):
+    """Whole 10 000-cell batches (lyapunov.py:517-529) of the same grid / model at random places
+    until ~budget_s of wall time is spent -> (cells, seconds)."""
     import cases
+    from threadpoolctl import threadpool_limits
     olyap = cases.oracle_lyapunov(case, compute_values=False)
     grid = olyap.discretization
     batch = 10000
     rng = np.random.default_rng(0)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        start = int(rng.integers(0, max(grid.nindex - batch, 1)))
-        idx = np.arange(start, min(start + batch, grid.nindex))
-        olyap.negative(grid.index_to_state(idx))
-        done += len(idx)
+    with threadpool_limits(limits=threads):
+        olyap.negative(grid.index_to_state(np.arange(min(batch, grid.nindex))))     # warm-up
+        done, t0 = 0, time.perf_counter()
+        while True:
+            start = int(rng.integers(0, max(grid.nindex - batch, 1)))
+            idx = np.arange(start, min(start + batch, grid.nindex))
+            olyap.negative(grid.index_to_state(idx))
+            done += len(idx)
+            elapsed = time.perf_counter() - t0
+            if elapsed > budget_s or done >= 4 * grid.nindex:
+                break
+    return done, elapsed
+
+
+def _reference_faithful(case, max_cells=6_000_000):
+    """What a user of the reference experiences: ``update_safe_set`` with the global ``np.argsort``
+    and the early exit at the first failing cell (lyapunov.py:512-587), through the oracle.  The
+    whole grid when it has at most ``max_cells`` cells, otherwise the central slab of the first
+    axis (the layers around x_0 = 0, which contain the initial safe set)."""
+    import copy
+    import cases
+    num = list(case["num_points"])
+    total = int(np.prod(num))
+    sub = copy.copy(case)
+    sample = "whole grid (%d cells)" % total
+    if total > max_cells:
+        rest = int(np.prod(num[1:]))
+        layers = max(2, min(num[0], max_cells // rest))
+        lo_i = (num[0] - layers) // 2
+        axis = np.linspace(case["limits"][0][0], case["limits"][0][1], num[0])
+        sub["limits"] = [[float(axis[lo_i]), float(axis[lo_i + layers - 1])]] + list(case["limits"][1:])
+        sub["num_points"] = [layers] + num[1:]
+        sample = ("central slab of %d of the %d layers of the first axis (%d of %d cells), same "
+                  "cell spacing and model" % (layers, num[0], layers * rest, total))
+    t0 = time.perf_counter()
+    olyap = cases.oracle_lyapunov(sub)                       # all_points + V on every cell
+    t_values = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    olyap.update_safe_set()                                  # argsort + batches + early exit
+    t_update = time.perf_counter() - t0
+    return {"reference_faithful_ms": 1e3 * t_update, "reference_faithful_values_ms": 1e3 * t_values,
+            "reference_faithful_sample": sample,
+            "reference_faithful_safe_cells": int(olyap.safe_set.sum())}
+
+
+def cpu_baseline(kind, case, budget_s=14.0):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    model, blas = _cpu_info()
+    out = {"unit": "checks/s", "cores": os.cpu_count(), "kind": "port", "cpu_model": model,
+           "blas": blas}
+    if kind == "bellman":
+        import cases
+        import oracle
+        import scipy.linalg
+        # one Jacobi sweep x 9 actions of the oracle on a sample of vertices
+        policy, dynamics, _, _ = cases.oracle_specs(case)
+        grid = oracle.GridWorld(case["limits"], case["num_points"])
+        vf = oracle.Triangulation(grid, np.zeros((grid.nindex, 1)), project=True)
+        d = case["d"]
+        reward = oracle.QuadraticFunction(-scipy.linalg.block_diag(0.1 * np.eye(d), 0.1 * np.eye(1)))
+        orl = oracle.PolicyIteration(policy, dynamics, reward, vf, gamma=0.98)
+        rng = np.random.default_rng(0)
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            idx = rng.integers(0, grid.nindex, 20000)
+            x = grid.index_to_state(idx)
+            for a in np.linspace(-1, 1, 9):
+                orl.future_values(x, actions=np.full((len(x), 1), a))
+            done += len(idx) * 9
         elapsed = time.perf_counter() - t0
-        if elapsed > budget_s or done >= grid.nindex:
-            break
-    return {"value": done / elapsed, "unit": "checks/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d cells (%d random 10000-cell batches of the same grid and GP) in %.1f s; "
-                      "NumPy/SciPy float64 oracle, BLAS threads = all cores" % (done, done // batch, elapsed)}
+        out.update(value=done / elapsed, unit="(vertex, action) pairs/s",
+                   sample="%d (vertex, action) pairs (random 20000-vertex batches x 9 actions) in "
+                          "%.1f s; NumPy/SciPy float64 oracle, BLAS threads = all cores"
+                          % (done, elapsed))
+        return out
+    done, elapsed = _oracle_batches(case, budget_s)
+    out["value"] = done / elapsed
+    out["sample"] = ("%d cells (%d random 10000-cell batches of the same grid and model) in %.1f s; "
+                     "NumPy/SciPy float64 oracle, BLAS threads = all cores"
+                     % (done, max(done // 10000, 1), elapsed))
+    done4, elapsed4 = _oracle_batches(case, budget_s / 3, threads=4)
+    out["threads4_value"] = done4 / elapsed4       # the notebooks run with num_cores = 4
+    out["threads4_sample"] = "%d cells in %.1f s with 4 BLAS threads" % (done4, elapsed4)
+    out.update(_reference_faithful(case))
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--num-points", type=int, default=128)
-    ap.add_argument("--n-gp", type=int, default=1024)
-    ap.add_argument("--family", default="cartpole", choices=["cartpole", "pendulum"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
-    args = ap.parse_args()
-
+# ---------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------
+def run_rank(args, rank, world, local_rank, backend):
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % max(ndev, 1))
+    dist = None
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(0)
-
-    from safe_learning_amd.benchmarks import build_lyapunov, make_case
-    case = make_case(args.family, num_points=args.num_points, n_gp=args.n_gp)
-    lyap = build_lyapunov(case)                    # uploads the model, computes V on the grid
-    ncells = lyap.discretization.nindex
-    d, p, n_gp = case["d"], case["d"] + case["m"], args.n_gp
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            dist.barrier()
         torch.cuda.synchronize()
 
+    kind, label, case = build_workload(args)
+    extra = {}
+    if kind == "lyapunov":
+        from safe_learning_amd.benchmarks import build_lyapunov
+        obj = build_lyapunov(case)                # uploads the model, computes V on the grid
+        units = obj.discretization.nindex
+        step = obj.update_safe_set
+        cells_per_launch = obj._hi - obj._lo
+    else:
+        obj, actions = build_policy_iteration(case)
+        units = obj.discretization.nindex * len(actions)
+        step = lambda: obj.value_iteration(actions)          # noqa: E731
+        cells_per_launch = obj._hi - obj._lo
+
     for _ in range(args.warmup):
-        lyap.update_safe_set()
+        step()
     barrier()
-    lyap.sweep_events = []                         # HIP events around the dominant kernel
+    obj.sweep_events = []                         # HIP events around the dominant kernel
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lyap.update_safe_set()
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in obj.sweep_events]
+    obj.sweep_events = None
+    avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    per_rank = [elapsed, avg_ms]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t[0])
+        t = torch.tensor(per_rank, dtype=torch.float64, device="cuda")
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank_all = [[float(v) for v in g] for g in gathered]
+        elapsed = max(r[0] for r in per_rank_all)
+        observed_world = dist.get_world_size()
+    else:
+        per_rank_all, observed_world = [per_rank], 1
 
-    kernel_ms = [a.elapsed_time(b) for a, b in lyap.sweep_events]
-    cells_per_launch = lyap._hi - lyap._lo
-    flops = flops_per_check(n_gp, p, d) * cells_per_launch
-    avg_ms = float(np.mean(kernel_ms))
-    achieved = flops / (avg_ms * 1e-3) / 1e12
-
-    traffic = None
-    try:                                           # PMC result of the same command (tools/pmc_traffic.py)
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        if world == 1 and args.num_points == 128 and args.n_gp == 1024 and args.family == "cartpole":
-            traffic = pmc["bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+    # ---- everything below is outside the timed region --------------------------------------
+    if kind == "lyapunov":
+        extra["safe_cells"] = int(obj.safe_count)
+        extra["c_max"] = float(obj.c_max)
+        extra["tau"] = float(case["tau"])
+        if "dynamics" in case and case["dynamics"].get("kind") == "gp":
+            dyn = case["dynamics"]
+            extra["gp_hyper"] = {"signal_std": float(np.sqrt(dyn["variance"])),
+                                 "noise_std": float(np.sqrt(dyn["noise_variance"])),
+                                 "lengthscale": float(np.ravel(dyn["lengthscales"])[0])}
+        # cells that pass the decrease check (popcount of the mask words of all ranks)
+        neg = obj._d_neg[:(cells_per_launch + 63) // 64]
+        cnt = torch.tensor([int(_popcount(neg))], dtype=torch.int64, device="cuda")
+        if world > 1:
+            dist.all_reduce(cnt)
+        extra["negative_cells"] = int(cnt[0])
+        # end to end: one more update including the bool[N] mask on the host (lyapunov.py:598-606)
+        barrier()
+        t1 = time.perf_counter()
+        obj.update_safe_set()
+        mask = obj.safe_set
+        end_to_end_ms = 1e3 * (time.perf_counter() - t1)
+        assert int(mask.sum()) == extra["safe_cells"]
+    else:
+        end_to_end_ms = None
+        # sweeps to convergence at max|dV| <= 1e-6 max|V| (SURVEY 8d metric iii), continuing from
+        # the table the timed sweeps left
+        sweeps, rel, last, monotone = args.warmup + args.steps, float("inf"), float("inf"), True
+        while sweeps < args.max_sweeps:
+            res = obj.value_iteration(actions)
+            sweeps += 1
+            vmax = float(obj.value_function._device_table.abs().max())
+            rel = res / max(vmax, 1e-300)
+            monotone = monotone and res <= last * (1 + 1e-12)
+            last = res
+            if rel <= 1e-6:
+                break
+        extra.update(sweeps_to_convergence=sweeps, relative_residual=rel,
+                     residual_monotone=bool(monotone), converged=bool(rel <= 1e-6))
 
     if rank == 0:
+        d = case["d"]
+        dyn = case.get("dynamics", {})
         out = {
-            # BASELINE.json's metric string; `value` is the checks/sec, `ms_per_step` the
-            # ms per safe_set update
-            "metric": "grid-cell Lyapunov checks/sec + ms/safe_set-update, 4D 128^4 grid, 1k-pt GP",
-            "value": ncells * args.steps / elapsed,
-            "unit": "checks/s",
+            "metric": HEADLINE_METRIC if args.config == "C4" else
+            ("Bellman sweep (vertex, action) pairs/sec + ms/sweep" if kind == "bellman" else
+             "grid-cell Lyapunov checks/sec + ms/safe_set-update"),
+            "value": units * args.steps / elapsed,
+            "unit": "checks/s" if kind == "lyapunov" else "(vertex, action) pairs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -137,21 +340,125 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s %d^%d GridWorld (%d cells), %d-point RBF GP dynamics, "
-                                   "quadratic Lyapunov function, Lyapunov.update_safe_set()"
-                                   % (args.family, args.num_points, d, ncells, n_gp),
-                       "grid_sharding": "contiguous index ranges over %d GPU(s)" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic,
-                         "kernel": "k_gp_sweep", "kernel_ms": avg_ms,
-                         "flops_per_check": flops_per_check(n_gp, p, d)},
+            "config": dict({"workload": label, "name": args.config,
+                            "grid_sharding": "contiguous 64-aligned index ranges over %d GPU(s)" % world,
+                            "collectives": {"backend": backend if world > 1 else None,
+                                            "world_size": observed_world,
+                                            "ranks_share_a_device": bool(world > max(ndev, 1))},
+                            "per_rank_kernel_ms": [r[1] for r in per_rank_all]}, **extra),
         }
+        if end_to_end_ms is not None:
+            out["end_to_end_ms"] = end_to_end_ms      # incl. bits->bytes and the bool[N] D2H
+        out["roofline"] = roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(case)
-        print(json.dumps(out))
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+            out["cpu_baseline"] = cpu_baseline(kind, case)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _popcount(words):
+    """Number of set bits in an int64 tensor (device side)."""
+    import torch
+    x = words.view(torch.uint8)
+    table = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=x.device)
+    return table[x.long()].sum()
+
+
+def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
+    """Achieved rate of the dominant kernel against the roofline that bounds it."""
+    is_gp = dyn.get("kind") == "gp"
+    if kind == "bellman":
+        n = len(dyn["X"])
+        flops = 2.0 * n * 9 * d                  # one FP64 GEMM [cells x n] . [n x A*D] (DESIGN 4.4)
+        achieved = flops * cells_per_launch / (avg_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "kernel": "k_bellman_mfma", "kernel_ms": avg_ms, "flops_per_vertex": flops}
+    if is_gp:
+        n, p = len(dyn["X"]), d + case["m"]
+        heads = d if case.get("stack") else 1
+        fpc = flops_per_check(n, p, d, heads)
+        achieved = fpc * cells_per_launch / (avg_ms * 1e-3) / 1e12
+        traffic, source = None, None
+        try:                                       # PMC passes of the same command (tools/pmc_traffic.py)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if world == 1 and args.config == "C4" and not args.num_points and not args.n_gp:
+                traffic, source = pmc["bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 " \
+                    "FETCH_SIZE x2 + WRITE_SIZE of this command, separate passes; not this run)"
+        except (OSError, ValueError, KeyError):
+            pass
+        return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_source": source, "kernel": "k_gp_sweep", "kernel_ms": avg_ms,
+                "flops_per_check": fpc,
+                "note": "compute-bound: 8.25 algorithmic HBM bytes per check (SURVEY 8d)"}
+    # analytic dynamics: SURVEY 8d's 10 B per check (V read 8 + init mask + mask write, states
+    # generated from the index); the kernel moves 8 B + 2 bits
+    bytes_per_check = 10.0
+    achieved = bytes_per_check * cells_per_launch / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "k_det_sweep",
+            "kernel_ms": avg_ms, "bytes_per_check": bytes_per_check,
+            "note": "the bit-exactness contract (one rounding per multiply and per add, no FMA; "
+                    "~165 FP64 operations per cart-pole cell) puts the FP64-VALU floor above the "
+                    "byte floor: at most ~28 % of the HBM peak is reachable for this configuration"}
+
+
+# ---------------------------------------------------------------------------------------------
+# launch
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawned(rank, args, world, port, backend):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    run_rank(args, rank, world, rank, backend)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C4", choices=CONFIGS)
+    ap.add_argument("--num-points", type=int, default=None)
+    ap.add_argument("--n-gp", type=int, default=None)
+    ap.add_argument("--family", default="cartpole", choices=["cartpole", "pendulum"])
+    ap.add_argument("--max-sweeps", type=int, default=3000, help="C5: bound of the convergence run")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=None,
+                    help="torch.distributed backend; default nccl (= RCCL), gloo if ranks share a GPU")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    import torch
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:                     # launched by torchrun: this process is one rank
+        world = int(env_world)
+        ndev = torch.cuda.device_count()
+        backend = args.backend or ("nccl" if ndev >= min(world, args.gpus or world) else "gloo")
+        run_rank(args, int(os.environ.get("RANK", "0")), world,
+                 int(os.environ.get("LOCAL_RANK", "0")), backend)
+        return
+    world = max(1, args.gpus)
+    if world == 1:
+        run_rank(args, 0, 1, 0, None)
+        return
+    # self-launch: one process per GPU (never fork a process that may hold a HIP context)
+    import torch.multiprocessing as mp
+    ndev = torch.cuda.device_count()
+    backend = args.backend or ("nccl" if ndev >= world else "gloo")
+    mp.spawn(_spawned, args=(args, world, _free_port(), backend), nprocs=world, join=True)
 
 
 if __name__ == "__main__":

@@ -67,7 +67,14 @@ class PolicyIteration(object):
             argmax = torch.empty(count, dtype=torch.int32, device=dev)
             if want_q:
                 q = torch.empty((count, actions.shape[0]), dtype=torch.float64, device=dev)
+        events = getattr(self, 'sweep_events', None)
+        if events is not None:                      # bench.py: HIP events on the kernel's stream
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
         ctx.bellman_sweep(lo, hi, actions, v_new, argmax, q, stats)
+        if events is not None:
+            stop.record()
+            events.append((start, stop))
         return v_new[:hi - lo], argmax, q, stats
 
     def _gather(self, shard):
@@ -162,10 +169,9 @@ class PolicyIteration(object):
         if best is None:
             best = self._gather(argmax[:self._hi - self._lo]).to(torch.int64)
         table = torch.from_numpy(action_space).to(best.device)[best]
-        if isinstance(self.policy, Triangulation):
-            self.policy._adopt_device_table(table.contiguous())
-        else:
-            self.policy = Triangulation(self.discretization, table.cpu().numpy())
+        if not isinstance(self.policy, Triangulation):
+            self.policy = Triangulation(self.discretization)
+        self.policy._adopt_device_table(table.contiguous())
 
     def bellmann_error(self, states=None):
         """``sum (future_values - V)^2`` (``:116-133``): over the grid in one sweep, or at the given

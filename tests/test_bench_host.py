@@ -1,0 +1,51 @@
+"""bench.py pieces that need no GPU: argument handling, roofline arithmetic, the CPU-baseline legs
+on small cases (the oracle is the thing timed there - allowed for bench.py's cpu_baseline only)."""
+
+import os
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_flops_per_check_contract():
+    # SURVEY 8d figures: C2, C3 (without the network), C4
+    assert bench.flops_per_check(512, 3, 2) == 7168 + 2048 + 263168
+    assert bench.flops_per_check(1024, 5, 4) == 1081344
+    assert bench.flops_per_check(2048, 3, 2) == 28672 + 8192 + 4198400
+    # FunctionStack: the kernel row and the solve are repeated per head
+    assert bench.flops_per_check(1024, 5, 4, heads=4) == 4 * (22528 + 1050624) + 8192
+
+
+def test_args_and_workloads():
+    args = bench.parse_args([])
+    assert args.gpus == 1 and args.config == "C4" and args.steps >= 1
+    for cfg in bench.CONFIGS:
+        args = bench.parse_args(["--config", cfg, "--num-points", "6", "--n-gp", "20"])
+        kind, label, case = bench.build_workload(args)
+        assert kind == ("bellman" if cfg == "C5" else "lyapunov")
+        assert isinstance(label, str) and case["d"] in (1, 2, 4)
+    # the headline: BASELINE.json's grid and GP sizes
+    kind, label, case = bench.build_workload(bench.parse_args([]))
+    assert case["num_points"] == [128] * 4 and len(case["dynamics"]["X"]) == 1024
+    assert "128^4" in label and "1024-point" in label
+
+
+def test_reference_faithful_leg_small():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    from gp_cases import INFORMED
+    case = cases.make_case("pendulum", num_points=40, n_gp=60, tau_scale=0.01, **INFORMED)
+    whole = bench._reference_faithful(case)
+    assert "whole grid" in whole["reference_faithful_sample"]
+    assert whole["reference_faithful_safe_cells"] > 100 and whole["reference_faithful_ms"] > 0
+    slab = bench._reference_faithful(case, max_cells=400)
+    assert "central slab of 10 of the 40 layers" in slab["reference_faithful_sample"]
+    done, seconds = bench._oracle_batches(case, 0.2, threads=2)
+    assert done >= 1600 and seconds > 0
+    model, blas = bench._cpu_info()
+    assert isinstance(model, str) and isinstance(blas, str)

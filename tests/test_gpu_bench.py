@@ -1,0 +1,72 @@
+"""bench.py on the GPU box: the single-rank line and the self-launched two-rank run (both ranks
+on cuda:0, gloo rendezvous on 127.0.0.1) must describe the same result."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(*flags):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(key, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_small_and_two_ranks():
+    small = ["--num-points", "16", "--n-gp", "300", "--steps", "2", "--warmup", "1"]
+    one = _run(*small)
+    assert one["n_gpus"] == 1 and one["value"] > 0
+    for key in ("metric", "unit", "ms_per_step", "roofline", "cpu_baseline", "end_to_end_ms"):
+        assert key in one
+    assert one["roofline"]["bound"] == "mfma" and 0 < one["roofline"]["frac"] < 1
+    cpu = one["cpu_baseline"]
+    for key in ("value", "cores", "kind", "sample", "threads4_value", "reference_faithful_ms",
+                "cpu_model", "blas"):
+        assert key in cpu
+    cfg = one["config"]
+    # the workload is not degenerate: cells pass the check and the level set grows
+    assert 0 < cfg["negative_cells"] < 16 ** 4
+    assert cfg["safe_cells"] >= 100
+    two = _run("--gpus", "2", "--no-cpu-baseline", *small)
+    assert two["n_gpus"] == 2 and two["config"]["collectives"]["world_size"] == 2
+    assert len(two["config"]["per_rank_kernel_ms"]) == 2
+    assert two["config"]["safe_cells"] == cfg["safe_cells"]
+    assert two["config"]["negative_cells"] == cfg["negative_cells"]
+    assert two["config"]["c_max"] == cfg["c_max"]
+
+
+@pytest.mark.parametrize("config,flags", [
+    ("C1", []),
+    ("C2", ["--num-points", "64", "--n-gp", "128"]),
+    ("C4-lin", ["--num-points", "24"]),
+    ("C4-det", ["--num-points", "16"]),
+])
+def test_bench_other_lyapunov_configs(config, flags):
+    out = _run("--config", config, "--no-cpu-baseline", *flags)
+    assert out["config"]["name"] == config and out["value"] > 0
+    assert out["roofline"]["bound"] == ("mfma" if config == "C2" else "hbm")
+
+
+def test_bench_c5_runs_to_convergence():
+    out = _run("--config", "C5", "--num-points", "10", "--n-gp", "128", "--steps", "3",
+               "--no-cpu-baseline", "--max-sweeps", "2500")
+    cfg = out["config"]
+    assert cfg["converged"] and cfg["relative_residual"] <= 1e-6
+    assert cfg["residual_monotone"]
+    assert 100 < cfg["sweeps_to_convergence"] < 2500      # gamma = 0.98
+    two = _run("--config", "C5", "--num-points", "10", "--n-gp", "128", "--steps", "3",
+               "--no-cpu-baseline", "--max-sweeps", "2500", "--gpus", "2")
+    assert two["config"]["sweeps_to_convergence"] == cfg["sweeps_to_convergence"]

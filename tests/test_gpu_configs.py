@@ -1,0 +1,188 @@
+"""BASELINE.json's other configurations at their full sizes (need an MI355X):
+
+  C2  pendulum 256^2, 512-point GP        every cell against the oracle
+  C3  pendulum 2048^2, 2048-point GP, LyapunovNetwork [64,64,64]
+                                          sub-range records + masks, sampled cells, level set
+  C4-det  cart-pole 128^4, Euler dynamics sampled cells, level set
+  C5  cart-pole 64^4 x 9 actions          one Bellman optimality sweep and one policy-evaluation
+                                          sweep on sampled vertices, monotone residual decay
+Reference: lyapunov.py:407-606, reinforcement_learning.py:65-140, 213-279.
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+import cases
+import oracle
+from conftest import ROOT
+from test_gpu_full_size import (_grid_points, _level_set_properties, _neg_mask, _point_records,
+                                _subrange_records)
+from test_gpu_lyapunov import _check_masks, _engine_records, _oracle_all
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, ROOT)
+
+
+def _workload(config, **over):
+    import bench
+    flags = ["--config", config]
+    for key, val in over.items():
+        flags += ["--" + key.replace("_", "-"), str(val)]
+    return bench.build_workload(bench.parse_args(flags))[2]
+
+
+def test_c2_pendulum_256_every_cell():
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = _workload("C2")
+    assert case["num_points"] == [256, 256] and len(case["dynamics"]["X"]) == 512
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    values, neg, rec = _engine_records(lyap)
+    ref_rec, ref_neg = _oracle_all(olyap)
+    assert_array_equal(values, olyap.values)
+    assert_allclose(rec[:, 2:4], ref_rec[:, 2:4], rtol=1e-9, atol=1e-13)
+    assert_allclose(rec[:, 4:], ref_rec[:, 4:], rtol=1e-7, atol=1e-12)
+    assert_allclose(rec[:, :2], ref_rec[:, :2], rtol=1e-7, atol=1e-12)
+    flips, _ = _check_masks(neg, ref_neg, rec, ref_rec)
+    assert ref_neg.sum() > 1000 and (~ref_neg).sum() > 1000
+    lyap.update_safe_set(); olyap.update_safe_set()
+    init = np.count_nonzero(cases.initial_safe_mask(case))
+    assert olyap.safe_set.sum() >= init + 1000
+    if flips == 0:
+        assert_array_equal(lyap.safe_set, olyap.safe_set)
+        assert lyap.c_max == olyap.c_max
+        assert lyap.safe_count == int(olyap.safe_set.sum())
+
+
+def _sampled_checks(lyap, olyap, n, neg, rtol, nsample, seed, starts=()):
+    """Sub-range sweeps (records + mask bits) and scattered explicit-point records vs the oracle."""
+    rng = np.random.default_rng(seed)
+    starts = set(starts) | {int(s) * 64 for s in rng.integers(0, n // 64 - 32, 4)}
+    both = 0
+    for lo in sorted(starts):
+        lo = max(0, (lo // 64) * 64)
+        hi = min(n, lo + 1536)
+        rec, bits = _subrange_records(lyap, lo, hi)
+        ref = cases.oracle_cell_records(olyap, np.arange(lo, hi))
+        assert_allclose(rec, ref, rtol=rtol, atol=1e-12)
+        ref_neg = ref[:, 0] < ref[:, 1]
+        margin = np.abs(ref[:, 0] - ref[:, 1]) / np.maximum(np.abs(ref[:, 0]), 1e-300)
+        assert not np.any((bits != ref_neg) & (margin > 1e-8))
+        assert_array_equal(bits, neg[lo:hi])
+        both += int(ref_neg.any() and (~ref_neg).any())
+    idx = np.unique(rng.integers(0, n, nsample))
+    ref = cases.oracle_cell_records(olyap, idx)
+    assert_allclose(_point_records(lyap, idx), ref, rtol=rtol, atol=1e-12)
+    ref_neg = ref[:, 0] < ref[:, 1]
+    margin = np.abs(ref[:, 0] - ref[:, 1]) / np.maximum(np.abs(ref[:, 0]), 1e-300)
+    assert not np.any((neg[idx] != ref_neg) & (margin > 1e-8))
+    assert ref_neg.any() and (~ref_neg).any()
+    return both
+
+
+def test_c3_pendulum_2048_network():
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = _workload("C3")
+    assert case["num_points"] == [2048, 2048] and len(case["dynamics"]["X"]) == 2048
+    lyap = build_lyapunov(case)
+    n = lyap.discretization.nindex
+    lyap.update_safe_set()
+    neg = _neg_mask(lyap)
+    assert neg.sum() > 10000 and (~neg).sum() > 10000
+    olyap = cases.oracle_lyapunov(case, compute_values=False)
+    # V of the network on sampled grid points (north_star: within 1e-5; here 1e-12)
+    rng = np.random.default_rng(5)
+    idx = np.unique(rng.integers(0, n, 20000))
+    v_ref = np.ravel(olyap.lyapunov_function(_grid_points(olyap.discretization, idx)))
+    assert_allclose(lyap.values[idx], v_ref, rtol=1e-12, atol=1e-15)
+    centre = (n // 2 + 1024) // 64 * 64
+    both = _sampled_checks(lyap, olyap, n, neg, 1e-8, 4000, 6, starts=(0, centre, centre + 2048 * 40))
+    assert both >= 1
+    # level-set structure of the whole result (the network's V has no exact ties to speak of)
+    init = np.zeros(n, dtype=bool)
+    init[lyap._initial_safe_set] = True
+    assert int((lyap.safe_set & ~init).sum()) >= 100
+    _level_set_properties(lyap, neg)
+
+
+def test_c4_det_cartpole_128_euler():
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = _workload("C4-det")
+    lyap = build_lyapunov(case)
+    n = lyap.discretization.nindex
+    assert n == 128 ** 4
+    lyap.update_safe_set()
+    neg = _neg_mask(lyap)
+    assert neg.sum() > 10 ** 6 and (~neg).sum() > 10 ** 6
+    olyap = cases.oracle_lyapunov(case, compute_values=False)
+    init = np.zeros(n, dtype=bool)
+    init[lyap._initial_safe_set] = True
+    assert int((lyap.safe_set & ~init).sum()) >= 100
+    _level_set_properties(lyap, neg)
+    failing = ~(neg | init)
+    i_star = int(np.flatnonzero(failing & (lyap.values == lyap.values[failing].min()))[0])
+    both = _sampled_checks(lyap, olyap, n, neg, 1e-10, 30000, 7,
+                           starts=(0, (i_star // 64) * 64 - 512, n // 2, n - 2048))
+    assert both >= 1
+
+
+def test_c5_cartpole_64_bellman_sweeps():
+    import scipy.linalg
+    import bench
+    from test_gpu_rl import ambiguous_points
+    case = _workload("C5")
+    assert case["num_points"] == [64] * 4 and len(case["dynamics"]["X"]) == 1024
+    rl, actions = bench.build_policy_iteration(case)
+    residuals = [rl.value_iteration(actions) for _ in range(3)]
+    table = rl.value_function.parameters.copy()            # input of the sweep under test
+    residuals.append(rl.value_iteration(actions))
+    new = rl.value_function.parameters[:, 0].copy()
+    greedy = rl.policy.parameters[:, 0].copy()
+
+    ogrid = oracle.GridWorld(case["limits"], case["num_points"])
+    ovf = oracle.Triangulation(ogrid, table, project=True)
+    opolicy, odynamics, _, _ = cases.oracle_specs(case)
+    d = case["d"]
+    oreward = oracle.QuadraticFunction(-scipy.linalg.block_diag(0.1 * np.eye(d), 0.1 * np.eye(1)))
+    orl = oracle.PolicyIteration.__new__(oracle.PolicyIteration)     # skip all_points (0.5 GB)
+    orl.dynamics, orl.reward_function, orl.value_function = odynamics, oreward, ovf
+    orl.gamma, orl.policy = 0.98, opolicy
+    n = ogrid.nindex
+    rng = np.random.default_rng(9)
+    idx = np.unique(np.concatenate([rng.integers(0, n, 2500), [0, n - 1, n // 2]]))
+    x = _grid_points(ogrid, idx)                        # state_space rows (all_points convention)
+    q = np.empty((len(idx), len(actions)))
+    ok = np.ones(len(idx), dtype=bool)
+    for a, action in enumerate(actions[:, 0]):
+        u = np.full((len(x), 1), action)
+        q[:, a] = orl.future_values(x, actions=u)[:, 0]
+        ok &= ~ambiguous_points(ovf, odynamics(x, u)[0])
+    assert ok.mean() > 0.5
+    assert_allclose(new[idx][ok], q.max(axis=1)[ok], rtol=1e-9, atol=1e-12)
+    top2 = np.sort(q, axis=1)[:, -2:]
+    tie = np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1])
+    assert not np.any((greedy[idx] != actions[np.argmax(q, axis=1), 0]) & ok & ~tie)
+    assert len(np.unique(greedy)) > 2                   # the greedy policy is not trivial
+
+    # policy-evaluation sweep (the reference's value_iteration()) with the greedy table policy
+    table2 = rl.value_function.parameters.copy()
+    rl.value_iteration()
+    evaluated = rl.value_function.parameters[:, 0]
+    ovf2 = oracle.Triangulation(ogrid, table2, project=True)
+    opol = oracle.Triangulation(ogrid, greedy[:, None])
+    orl.value_function = ovf2
+    u = opol(x)
+    ref = orl.future_values(x, actions=u)[:, 0]
+    ok = ~ambiguous_points(opol, x) & ~ambiguous_points(ovf2, odynamics(x, u)[0])
+    assert ok.mean() > 0.5
+    assert_allclose(evaluated[idx][ok], ref[ok], rtol=1e-9, atol=1e-12)
+
+    # residual of the optimality sweeps decays monotonically (gamma-contraction)
+    residuals += [rl.value_iteration(actions) for _ in range(12)]
+    tail = residuals[-12:]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(tail, tail[1:]))
+    assert tail[-1] < tail[0]
