@@ -156,17 +156,21 @@ def make_case(name, num_points=None, n_gp=None, dynamics=None, seed=0, stack=Fal
 
 
 HEADLINE_GP = 'informed'
+HEADLINE_TAU_SCALE = 0.0005
 
 
 def headline_case(num_points=128, n_gp=1024, family='cartpole', stack=False, variant=None):
     """BASELINE.json's headline workload (configs[3]): cart-pole 128^4 cells, 1024-point shared
     RBF GP over [x, u].  Grid, GP size, kernel, policy, V, L_v, L_f follow SURVEY.md 8d; the GP
-    hyper-parameters are the ``informed`` set and tau = 0 (``lyapunov_function_learning.ipynb``
-    also verifies with tau = 0) because with 8d's literal values no cell passes the decrease
-    check, which would make mask parity vacuous.  The cost of a sweep does not depend on the
+    hyper-parameters are the ``informed`` set and tau = HEADLINE_TAU_SCALE x (sum of the grid
+    spacings / 2), because with 8d's literal values (and the full tau) no cell passes the decrease
+    check, which would make mask parity vacuous: measured on the 128^4 grid, 8d's values give 1
+    passing cell of 2.7e8 and a safe set equal to the initial set; this workload has 8.5e7 passing
+    cells and a level set that grows by 1.3e4 cells.  The cost of a sweep does not depend on the
     hyper-parameters (the kernel has no early exit)."""
     hyper = GP_VARIANTS[HEADLINE_GP if variant is None else variant]
-    return make_case(family, num_points=num_points, n_gp=n_gp, stack=stack, tau_scale=0.0, **hyper)
+    return make_case(family, num_points=num_points, n_gp=n_gp, stack=stack,
+                     tau_scale=HEADLINE_TAU_SCALE, **hyper)
 
 
 def initial_safe_mask(case):

@@ -91,3 +91,27 @@ def oracle_cell_records(lyap, indices):
         mean, err = nxt, np.zeros_like(nxt)
     threshold = np.broadcast_to(threshold, decrease.shape)
     return np.hstack((decrease, threshold, mean, err))
+
+
+def lyapunov_like_network_weights(P, layer_dims, scale=0.5, eps=1e-8):
+    """LyapunovNetwork weights whose V is close to ``scale^2 x^T P x`` near the origin (a network
+    that IS a Lyapunov candidate, unlike a randomly initialised one): the first layer's kernel
+    ``W^T W + eps I`` equals ``scale^2 P`` and the remaining kernels pass the leading components
+    through.  Variable order of ``examples/utilities.py:95-99``."""
+    P = np.asarray(P, dtype=np.float64)
+    d = len(P)
+    weights, in_dim = [], d
+    for i, out_dim in enumerate(layer_dims):
+        hidden = int(np.ceil((in_dim + 1) / 2))
+        W = np.zeros((hidden, in_dim))
+        if i == 0:
+            assert hidden >= d
+            W[:d, :d] = np.linalg.cholesky(scale ** 2 * P - eps * np.eye(d)).T
+        else:
+            k = min(hidden, in_dim)
+            W[:k, :k] = np.eye(k)
+        weights.append(W)
+        if out_dim > in_dim:
+            weights.append(np.zeros((out_dim - in_dim, in_dim)))
+        in_dim = out_dim
+    return weights

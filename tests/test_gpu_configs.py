@@ -102,10 +102,10 @@ def test_c3_pendulum_2048_network():
     centre = (n // 2 + 1024) // 64 * 64
     both = _sampled_checks(lyap, olyap, n, neg, 1e-8, 4000, 6, starts=(0, centre, centre + 2048 * 40))
     assert both >= 1
-    # level-set structure of the whole result (the network's V has no exact ties to speak of)
-    init = np.zeros(n, dtype=bool)
-    init[lyap._initial_safe_set] = True
-    assert int((lyap.safe_set & ~init).sum()) >= 100
+    # level-set structure of the whole result.  The sublevel sets of a randomly initialised
+    # network (Xavier-uniform weights) are not invariant under the dynamics, so the
+    # safe set stays the initial set here; test_network_level_set_grows covers a network whose
+    # level set grows.
     _level_set_properties(lyap, neg)
 
 
