@@ -284,7 +284,9 @@ def run_rank(args, rank, world, local_rank, backend):
 
     # ---- everything below is outside the timed region --------------------------------------
     if kind == "lyapunov":
+        from safe_learning_amd.benchmarks import initial_safe_mask
         extra["safe_cells"] = int(obj.safe_count)
+        extra["initial_cells"] = int(np.count_nonzero(initial_safe_mask(case)))
         extra["c_max"] = float(obj.c_max)
         extra["tau"] = float(case["tau"])
         if "dynamics" in case and case["dynamics"].get("kind") == "gp":

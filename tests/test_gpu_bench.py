@@ -26,7 +26,7 @@ def _run(*flags):
 
 
 def test_bench_line_small_and_two_ranks():
-    small = ["--num-points", "16", "--n-gp", "300", "--steps", "2", "--warmup", "1"]
+    small = ["--num-points", "24", "--n-gp", "300", "--steps", "2", "--warmup", "1"]
     one = _run(*small)
     assert one["n_gpus"] == 1 and one["value"] > 0
     for key in ("metric", "unit", "ms_per_step", "roofline", "cpu_baseline", "end_to_end_ms"):
@@ -38,8 +38,8 @@ def test_bench_line_small_and_two_ranks():
         assert key in cpu
     cfg = one["config"]
     # the workload is not degenerate: cells pass the check and the level set grows
-    assert 0 < cfg["negative_cells"] < 16 ** 4
-    assert cfg["safe_cells"] >= 100
+    assert 0 < cfg["negative_cells"] < 24 ** 4
+    assert cfg["safe_cells"] >= cfg["initial_cells"] + 50
     two = _run("--gpus", "2", "--no-cpu-baseline", *small)
     assert two["n_gpus"] == 2 and two["config"]["collectives"]["world_size"] == 2
     assert len(two["config"]["per_rank_kernel_ms"]) == 2

@@ -191,7 +191,7 @@ def test_cartpole_128_gp_dynamics():
 
 def test_cartpole_gp_function_stack_full_head_count():
     """FunctionStack of four single-output 1024-point GPs (the notebooks' style, 4x the work per
-    cell) on 32^4 cells: non-degenerate, records and masks on sub-ranges vs the oracle."""
+    cell) on 48^4 cells: non-degenerate, records and masks on sub-ranges vs the oracle."""
     from safe_learning_amd.benchmarks import headline_case
-    case = headline_case(num_points=32, stack=True)
+    case = headline_case(num_points=48, stack=True)
     _gp_full_size_checks(case, 1500, 3)
