@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["sl_kernels.hip", "sl_gp.hip", "sl_bellman.hip", "sl_nn.hip"]
+SOURCES = ["sl_kernels.hip", "sl_gp.hip", "sl_gp4.hip", "sl_bellman.hip", "sl_nn.hip"]
 LIB = os.path.join(HERE, "libslhip.so")
 
 
@@ -22,6 +22,22 @@ def _newer(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _audit_gp4(objdir, verbose):
+    """k_gp_sweep4 owns the accumulator registers through inline asm: prove on the generated code
+    that the compiler never uses one and keeps the MFMA loops free of spill traffic."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_gp4
+    listings = [f for f in glob.glob(os.path.join(objdir, "sl_gp4*gfx950*.s"))]
+    if not listings:
+        raise RuntimeError("device assembly of sl_gp4.hip not found in %s" % objdir)
+    report, problems = audit_gp4.audit(listings[0])
+    if verbose:
+        print("\n".join(report))
+    if problems:
+        raise RuntimeError("sl_gp4.hip failed its code audit:\n" + "\n".join(problems))
 
 
 def build(verbose=False, force=False):
@@ -44,7 +60,12 @@ def build(verbose=False, force=False):
     jobs = []
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        extra = []
+        if os.path.basename(src) == "sl_gp4.hip":
+            # fixed accumulator registers in inline asm: the compiler must not spill into the
+            # accumulator file; keep the device assembly for the audit below
+            extra = ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps=obj"]
+        cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         jobs.append((obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -56,6 +77,7 @@ def build(verbose=False, force=False):
         failed = failed or proc.returncode != 0
     if failed:
         raise RuntimeError("hipcc failed")
+    _audit_gp4(objdir, verbose)
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [obj for obj, _ in jobs]
     res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:

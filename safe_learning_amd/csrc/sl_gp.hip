@@ -37,10 +37,12 @@ typedef double sl_d2 __attribute__((ext_vector_type(2)));
 // configurations: {W wavefronts, R row blocks per wavefront, CB cell blocks}
 //   cfg 0: small n (tests)   W=4 R=1 CB=1   panel   64 rows, 16 cells
 //   cfg 1:                    W=8 R=8 CB=2   panel 1024 rows, 32 cells
-//   cfg 2:                    W=8 R=4 CB=4   panel  512 rows, 64 cells
-static const int kCfgW[3] = {4, 8, 8};
-static const int kCfgR[3] = {1, 8, 4};
-static const int kCfgCB[3] = {1, 2, 4};
+//   cfg 2:                    W=8 R=4 CB=4   panel  512 rows, 64 cells; fast-path models run
+//                             k_gp_sweep4 instead (sl_gp4.hip: 4x4x4 MFMAs, W=4 R=8 CB=4)
+//   cfg 3:                    as cfg 2, always on this file's kernel (SL_GP_CFG=3: comparisons)
+static const int kCfgW[4] = {4, 8, 8, 8};
+static const int kCfgR[4] = {1, 8, 4, 4};
+static const int kCfgCB[4] = {1, 2, 4, 4};
 
 static inline int cfg_panel_rows(int cfg) { return 16 * kCfgR[cfg] * kCfgW[cfg]; }
 
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
 // =============================================================================================
 static int choose_cfg(int n) {
     const char* env = getenv("SL_GP_CFG");
-    if (env && env[0] >= '0' && env[0] <= '2') return env[0] - '0';
+    if (env && env[0] >= '0' && env[0] <= '3') return env[0] - '0';
     if (n <= 256) return 0;
     return 2;        // 64-cell tiles: half the Linv traffic per MFMA of cfg 1, measured fastest
 }
@@ -499,6 +501,9 @@ int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
                        covered, model.m.grid.d);
     const bool general = sl_model_is_general(model);
     const int variant = sl_dim_variant_of(model);
+    if (ctx->gp_cfg == 2 && sl_gp4_supports(model))
+        return sl_gp4_sweep_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
+                                   d_dbg, d_points);
     // training inputs too large to sit in LDS beside the k_x buffers: 64-cell-tile configuration
     // with the inputs read from L2 (fast-path models with 2 or 4 state dimensions)
     {
@@ -509,7 +514,7 @@ int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
         }
         const size_t fixed = sizeof(double) * (2 * SL_GP_SLABS_PER_CHUNK * 4 * 64 + 8 * 64 +
                                                8 * 16 * SL_GP_DOUT_MAX + 2 * 64 * SL_D + 2 * 8);
-        if (ctx->gp_cfg == 2 && fixed + sizeof(double) * xs_max > 160 * 1024) {
+        if (ctx->gp_cfg >= 2 && fixed + sizeof(double) * xs_max > 160 * 1024) {
             if (!general && variant == 4)
                 return launch_cfg<8, 4, 4, false, 4, 1, true>(ctx, model, lo, hi, d_init_bits, d_values,
                                                               d_neg_bits, nblocks, d_dbg, d_points);
@@ -540,6 +545,7 @@ int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
         SL_GP_CASE(0, 4, 1, 1)
         SL_GP_CASE(1, 8, 8, 2)
         SL_GP_CASE(2, 8, 4, 4)
+        SL_GP_CASE(3, 8, 4, 4)
     }
 #undef SL_GP_CASE
 #undef SL_GP_LAUNCH

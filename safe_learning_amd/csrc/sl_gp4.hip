@@ -1,0 +1,562 @@
+// sl_gp4.hip - the GP-dynamics Lyapunov sweep on v_mfma_f64_4x4x4_4b_f64 (training sets > 256
+// points, closed-form policy and quadratic V: the headline path).  Same mathematics, data layout
+// in HBM and epilogue as k_gp_sweep (sl_gp.hip); what differs is how the FP64 matrix pipe is fed:
+//
+//  * v_mfma_f64_16x16x4_f64 issues every ~85-100 cycles on gfx950 (2048 flops), the 4-block
+//    v_mfma_f64_4x4x4_4b_f64 every 16.3 (512 flops): 47 against 76 TFLOP/s in isolation.  Its
+//    four blocks are independent 4x4x4 products (block b = lanes 4b..4b+3 of every row of 16
+//    lanes, tests/test_gpu_lyapunov.py::test_mfma_4x4x4_block_layout), so a 16-row x 16-cell x 4
+//    tile takes four instructions: the A fragment (rows) stays, the k_x fragment (cells) is read
+//    from LDS rotated by 0/4/8/12 lanes per row of 16.
+//  * FP64 VALU work shares that pipe (measured: no overlap with FP64 MFMAs, own wave or partner),
+//    so nothing is gained from a second wavefront per SIMD: ONE wavefront per SIMD (W = 4) with
+//    the whole 512-register file - 8 row blocks x 4 cell blocks x 4 rotations = 128 FP64
+//    accumulators per lane - halves the operand traffic per MFMA.
+//  * The accumulators sit at FIXED accumulator registers a[0:255] and are only touched by
+//    inline-asm MFMA groups.  With C++ accumulator variables every branch around the MFMAs (the
+//    lower triangle makes the set of active row blocks chunk dependent) costs phi copies,
+//    out-of-place MFMAs and spills (measured: 36 instead of 62 TFLOP/s for the GEMM phase).
+//  * One straight-line body per number of active row blocks (template R0), operands software
+//    pipelined: A fragments (buffer loads with scalar offsets) two slab pairs ahead in three
+//    register sets, k_x fragments one rotation ahead.
+//  * k_x generation: where the GP input [x, policy(x)] / lengthscales is affine in the cell index
+//    along the wavefront's 16 cells (a row of the last grid axis, policy linear or saturated) the
+//    RBF values form a Gaussian sequence e_{c+1} = e_c rho_c, rho_{c+1} = rho_c Q: two
+//    exponentials per (training point, 16 cells) instead of 16 (lane = training point).  The test
+//    is on the values themselves, so any other case (explicit points, kinks of the saturation,
+//    rows that end inside the block) silently takes one exponential per (point, cell).
+//    The posterior mean k_x . alpha' is accumulated from the LDS copy of each new chunk.
+//
+// Measured in tools/gp_lab.hip (1 Mi cells, 1024 points): 16x16x4 structure 49.5 TFLOP/s, this
+// one 60.5; profiles/r02_summary.md has the ablation.
+#include "sl_common.h"
+
+typedef double sl_d2 __attribute__((ext_vector_type(2)));
+typedef unsigned sl_u4 __attribute__((ext_vector_type(4)));
+
+namespace gp4 {
+
+constexpr int R = 8, CB = 4, W = 4;
+constexpr int C = 16 * CB;                 // cells per tile
+constexpr int RP = 16 * R * W;             // rows per panel (512)
+constexpr int RB = R * W;                  // row blocks per panel
+// k_x chunk (64 training points x 64 cells) in LDS:
+//   [slab pair 8][cell block CB][k 4][slot 16][slab of the pair 2]
+// The slot of cell c16 in row k is c16 ^ 4k and consecutive slab pairs are 4 doubles apart
+// modulo the banks: fragment reads (lane = (k, cell), 16 B) and generation writes (lane =
+// training point, 8 B, one cell per instruction) are both free of bank conflicts.
+constexpr int KXS2 = CB * 128 + 4;
+constexpr int KXBUF = 8 * KXS2;
+static_assert(R * CB * 4 * 2 == 256, "the accumulators fill the 256 accumulator registers");
+
+struct AFrag { sl_d2 v[R]; };
+struct BFrag { sl_d2 v[CB]; };
+
+// The 128 accumulators live at FIXED accumulator registers, acc(r, cb, rot) = a[2 i : 2 i + 1] with
+// i = (r * CB + cb) * 4 + rot, and only the asm statements below touch them.  (As C++ values -
+// builtin MFMAs or "+a" asm operands - the 128 live accumulators next to 128 operand registers
+// make the compiler emit out-of-place MFMAs, accumulator copies at every branch and scratch
+// spills inside the MFMA loops.)  Every statement lists the whole accumulator file as clobbered,
+// so the compiler cannot keep a value of its own in an accumulator register across any of them;
+// tools/audit_gp4.py (run by the build) proves on the generated code that it never uses one.
+#define SL_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+#define SL_ALL_AGPRS                                                                               \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", SL_A10(1), SL_A10(2), SL_A10(3),   \
+        SL_A10(4), SL_A10(5), SL_A10(6), SL_A10(7), SL_A10(8), SL_A10(9), SL_A10(10), SL_A10(11),   \
+        SL_A10(12), SL_A10(13), SL_A10(14), SL_A10(15), SL_A10(16), SL_A10(17), SL_A10(18),        \
+        SL_A10(19), SL_A10(20), SL_A10(21), SL_A10(22), SL_A10(23), SL_A10(24), "a250", "a251",     \
+        "a252", "a253", "a254", "a255"
+
+template <int BASE>
+__device__ __forceinline__ void acc_zero16() {
+    asm volatile(
+        "v_accvgpr_write_b32 a%c0, 0\n\tv_accvgpr_write_b32 a%c1, 0\n\tv_accvgpr_write_b32 a%c2, 0\n\t"
+        "v_accvgpr_write_b32 a%c3, 0\n\tv_accvgpr_write_b32 a%c4, 0\n\tv_accvgpr_write_b32 a%c5, 0\n\t"
+        "v_accvgpr_write_b32 a%c6, 0\n\tv_accvgpr_write_b32 a%c7, 0\n\tv_accvgpr_write_b32 a%c8, 0\n\t"
+        "v_accvgpr_write_b32 a%c9, 0\n\tv_accvgpr_write_b32 a%c10, 0\n\tv_accvgpr_write_b32 a%c11, 0\n\t"
+        "v_accvgpr_write_b32 a%c12, 0\n\tv_accvgpr_write_b32 a%c13, 0\n\tv_accvgpr_write_b32 a%c14, 0\n\t"
+        "v_accvgpr_write_b32 a%c15, 0\n\ts_nop 3"
+        :
+        : "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3), "i"(BASE + 4), "i"(BASE + 5),
+          "i"(BASE + 6), "i"(BASE + 7), "i"(BASE + 8), "i"(BASE + 9), "i"(BASE + 10), "i"(BASE + 11),
+          "i"(BASE + 12), "i"(BASE + 13), "i"(BASE + 14), "i"(BASE + 15)
+        : SL_ALL_AGPRS);
+}
+template <int BASE = 0>
+__device__ __forceinline__ void acc_zero_all() {
+    acc_zero16<BASE>();
+    if constexpr (BASE + 16 < 256) acc_zero_all<BASE + 16>();
+}
+template <int N>
+__device__ __forceinline__ double acc_read() {
+    unsigned lo, hi;
+    asm volatile("v_accvgpr_read_b32 %0, a%c2\n\tv_accvgpr_read_b32 %1, a%c3\n\ts_nop 0"
+                 : "=v"(lo), "=v"(hi)
+                 : "i"(N), "i"(N + 1));
+    return __hiloint2double((int)hi, (int)lo);
+}
+// |a|^2 contributions of the panel: ssr[cb][rot] += acc(r, cb, rot)^2 over the row blocks
+template <int I = 0>
+__device__ __forceinline__ void acc_squares(double (&ssr)[CB][4]) {
+    const double v = acc_read<2 * I>();
+    ssr[(I / 4) % CB][I % 4] = fma(v, v, ssr[(I / 4) % CB][I % 4]);
+    if constexpr (I + 1 < R * CB * 4) acc_squares<I + 1>(ssr);
+}
+
+// eight MFMAs of one (row block, rotation): both slabs of the pair for the four cell blocks.  The
+// operands come straight from loads (the compiler's s_waitcnt precedes the statement); an
+// accumulate chain on one register needs no wait states.
+template <int RI, int ROT>
+__device__ __forceinline__ void group(const sl_d2& av, const BFrag& b) {
+    constexpr int N0 = 2 * ((RI * CB + 0) * 4 + ROT), N1 = 2 * ((RI * CB + 1) * 4 + ROT);
+    constexpr int N2 = 2 * ((RI * CB + 2) * 4 + ROT), N3 = 2 * ((RI * CB + 3) * 4 + ROT);
+    asm volatile(
+        "v_mfma_f64_4x4x4_4b_f64 a[%c10:%c11], %0, %2, a[%c10:%c11]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 a[%c12:%c13], %0, %4, a[%c12:%c13]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 a[%c14:%c15], %0, %6, a[%c14:%c15]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 a[%c16:%c17], %0, %8, a[%c16:%c17]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 a[%c10:%c11], %1, %3, a[%c10:%c11]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 a[%c12:%c13], %1, %5, a[%c12:%c13]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 a[%c14:%c15], %1, %7, a[%c14:%c15]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 a[%c16:%c17], %1, %9, a[%c16:%c17]"
+        :
+        : "v"(av.x), "v"(av.y), "v"(b.v[0].x), "v"(b.v[0].y), "v"(b.v[1].x), "v"(b.v[1].y),
+          "v"(b.v[2].x), "v"(b.v[2].y), "v"(b.v[3].x), "v"(b.v[3].y), "i"(N0), "i"(N0 + 1),
+          "i"(N1), "i"(N1 + 1), "i"(N2), "i"(N2 + 1), "i"(N3), "i"(N3 + 1)
+        : SL_ALL_AGPRS);
+}
+template <int R0, int ROT, int RI = R0>
+__device__ __forceinline__ void mfmas(const AFrag& a, const BFrag& b) {
+    if constexpr (RI < R) {
+        group<RI, ROT>(a.v[RI], b);
+        mfmas<R0, ROT, RI + 1>(a, b);
+    }
+}
+__device__ __forceinline__ void load_b(BFrag& b, const double* kxs, int off) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) b.v[cb] = *reinterpret_cast<const sl_d2*>(kxs + cb * 128 + off);
+}
+// A fragments of slab pair s2abs for the row blocks r >= R0: one coalesced 1 KiB buffer load per
+// fragment, the fragment's byte offset in the scalar operand
+template <int R0>
+__device__ __forceinline__ void load_a(AFrag& a, __amdgpu_buffer_rsrc_t rsrc, const int (&rowoff)[R],
+                                       int s2abs, int lane) {
+#pragma unroll
+    for (int r = R0; r < R; ++r)
+        a.v[r] = __builtin_bit_cast(
+            sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[r] + s2abs * 1024, 0));
+}
+// one slab pair: the four rotations, the k_x fragment of the next rotation (or of the next slab
+// pair's first rotation) requested before the MFMAs of the current one
+template <int R0>
+__device__ __forceinline__ void slab_pair(const AFrag& a, BFrag& be, BFrag& bo,
+                                          const double* kxs, const double* kxs_next,
+                                          const int (&boff)[4]) {
+    load_b(bo, kxs, boff[1]);
+    mfmas<R0, 0>(a, be);
+    load_b(be, kxs, boff[2]);
+    mfmas<R0, 1>(a, bo);
+    load_b(bo, kxs, boff[3]);
+    mfmas<R0, 2>(a, be);
+    load_b(be, kxs_next, boff[0]);
+    mfmas<R0, 3>(a, bo);
+}
+// one chunk of 64 training points against the row blocks r >= R0
+template <int R0>
+__device__ __forceinline__ void chunk(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
+                                      const int (&rowoff)[R], int ch, int lane, const int (&boff)[4]) {
+    AFrag a0, a1, a2;
+    BFrag be, bo;
+    load_a<R0>(a0, rsrc, rowoff, 8 * ch, lane);
+    load_a<R0>(a1, rsrc, rowoff, 8 * ch + 1, lane);
+    load_b(be, kxb, boff[0]);
+    for (int s2 = 0; s2 < 6; s2 += 3) {
+        const double* k0 = kxb + s2 * KXS2;
+        load_a<R0>(a2, rsrc, rowoff, 8 * ch + s2 + 2, lane);
+        slab_pair<R0>(a0, be, bo, k0, k0 + KXS2, boff);
+        load_a<R0>(a0, rsrc, rowoff, 8 * ch + s2 + 3, lane);
+        slab_pair<R0>(a1, be, bo, k0 + KXS2, k0 + 2 * KXS2, boff);
+        load_a<R0>(a1, rsrc, rowoff, 8 * ch + s2 + 4, lane);
+        slab_pair<R0>(a2, be, bo, k0 + 2 * KXS2, k0 + 3 * KXS2, boff);
+    }
+    slab_pair<R0>(a0, be, bo, kxb + 6 * KXS2, kxb + 7 * KXS2, boff);
+    slab_pair<R0>(a1, be, bo, kxb + 7 * KXS2, kxb + 7 * KXS2, boff);
+}
+// q = chunk index relative to the panel's diagonal band.  Row block r of a wavefront has its
+// diagonal in chunk r of the band: blocks r >= q are active (the diagonal block's fragments are
+// zero above the diagonal), blocks r < q lie above it; q < 0: every block is active.
+__device__ __forceinline__ void chunk_any(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
+                                          const int (&rowoff)[R], int q, int ch, int lane,
+                                          const int (&boff)[4]) {
+    switch (q) {
+        case 1: chunk<1>(rsrc, kxb, rowoff, ch, lane, boff); break;
+        case 2: chunk<2>(rsrc, kxb, rowoff, ch, lane, boff); break;
+        case 3: chunk<3>(rsrc, kxb, rowoff, ch, lane, boff); break;
+        case 4: chunk<4>(rsrc, kxb, rowoff, ch, lane, boff); break;
+        case 5: chunk<5>(rsrc, kxb, rowoff, ch, lane, boff); break;
+        case 6: chunk<6>(rsrc, kxb, rowoff, ch, lane, boff); break;
+        case 7: chunk<7>(rsrc, kxb, rowoff, ch, lane, boff); break;
+        default: chunk<0>(rsrc, kxb, rowoff, ch, lane, boff); break;
+    }
+}
+
+// a wave-uniform double held in scalar registers
+__device__ __forceinline__ double uniform(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+}  // namespace gp4
+
+// XSG: the scaled training inputs do not fit LDS and are read from L2 during generation.
+template <int DT, int MT, bool XSG>
+__global__ __launch_bounds__(256, 1) void k_gp_sweep4(
+    const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
+    const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
+    uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
+    int xs_doubles, int alpha_doubles, const double* __restrict__ points) {
+    using namespace gp4;
+    asm volatile("" ::: SL_ALL_AGPRS);           // the accumulator file belongs to the MFMA groups
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* xs_l = smem;                           // [p][n_pad]
+    double* alpha_l = xs_l + xs_doubles;           // [n_pad][dout] when it fits
+    double* kx_l = alpha_l + alpha_doubles;        // [2][KXBUF]
+    double* part_ss = kx_l + 2 * KXBUF;            // [W][4 rotations][C]
+    double* cell_mean = part_ss + W * 4 * C;       // [C][SL_D]
+    double* cell_err = cell_mean + C * SL_D;       // [C][SL_D]
+    double* cin = cell_err + C * SL_D;             // [C][SL_P] scaled GP inputs of the tile's cells
+    uint64_t* sv = reinterpret_cast<uint64_t*>(cin + C * SL_P);        // [W]
+    int64_t* si = reinterpret_cast<int64_t*>(sv + W);                  // [W]
+
+    const SlDims nd = sl_dims<DT, MT>(M);
+    const int d = nd.d, p = nd.p;
+    constexpr int DOUT_UNROLL = DT > 0 ? DT : SL_MAX_STATE_DIM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // = cell block this wave generates
+    const int lcol = lane & 15, lk = lane >> 4, blk = (lane >> 2) & 3, low = lane & 3;
+    int boff[4];
+#pragma unroll
+    for (int rot = 0; rot < 4; ++rot)
+        boff[rot] = 2 * (16 * lk + ((4 * ((blk + rot) & 3) + low) ^ (4 * lk)));
+    const int own = 2 * (16 * lk + (lcol ^ (4 * lk)));            // this lane's own (k, cell) item
+    // generation writes (lane = point jj of the chunk): slab pair jj >> 3, slab (jj >> 2) & 1, k = jj & 3
+    const int wbase = (lane >> 3) * KXS2 + wave * 128 + 32 * (lane & 3) + ((lane >> 2) & 1);
+    const int wswz = 4 * (lane & 3);
+    uint64_t best_v = ~0ull;
+    int64_t best_i = INT64_MAX;
+    int staged_head = -1;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t tile_base = lo + tile * C;
+        if (tile_base >= hi) {                     // padding tile: only clears mask bits
+            if (tid == 0) neg_bits[(tile_base - lo) >> 6] = 0ull;
+            continue;
+        }
+
+        for (int h = 0; h < gp.nheads; ++h) {
+            const SlGpHeadDev& hd = gp.head[h];
+            const int n_pad = hd.n_pad, dout = hd.dout;
+            const double variance = hd.variance;
+            const double* __restrict__ alphap = alpha_doubles > 0 ? alpha_l : hd.alpha;
+            const double* __restrict__ xs_glob = hd.xs;
+            __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void*)hd.mpack, 0, 0x7fffffff, 0x27000);
+            if (staged_head != h) {
+                __syncthreads();
+                if (!XSG)
+                    for (int k = tid; k < p * n_pad; k += W * 64) xs_l[k] = hd.xs[k];
+                if (alpha_doubles > 0)
+                    for (int k = tid; k < n_pad * dout; k += W * 64) alpha_l[k] = hd.alpha[k];
+                staged_head = h;
+            }
+            // scaled GP input [x, policy(x)] / lengthscales of the 64 cells (lane = cell of block `wave`)
+            if (lk == 0) {
+                double xg[SL_P], u[SL_M];
+                int64_t gidx = tile_base + 16 * wave + lcol;
+                gidx = gidx < hi ? gidx : hi - 1;
+                sl_cell_state(M, d, gidx, points, xg);
+                sl_policy_any<false>(M, nd, aux.tri, gidx, xg, u);
+                sl_append_action(nd, u, xg);
+#pragma unroll
+                for (int q = 0; q < SL_P; ++q)
+                    cin[(16 * wave + lcol) * SL_P + q] = (q < p) ? xg[q] * hd.inv_ls[q] : 0.0;
+            }
+            __syncthreads();
+            // Is the input affine in the cell index over this wavefront's 16 cells?  Then
+            // z_j(c) = |X_j - x(c)|^2 is quadratic in c and k_x a Gaussian sequence.
+            double x0[SL_P], dlt[SL_P], a2 = 0.0;
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < SL_P; ++q) {
+                if (q < p) {
+                    x0[q] = uniform(cin[(16 * wave) * SL_P + q]);
+                    dlt[q] = uniform(cin[(16 * wave + 1) * SL_P + q] - x0[q]);
+                    const double end = cin[(16 * wave + 15) * SL_P + q];
+                    ok = ok && fabs(end - fma(15.0, dlt[q], x0[q])) <= 1e-13 * fmax(1.0, fabs(end));
+                    a2 = fma(dlt[q], dlt[q], a2);
+                }
+            }
+            const bool affine = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+            a2 = uniform(a2);
+            const double qstep = uniform(sl_exp_nonpos(-a2));
+
+            double gmean[DOUT_UNROLL];
+#pragma unroll
+            for (int dd = 0; dd < DOUT_UNROLL; ++dd) gmean[dd] = 0.0;
+
+            // k_x chunk `ch` -> LDS buffer `buf` (lane = training point 64 ch + lane)
+            auto generate = [&](int ch, int buf) {
+                double* kxw = kx_l + buf * KXBUF + wbase;
+                const int j = 64 * ch + lane;
+                if (affine) {
+                    double z = 0.0, bj = 0.0;
+#pragma unroll
+                    for (int q = 0; q < SL_P; ++q) {
+                        if (q < p) {
+                            const double xv = XSG ? xs_glob[q * n_pad + j] : xs_l[q * n_pad + j];
+                            const double dq = xv - x0[q];
+                            z = fma(dq, dq, z);
+                            bj = fma(dq, dlt[q], bj);
+                        }
+                    }
+                    double e = variance * sl_exp_nonpos(-0.5 * z);
+                    double rho = sl_exp_nonpos(bj - 0.5 * a2);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        kxw[2 * (c ^ wswz)] = e;
+                        e *= rho;
+                        rho *= qstep;
+                    }
+                } else {
+                    double xv[SL_P];
+#pragma unroll
+                    for (int q = 0; q < SL_P; ++q)
+                        if (q < p) xv[q] = XSG ? xs_glob[q * n_pad + j] : xs_l[q * n_pad + j];
+                    for (int c = 0; c < 16; ++c) {
+                        double z = 0.0;
+#pragma unroll
+                        for (int q = 0; q < SL_P; ++q) {
+                            if (q < p) {
+                                const double dq = xv[q] - cin[(16 * wave + c) * SL_P + q];
+                                z = fma(dq, dq, z);
+                            }
+                        }
+                        kxw[2 * (c ^ wswz)] = variance * sl_exp_nonpos(-0.5 * z);
+                    }
+                }
+            };
+            // posterior mean k_x . alpha' from the LDS copy of a new chunk (lane = (k, cell))
+            auto mean_pass = [&](int ch, int buf) {
+                const double* kxr = kx_l + buf * KXBUF + wave * 128 + own;
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) {
+                    const sl_d2 kx = *reinterpret_cast<const sl_d2*>(kxr + s2 * KXS2);
+                    const int j = 64 * ch + 8 * s2 + lk;
+#pragma unroll
+                    for (int dd = 0; dd < DOUT_UNROLL; ++dd) {
+                        if (dd < dout) {
+                            gmean[dd] = fma(kx.x, alphap[j * dout + dd], gmean[dd]);
+                            gmean[dd] = fma(kx.y, alphap[(j + 4) * dout + dd], gmean[dd]);
+                        }
+                    }
+                }
+            };
+
+            const int npanels = n_pad / RP;
+            for (int pan = 0; pan < npanels; ++pan) {
+                acc_zero_all();
+                int rowoff[R];                     // byte offset of each owned row block's fragments
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int wsel = (r & 1) ? (W - 1 - wave) : wave;     // balance the triangle
+                    rowoff[r] = (pan * RB + r * W + wsel) * hd.nslab2 * 1024;
+                }
+                const int nchunks = (pan + 1) * (RP / 64);
+                const int first_new_chunk = pan * (RP / 64);     // chunks not generated before
+                generate(0, 0);
+                __syncthreads();
+                for (int ch = 0; ch < nchunks; ++ch) {
+                    const int buf = ch & 1;
+                    if (ch >= first_new_chunk) mean_pass(ch, buf);
+                    const int q = __builtin_amdgcn_readfirstlane(ch - 8 * pan);
+                    chunk_any(rsrc, kx_l + buf * KXBUF, rowoff, q, ch, lane, boff);
+                    if (ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
+                    __syncthreads();
+                }
+                // |a|^2 of this panel's rows.  The rows of a block live in the four lane groups
+                // (row = lane >> 4): fold them; every (wave, rotation) plane of part_ss then holds
+                // one partial sum per cell, owned by one lane (no other wave touches the plane).
+                asm volatile("s_nop 15\n\ts_nop 15" ::: SL_ALL_AGPRS);   // MFMA results -> reads
+                double ssr[CB][4];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int rot = 0; rot < 4; ++rot) ssr[cb][rot] = 0.0;
+                acc_squares(ssr);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int rot = 0; rot < 4; ++rot) {
+                        ssr[cb][rot] += __shfl_xor(ssr[cb][rot], 16, 64);
+                        ssr[cb][rot] += __shfl_xor(ssr[cb][rot], 32, 64);
+                    }
+                if (lane < 16) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int rot = 0; rot < 4; ++rot) {
+                            double* slot = part_ss + (wave * 4 + rot) * C + 16 * cb + 4 * ((blk + rot) & 3) + low;
+                            *slot = (pan == 0 ? 0.0 : *slot) + ssr[cb][rot];
+                        }
+                }
+            }
+#pragma unroll
+            for (int dd = 0; dd < DOUT_UNROLL; ++dd) {
+                gmean[dd] += __shfl_xor(gmean[dd], 16, 64);
+                gmean[dd] += __shfl_xor(gmean[dd], 32, 64);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int dd = 0; dd < DOUT_UNROLL; ++dd)
+                    if (dd < dout) cell_mean[(16 * wave + lane) * SL_D + hd.col0 + dd] = gmean[dd];
+            }
+            __syncthreads();
+            if (tid < C) {
+                double sumsq = 0.0;
+                for (int k = 0; k < W * 4; ++k) sumsq += part_ss[k * C + tid];
+                const double var = variance - sumsq;                       // functions.py:451
+                const double e = gp.beta * sqrt(var);                      // functions.py:514
+                for (int dd = 0; dd < dout; ++dd) cell_err[tid * SL_D + hd.col0 + dd] = e;
+            }
+            __syncthreads();
+        }
+
+        // ---- per-cell decrease check, mask word, failing-cell key (as k_gp_sweep) -------------------
+        const int64_t idx = tile_base + tid;
+        const bool valid = (tid < C) && (idx < hi);
+        bool negative = false;
+        double v_x = 0.0;
+        if (valid) {
+            double x[SL_P], u[SL_M], prior[SL_D], mean[SL_D], err[SL_D];
+            sl_cell_state(M, d, idx, points, x);
+            sl_policy_any<false>(M, nd, aux.tri, idx, x, u);
+            sl_append_action(nd, u, x);
+            sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);   // m(x*), functions.py:439
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) {
+                if (k < d) {
+                    mean[k] = cell_mean[tid * SL_D + k] + prior[k];
+                    err[k] = cell_err[tid * SL_D + k];
+                }
+            }
+            SlCellCheck c = sl_cell_check<false>(M, d, aux, x, mean, err);
+            negative = c.negative;
+            v_x = values ? values[idx - lo] : c.v_x;       // ordering key: lyapunov.py:512
+            if (dbg) {
+                double* o = dbg + (idx - lo) * (2 + 2 * d);
+                o[0] = c.decrease; o[1] = c.threshold;
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k) if (k < d) { o[2 + k] = mean[k]; o[2 + d + k] = err[k]; }
+            }
+        }
+        if (wave == 0) {
+            const uint64_t word = __ballot(negative);
+            uint64_t init = 0ull;
+            if (init_bits) init = init_bits[(tile_base - lo) >> 6];
+            if (lane == 0) neg_bits[(tile_base - lo) >> 6] = word;
+            const bool okc = negative || ((init >> lane) & 1ull);
+            if (valid && !okc) sl_key_min(best_v, best_i, sl_vbits(v_x), idx);
+        }
+        // (cell_mean / cell_err / cin are rewritten only after the next tile's barriers)
+    }
+    __syncthreads();
+    sl_block_reduce_key<true>(best_v, best_i, sv, si);
+    if (tid == 0) { partials[blockIdx.x].vbits = best_v; partials[blockIdx.x].index = best_i; }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static size_t gp4_fixed_lds() {
+    return sizeof(double) * (2 * gp4::KXBUF + gp4::W * 4 * gp4::C + 2 * gp4::C * SL_D + gp4::C * SL_P) +
+           2 * gp4::W * sizeof(uint64_t);
+}
+
+// true when the training inputs of every head fit LDS next to the fixed buffers
+bool sl_gp4_xs_fit(sl_ctx* ctx, int p) {
+    int xs_max = 0;
+    for (int h = 0; h < ctx->h_gp.nheads; ++h) {
+        const int v = p * ctx->gp_heads[h].n_pad;
+        xs_max = v > xs_max ? v : xs_max;
+    }
+    return gp4_fixed_lds() + sizeof(double) * ((xs_max + 1) & ~1) <= 160 * 1024;
+}
+
+template <int DT, int MT, bool XSG>
+static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
+                   const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
+                   int* nblocks, double* d_dbg, const double* d_points) {
+    const int64_t ntiles = (hi - lo + 63) / 64;
+    const int p = model.in_dim;
+    int xs_doubles = 0, alpha_doubles = 0;
+    for (int h = 0; h < ctx->h_gp.nheads; ++h) {
+        if (ctx->gp_heads[h].p != p)
+            return sl_fail(ctx, SL_ERR_INVALID, "GP head %d has input dim %d, model has %d", h,
+                           ctx->gp_heads[h].p, p);
+        if (ctx->gp_heads[h].n_pad % gp4::RP)
+            return sl_fail(ctx, SL_ERR_INVALID, "GP head %d: n_pad %d is not a multiple of %d", h,
+                           ctx->gp_heads[h].n_pad, gp4::RP);
+        const int v = p * ctx->gp_heads[h].n_pad, a = ctx->gp_heads[h].n_pad * ctx->gp_heads[h].dout;
+        xs_doubles = v > xs_doubles ? v : xs_doubles;
+        alpha_doubles = a > alpha_doubles ? a : alpha_doubles;
+    }
+    xs_doubles = XSG ? 0 : ((xs_doubles + 1) & ~1);          // keep the k_x buffers 16-byte aligned
+    alpha_doubles = (alpha_doubles + 1) & ~1;
+    size_t lds = gp4_fixed_lds() + sizeof(double) * xs_doubles;
+    if (lds + sizeof(double) * alpha_doubles <= 160 * 1024) lds += sizeof(double) * alpha_doubles;
+    else alpha_doubles = 0;                                   // alpha' then comes from L2
+    if (lds > 160 * 1024)
+        return sl_fail(ctx, SL_ERR_UNSUPPORTED, "GP training set too large for LDS staging "
+                                                "(%zu bytes needed)", lds);
+    auto kern = k_gp_sweep4<DT, MT, XSG>;
+    SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t blocks = ntiles < ctx->num_cu ? ntiles : ctx->num_cu;
+    if (blocks > SL_MAX_GRID) blocks = SL_MAX_GRID;
+    *nblocks = (int)blocks;
+    SlAux aux{ctx->d_tri, ctx->d_net};
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(gp4::W * 64), lds, ctx->stream, model,
+                       ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,
+                       ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, d_points);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+// Fast-path models (closed-form or per-vertex table policy, quadratic V) with panels of 512 rows.
+int sl_gp4_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
+                        const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
+                        int* nblocks, double* d_dbg, const double* d_points) {
+    const int variant = sl_dim_variant_of(model);
+    const bool xsg = !sl_gp4_xs_fit(ctx, model.in_dim);
+#define SL_GP4(D_, M_)                                                                            \
+    return xsg ? launch4<D_, M_, true>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,     \
+                                       nblocks, d_dbg, d_points)                                  \
+               : launch4<D_, M_, false>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,    \
+                                        nblocks, d_dbg, d_points)
+    switch (variant) {
+        case 1: SL_GP4(1, 1);
+        case 2: SL_GP4(2, 1);
+        case 3: SL_GP4(3, 1);
+        case 4: SL_GP4(4, 1);
+        default: break;
+    }
+#undef SL_GP4
+    return sl_fail(ctx, SL_ERR_UNSUPPORTED, "k_gp_sweep4 is compiled for 1..4 state dimensions and "
+                                            "one action dimension");
+}
+
+// models this kernel is instantiated for (the others stay on k_gp_sweep)
+bool sl_gp4_supports(const SlDevModel& model) {
+    return !sl_model_is_general(model) && sl_dim_variant_of(model) >= 1;
+}

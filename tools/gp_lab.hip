@@ -16,6 +16,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <functional>
 #include <vector>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -40,6 +42,7 @@ struct Problem {
     const double* xs;         // [P][n_pad]  training inputs / lengthscale
     const double* alpha;      // [n_pad][DOUT]
     const double* mpack;      // MFMA A fragments [row block 16][slab pair 8][lane 64][2]
+    const double* mstream;    // the same fragments in the order the V3 wavefronts consume them
     const double* linv;       // dense row-major [n_pad][n_pad] (naive reference only)
     double variance;
     double kgain[4];          // policy u = clamp(k . x, -1, 1)
@@ -64,6 +67,37 @@ __device__ __forceinline__ void cell_input(const Problem& pr, int64_t idx, doubl
 #pragma unroll
     for (int q = 0; q < 4; ++q) xg[q] = x[q] * pr.inv_ls[q];
     xg[4] = u * pr.inv_ls[4];
+}
+
+// exp(x) for moderate |x|: 13-term Taylor polynomial after range reduction (production's
+// sl_exp_nonpos), ~20 instructions, within 2 ulp
+__device__ __forceinline__ double fast_exp(double x) {
+    x = x < -800.0 ? -800.0 : x;
+    const double k = rint(x * 1.4426950408889634);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double q = 1.6059043836821613e-10;
+    q = fma(q, r, 2.08767569878681e-09);
+    q = fma(q, r, 2.505210838544172e-08);
+    q = fma(q, r, 2.755731922398589e-07);
+    q = fma(q, r, 2.7557319223985893e-06);
+    q = fma(q, r, 2.48015873015873e-05);
+    q = fma(q, r, 1.984126984126984e-04);
+    q = fma(q, r, 1.3888888888888889e-03);
+    q = fma(q, r, 8.333333333333333e-03);
+    q = fma(q, r, 4.1666666666666664e-02);
+    q = fma(q, r, 1.6666666666666666e-01);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return ldexp(q, (int)k);
+}
+
+// a wave-uniform double held in scalar registers
+__device__ __forceinline__ double uniform(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -266,20 +300,65 @@ __global__ __launch_bounds__(W * 64) void k_v1(const Problem pr, int64_t lo, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// V2: v_mfma_f64_4x4x4_4b_f64, one wavefront per SIMD (W = 4, 512 registers), R x CB x 4 rotations
-// of accumulators per wavefront.  A fragments = the 16x16x4 layout (block b of the instruction
-// = rows 4b..4b+3 of the 16-row block); the four 4-cell groups of a 16-cell block are paired
-// with the row groups by reading the k_x fragment rotated by 0/4/8/12 lanes per row of 16.
-//   GEN: 0 = no k_x generation (GEMM phase only, garbage results), 1 = exp per (point, cell)
-//   DIAG: 0 = the diagonal row block of a chunk runs all 8 slab pairs (zeros above the diagonal),
-//         1 = predicated on its count of slab pairs on or below the diagonal
+// V3: V2's structure with the accumulators at FIXED accumulator registers a[0:255], touched only
+// by inline-asm MFMA groups (no C++ data flow through them): control flow around the groups then
+// needs no phi copies, and every MFMA accumulates in place.  acc(r, cb, rot) = a[2 i : 2 i + 1],
+// i = (r * CB + cb) * 4 + rot.
 // ---------------------------------------------------------------------------------------------
-template <int R, int CB, int SKIP = 0>      // SKIP bit 0: no A loads, bit 1: no B loads (cost attribution)
-struct V2 {
+#define SL_A16(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+#define SL_ALL_AGPRS                                                                               \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", SL_A16(1), SL_A16(2), SL_A16(3),   \
+        SL_A16(4), SL_A16(5), SL_A16(6), SL_A16(7), SL_A16(8), SL_A16(9), SL_A16(10), SL_A16(11),   \
+        SL_A16(12), SL_A16(13), SL_A16(14), SL_A16(15), SL_A16(16), SL_A16(17), SL_A16(18),        \
+        SL_A16(19), SL_A16(20), SL_A16(21), SL_A16(22), SL_A16(23), SL_A16(24), "a250", "a251",     \
+        "a252", "a253", "a254", "a255"
+
+template <int BASE>
+__device__ __forceinline__ void acc_zero16() {
+    asm volatile(
+        "v_accvgpr_write_b32 a%c0, 0\n\tv_accvgpr_write_b32 a%c1, 0\n\tv_accvgpr_write_b32 a%c2, 0\n\t"
+        "v_accvgpr_write_b32 a%c3, 0\n\tv_accvgpr_write_b32 a%c4, 0\n\tv_accvgpr_write_b32 a%c5, 0\n\t"
+        "v_accvgpr_write_b32 a%c6, 0\n\tv_accvgpr_write_b32 a%c7, 0\n\tv_accvgpr_write_b32 a%c8, 0\n\t"
+        "v_accvgpr_write_b32 a%c9, 0\n\tv_accvgpr_write_b32 a%c10, 0\n\tv_accvgpr_write_b32 a%c11, 0\n\t"
+        "v_accvgpr_write_b32 a%c12, 0\n\tv_accvgpr_write_b32 a%c13, 0\n\tv_accvgpr_write_b32 a%c14, 0\n\t"
+        "v_accvgpr_write_b32 a%c15, 0\n\ts_nop 3"
+        :
+        : "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3), "i"(BASE + 4), "i"(BASE + 5),
+          "i"(BASE + 6), "i"(BASE + 7), "i"(BASE + 8), "i"(BASE + 9), "i"(BASE + 10), "i"(BASE + 11),
+          "i"(BASE + 12), "i"(BASE + 13), "i"(BASE + 14), "i"(BASE + 15));
+}
+template <int N>
+__device__ __forceinline__ double acc_read() {
+    unsigned lo, hi;
+    asm volatile("v_accvgpr_read_b32 %0, a%c2\n\tv_accvgpr_read_b32 %1, a%c3\n\ts_nop 0"
+                 : "=v"(lo), "=v"(hi)
+                 : "i"(N), "i"(N + 1));
+    return __hiloint2double((int)hi, (int)lo);
+}
+template <int I, int NACC>
+struct AccLoop {
+    static __device__ __forceinline__ void zero() {
+        acc_zero16<2 * I>();
+        if constexpr (2 * I + 16 < 2 * NACC) AccLoop<I + 8, NACC>::zero();
+    }
+};
+
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+// OPT bit 0: A fragments through buffer loads (scalar offset per fragment, no 64-bit VALU address
+// arithmetic); bit 2: the diagonal row block of a chunk runs only its slab pairs on or below the
+// diagonal
+template <int R, int CB, int SKIP = 0, int OPT = 0>
+struct V3 {
     static constexpr int W = 4, C = 16 * CB, RP = 16 * R * W, RB = R * W;
-    static constexpr int KXBUF = 16 * CB * 64;
-    static_assert(CB == W, "wave w generates cell block w");
-    struct BFrag { d2 v[CB]; };                         // one rotation: [cell block]
+    // k_x chunk in LDS: [slab pair 8][cell block CB][k 4][slot 16][slab of the pair 2]; the slot
+    // of cell c16 in row k is c16 ^ 4k and slab pairs are 4 doubles apart modulo the banks, so
+    // that both the fragment reads (lane = (k, cell), 16 B) and the generation writes (lane =
+    // training point, 8 B, one cell per instruction) are free of bank conflicts
+    static constexpr int KXS2 = CB * 128 + 4;
+    static constexpr int KXBUF = 8 * KXS2;
+    static_assert(CB == 4 && R * CB * 4 * 2 <= 256, "accumulators must fit a[0:255]");
+    struct BFrag { d2 v[CB]; };
     struct AFrag { d2 v[R]; };
 
     static __device__ __forceinline__ void load_b(BFrag& b, const double* kxs, int off) {
@@ -287,96 +366,176 @@ struct V2 {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) b.v[cb] = *reinterpret_cast<const d2*>(kxs + cb * 128 + off);
     }
-    // row blocks r >= r0 are active in this chunk: one uniform multiway branch into the unrolled
-    // sequence of row blocks (fall-through), no per-block predicates
-#define SL_FROM(R0_, BODY)                                                                       \
-    switch (R0_) {                                                                               \
-        case 0: if (R > 0) { BODY(0) } [[fallthrough]];                                          \
-        case 1: if (R > 1) { BODY(1) } [[fallthrough]];                                          \
-        case 2: if (R > 2) { BODY(2) } [[fallthrough]];                                          \
-        case 3: if (R > 3) { BODY(3) } [[fallthrough]];                                          \
-        case 4: if (R > 4) { BODY(4) } [[fallthrough]];                                          \
-        case 5: if (R > 5) { BODY(5) } [[fallthrough]];                                          \
-        case 6: if (R > 6) { BODY(6) } [[fallthrough]];                                          \
-        case 7: if (R > 7) { BODY(7) } [[fallthrough]];                                          \
-        default: break;                                                                          \
-    }
+    // R0 = first active row block of the chunk (static: one straight-line body per value)
+    template <int R0>
     static __device__ __forceinline__ void load_a(AFrag& a, const Problem& pr, const int (&rowblk)[R],
-                                                  int r0, int s2abs, int lane) {
+                                                  int s2abs, int lane, int abase = 0) {
         if (SKIP & 1) return;
-#define SL_LOAD_A(r_)                                                                            \
-    {                                                                                            \
-        constexpr int r = (r_) < R ? (r_) : 0;                                                   \
-        const double* base = pr.mpack + ((size_t)rowblk[r] * pr.nslab2 + (size_t)s2abs) * 128;   \
-        a.v[r] = *reinterpret_cast<const d2*>(base + lane * 2);                                  \
+        if (OPT & 1) {
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((OPT & 2) ? pr.mstream : pr.mpack), 0, 0x7fffffff, 0x27000);
+#pragma unroll
+            for (int r = R0; r < R; ++r) {
+                int soff = (rowblk[r] * pr.nslab2 + s2abs) * 1024;
+                if (OPT & 2) soff = abase + ((s2abs & 7) * R + r) * 1024;   // stream order
+                if (SKIP & 4) soff = r * 1024;                      // L1-resident
+                if (SKIP & 8) soff &= (256 * 1024 - 1);             // L2-resident 256 KB window
+                a.v[r] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, soff, 0));
+            }
+            return;
+        }
+#pragma unroll
+        for (int r = R0; r < R; ++r) {
+            const double* base = pr.mpack + ((size_t)rowblk[r] * pr.nslab2 + (size_t)s2abs) * 128;
+            a.v[r] = *reinterpret_cast<const d2*>(base + lane * 2);
+        }
     }
-        SL_FROM(r0, SL_LOAD_A)
-#undef SL_LOAD_A
+    // eight MFMAs of one (row block, rotation): both slabs of the pair for the four cell blocks
+    template <int RI, int ROT>
+    static __device__ __forceinline__ void group(const d2& av, const BFrag& b) {
+        constexpr int N0 = 2 * ((RI * CB + 0) * 4 + ROT), N1 = 2 * ((RI * CB + 1) * 4 + ROT);
+        constexpr int N2 = 2 * ((RI * CB + 2) * 4 + ROT), N3 = 2 * ((RI * CB + 3) * 4 + ROT);
+        if (OPT & 16) {
+            asm volatile(
+                "v_mfma_f64_4x4x4_4b_f64 a[%c10:%c11], %0, %2, a[%c10:%c11]\n\t"
+                "v_mfma_f64_4x4x4_4b_f64 a[%c12:%c13], %0, %4, a[%c12:%c13]\n\t"
+                "v_mfma_f64_4x4x4_4b_f64 a[%c14:%c15], %0, %6, a[%c14:%c15]\n\t"
+                "v_mfma_f64_4x4x4_4b_f64 a[%c16:%c17], %0, %8, a[%c16:%c17]\n\t"
+                "v_mfma_f64_4x4x4_4b_f64 a[%c10:%c11], %1, %3, a[%c10:%c11]\n\t"
+                "v_mfma_f64_4x4x4_4b_f64 a[%c12:%c13], %1, %5, a[%c12:%c13]\n\t"
+                "v_mfma_f64_4x4x4_4b_f64 a[%c14:%c15], %1, %7, a[%c14:%c15]\n\t"
+                "v_mfma_f64_4x4x4_4b_f64 a[%c16:%c17], %1, %9, a[%c16:%c17]"
+                :
+                : "v"(av.x), "v"(av.y), "v"(b.v[0].x), "v"(b.v[0].y), "v"(b.v[1].x), "v"(b.v[1].y),
+                  "v"(b.v[2].x), "v"(b.v[2].y), "v"(b.v[3].x), "v"(b.v[3].y), "i"(N0), "i"(N0 + 1),
+                  "i"(N1), "i"(N1 + 1), "i"(N2), "i"(N2 + 1), "i"(N3), "i"(N3 + 1));
+            return;
+        }
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_mfma_f64_4x4x4_4b_f64 a[%c10:%c11], %0, %2, a[%c10:%c11]\n\t"
+            "v_mfma_f64_4x4x4_4b_f64 a[%c12:%c13], %0, %4, a[%c12:%c13]\n\t"
+            "v_mfma_f64_4x4x4_4b_f64 a[%c14:%c15], %0, %6, a[%c14:%c15]\n\t"
+            "v_mfma_f64_4x4x4_4b_f64 a[%c16:%c17], %0, %8, a[%c16:%c17]\n\t"
+            "v_mfma_f64_4x4x4_4b_f64 a[%c10:%c11], %1, %3, a[%c10:%c11]\n\t"
+            "v_mfma_f64_4x4x4_4b_f64 a[%c12:%c13], %1, %5, a[%c12:%c13]\n\t"
+            "v_mfma_f64_4x4x4_4b_f64 a[%c14:%c15], %1, %7, a[%c14:%c15]\n\t"
+            "v_mfma_f64_4x4x4_4b_f64 a[%c16:%c17], %1, %9, a[%c16:%c17]"
+            :
+            : "v"(av.x), "v"(av.y), "v"(b.v[0].x), "v"(b.v[0].y), "v"(b.v[1].x), "v"(b.v[1].y),
+              "v"(b.v[2].x), "v"(b.v[2].y), "v"(b.v[3].x), "v"(b.v[3].y), "i"(N0), "i"(N0 + 1),
+              "i"(N1), "i"(N1 + 1), "i"(N2), "i"(N2 + 1), "i"(N3), "i"(N3 + 1));
     }
-    template <int ROT>
-    static __device__ __forceinline__ void mfmas(double (&acc)[R][CB][4], const AFrag& a,
-                                                 const BFrag& b, int r0) {
-#define SL_GROUP(r_)                                                                             \
-    {                                                                                            \
-        constexpr int r = (r_) < R ? (r_) : 0;                                                   \
-        _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                        \
-            acc[r][cb][ROT] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[r].x, b.v[cb].x,            \
-                                                                  acc[r][cb][ROT], 0, 0, 0);     \
-        _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                        \
-            acc[r][cb][ROT] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[r].y, b.v[cb].y,            \
-                                                                  acc[r][cb][ROT], 0, 0, 0);     \
+    // DG: the chunk has a diagonal row block (block R0), active while `diag_on`
+    template <int R0, bool DG, int ROT, int RI = R0>
+    static __device__ __forceinline__ void mfmas(const AFrag& a, const BFrag& b, bool diag_on) {
+        if constexpr (RI < R) {
+            if (DG && RI == R0) {
+                if (diag_on) group<RI, ROT>(a.v[RI], b);
+            } else {
+                group<RI, ROT>(a.v[RI], b);
+            }
+            mfmas<R0, DG, ROT, RI + 1>(a, b, diag_on);
+        }
     }
-        SL_FROM(r0, SL_GROUP)
-#undef SL_GROUP
-    }
-    // one slab pair: the four rotations, the k_x fragment of the next rotation (or of the next
-    // slab pair's first rotation) requested before the MFMAs of the current one
-    static __device__ __forceinline__ void slab_pair(double (&acc)[R][CB][4], const AFrag& a,
-                                                     BFrag& be, BFrag& bo, const double* kxs,
-                                                     const double* kxs_next, int r0,
-                                                     const int (&boff)[4]) {
+    template <int R0, bool DG>
+    static __device__ __forceinline__ void slab_pair(const AFrag& a, BFrag& be, BFrag& bo,
+                                                     const double* kxs, const double* kxs_next,
+                                                     const int (&boff)[4], bool diag_on) {
         load_b(bo, kxs, boff[1]);
-        mfmas<0>(acc, a, be, r0);
+        mfmas<R0, DG, 0>(a, be, diag_on);
         load_b(be, kxs, boff[2]);
-        mfmas<1>(acc, a, bo, r0);
+        mfmas<R0, DG, 1>(a, bo, diag_on);
         load_b(bo, kxs, boff[3]);
-        mfmas<2>(acc, a, be, r0);
+        mfmas<R0, DG, 2>(a, be, diag_on);
         load_b(be, kxs_next, boff[0]);
-        mfmas<3>(acc, a, bo, r0);
+        mfmas<R0, DG, 3>(a, bo, diag_on);
     }
-    // one chunk of 64 training points: A fragments in ping-pong register sets, those of slab pair
-    // s2 + 1 requested before the MFMAs of slab pair s2
-    static __device__ __forceinline__ void chunk(double (&acc)[R][CB][4], const Problem& pr,
-                                                 const double* kxb, const int (&rowblk)[R],
-                                                 int r0, int ch, int lane, const int (&boff)[4]) {
-        AFrag a0, a1;
-        BFrag be, bo;
-        if (SKIP) {
+    template <int R0, bool DG>
+    static __device__ __forceinline__ void chunk(const Problem& pr, const double* kxb,
+                                                 const int (&rowblk)[R], int ch, int lane,
+                                                 const int (&boff)[4], int dc, int abase) {
+        if constexpr (R0 < R) {
+            AFrag a0, a1;
+            BFrag be, bo;
+            if (SKIP) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) a0.v[r] = a1.v[r] = (d2){1.0 + lane * 1e-9, 1.0 - lane * 1e-9};
+                for (int r = 0; r < R; ++r) a0.v[r] = a1.v[r] = (d2){1.0 + lane * 1e-9, 1.0 - lane * 1e-9};
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) be.v[cb] = bo.v[cb] = (d2){1e-3 * lane, 1e-3};
+                for (int cb = 0; cb < CB; ++cb) be.v[cb] = bo.v[cb] = (d2){1e-3 * lane, 1e-3};
+            }
+            if (OPT & 8) {
+                // A fragments requested two slab pairs ahead (three register sets)
+                AFrag a2;
+                load_a<R0>(a0, pr, rowblk, 8 * ch, lane, abase);
+                load_a<R0>(a1, pr, rowblk, 8 * ch + 1, lane, abase);
+                load_b(be, kxb, boff[0]);
+                for (int s2 = 0; s2 < 6; s2 += 3) {
+                    const double* k0 = kxb + s2 * KXS2;
+                    load_a<R0>(a2, pr, rowblk, 8 * ch + s2 + 2, lane, abase);
+                    slab_pair<R0, DG>(a0, be, bo, k0, k0 + KXS2, boff, s2 < dc);
+                    load_a<R0>(a0, pr, rowblk, 8 * ch + s2 + 3, lane, abase);
+                    slab_pair<R0, DG>(a1, be, bo, k0 + KXS2, k0 + 2 * KXS2, boff, s2 + 1 < dc);
+                    load_a<R0>(a1, pr, rowblk, 8 * ch + s2 + 4, lane, abase);
+                    slab_pair<R0, DG>(a2, be, bo, k0 + 2 * KXS2, k0 + 3 * KXS2, boff, s2 + 2 < dc);
+                }
+                slab_pair<R0, DG>(a0, be, bo, kxb + 6 * KXS2, kxb + 7 * KXS2, boff, 6 < dc);
+                slab_pair<R0, DG>(a1, be, bo, kxb + 7 * KXS2, kxb + 7 * KXS2, boff, 7 < dc);
+                return;
+            }
+            load_a<R0>(a0, pr, rowblk, 8 * ch, lane, abase);
+            load_b(be, kxb, boff[0]);
+            for (int s2 = 0; s2 < 8; s2 += 2) {
+                const double* k0 = kxb + s2 * KXS2;
+                const double* k1 = k0 + KXS2;
+                const double* k2 = (s2 + 2 < 8) ? k1 + KXS2 : k1;
+                load_a<R0>(a1, pr, rowblk, 8 * ch + s2 + 1, lane, abase);
+                slab_pair<R0, DG>(a0, be, bo, k0, k1, boff, s2 < dc);
+                if (s2 + 2 < 8) load_a<R0>(a0, pr, rowblk, 8 * ch + s2 + 2, lane, abase);
+                slab_pair<R0, DG>(a1, be, bo, k1, k2, boff, s2 + 1 < dc);
+            }
         }
-        load_a(a0, pr, rowblk, r0, 8 * ch, lane);
-        load_b(be, kxb, boff[0]);
-        for (int s2 = 0; s2 < 8; s2 += 2) {
-            const double* k0 = kxb + s2 * CB * 128;
-            const double* k1 = k0 + CB * 128;
-            const double* k2 = (s2 + 2 < 8) ? k1 + CB * 128 : k1;
-            load_a(a1, pr, rowblk, r0, 8 * ch + s2 + 1, lane);
-            slab_pair(acc, a0, be, bo, k0, k1, r0, boff);
-            if (s2 + 2 < 8) load_a(a0, pr, rowblk, r0, 8 * ch + s2 + 2, lane);
-            slab_pair(acc, a1, be, bo, k1, k2, r0, boff);
+    }
+    // q = chunk index relative to the panel's diagonal band (q < 0: every block is full)
+    static __device__ __forceinline__ void chunk_any(const Problem& pr, const double* kxb,
+                                                     const int (&rowblk)[R], int q, int ch, int lane,
+                                                     const int (&boff)[4], int wave, int pan) {
+        constexpr bool DG = (OPT & 4) != 0;
+        // stream order: chunks of panel 0, then of panel 1, ...; per chunk [wave][slab pair][r]
+        const int abase = ((4 * pan * (pan + 1) + ch) * W + wave) * (8 * R * 1024);
+        int dc = 8;
+        if (DG && q >= 0) dc = 2 * ((q & 1) ? (W - 1 - wave) : wave) + 2;
+        switch (q) {
+            case 0: chunk<0, DG>(pr, kxb, rowblk, ch, lane, boff, dc, abase); break;
+            case 1: chunk<1, DG>(pr, kxb, rowblk, ch, lane, boff, dc, abase); break;
+            case 2: chunk<2, DG>(pr, kxb, rowblk, ch, lane, boff, dc, abase); break;
+            case 3: chunk<3, DG>(pr, kxb, rowblk, ch, lane, boff, dc, abase); break;
+            case 4: chunk<4, DG>(pr, kxb, rowblk, ch, lane, boff, dc, abase); break;
+            case 5: chunk<5, DG>(pr, kxb, rowblk, ch, lane, boff, dc, abase); break;
+            case 6: chunk<6, DG>(pr, kxb, rowblk, ch, lane, boff, dc, abase); break;
+            case 7: chunk<7, DG>(pr, kxb, rowblk, ch, lane, boff, dc, abase); break;
+            default: chunk<0, false>(pr, kxb, rowblk, ch, lane, boff, 8, abase); break;
         }
+    }
+    template <int I>
+    static __device__ __forceinline__ void squares(double (&ssr)[CB][4]) {
+        // I = (r * CB + cb) * 4 + rot
+        const double v = acc_read<2 * I>();
+        ssr[(I / 4) % CB][I % 4] = fma(v, v, ssr[(I / 4) % CB][I % 4]);
+        if constexpr (I + 1 < R * CB * 4) squares<I + 1>(ssr);
     }
 };
 
-template <int R, int CB, int GEN, int SKIP>
-__global__ __launch_bounds__(256, 1) void k_v2(const Problem pr, int64_t lo, int64_t ntiles,
+template <int R, int CB, int GEN, int SKIP, int OPT = 0>
+__global__ __launch_bounds__(256, 1) void k_v3(const Problem pr, int64_t lo, int64_t ntiles,
                                                double* __restrict__ ss_out,
                                                double* __restrict__ mean_out) {
-    using K = V2<R, CB, SKIP>;
-    constexpr int W = K::W, C = K::C, RP = K::RP, RB = K::RB, KXBUF = K::KXBUF;
+    // GEN: 0 none, 1 exp (library) per (cell, point), lane = (k, cell); 3 the same with fast_exp;
+    //      2 lane = training point, geometric recurrence along the 16 cells of the wavefront's
+    //        cell block where the GP input is affine in the cell index, mean from the LDS copy
+    using K = V3<R, CB, SKIP, OPT>;
+    constexpr int W = K::W, C = K::C, RP = K::RP, RB = K::RB, KXBUF = K::KXBUF, KXS2 = K::KXS2;
+    asm volatile("" ::: SL_ALL_AGPRS);               // the accumulator file belongs to the MFMA groups
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n_pad = pr.n_pad;
     double* xs_l = smem;
@@ -384,19 +543,48 @@ __global__ __launch_bounds__(256, 1) void k_v2(const Problem pr, int64_t lo, int
     double* kx_l = alpha_l + n_pad * DOUT;
     double* part_ss = kx_l + 2 * KXBUF;            // [W][4 rot][C]
     double* cell_m = part_ss + W * 4 * C;          // [C][DOUT]
+    double* cin = cell_m + C * DOUT;               // [C][P] GP inputs of the tile's cells
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lcol = lane & 15, lk = lane >> 4, blk = (lane >> 2) & 3, low = lane & 3;
     int boff[4];
 #pragma unroll
-    for (int rot = 0; rot < 4; ++rot) boff[rot] = 2 * (16 * lk + 4 * ((blk + rot) & 3) + low);
+    for (int rot = 0; rot < 4; ++rot)
+        boff[rot] = 2 * (16 * lk + ((4 * ((blk + rot) & 3) + low) ^ (4 * lk)));
+    const int own = 2 * (16 * lk + (lcol ^ (4 * lk)));            // this lane's own (k, cell) item
+    // generation writes of GEN 2: lane = point jj of the chunk -> slab pair jj >> 3, slab (jj >> 2) & 1,
+    // row k = jj & 3
+    const int wbase = (lane >> 3) * KXS2 + wave * 128 + 32 * (lane & 3) + ((lane >> 2) & 1);
     for (int k = tid; k < P * n_pad; k += W * 64) xs_l[k] = pr.xs[k];
     for (int k = tid; k < n_pad * DOUT; k += W * 64) alpha_l[k] = pr.alpha[k];
     __syncthreads();
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t tile_base = lo + tile * C;
         double xg[P];
-        cell_input(pr, tile_base + 16 * wave + lcol, xg);      // this wave generates cell block `wave`
+        cell_input(pr, tile_base + 16 * wave + lcol, xg);
+        // recurrence set-up: is the GP input affine in the cell index over this wave's 16 cells?
+        double x0[P], dlt[P], A2 = 0.0, Q = 1.0;
+        bool affine = false;
+        if (GEN == 2) {
+            if (lk == 0) {
+#pragma unroll
+                for (int q = 0; q < P; ++q) cin[(16 * wave + lcol) * P + q] = xg[q];
+            }
+            __syncthreads();
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                x0[q] = uniform(cin[(16 * wave) * P + q]);
+                dlt[q] = uniform(cin[(16 * wave + 1) * P + q] - x0[q]);
+                const double end = cin[(16 * wave + 15) * P + q];
+                const double pred = fma(15.0, dlt[q], x0[q]);
+                ok = ok && fabs(end - pred) <= 1e-13 * fmax(1.0, fabs(end));
+                A2 = fma(dlt[q], dlt[q], A2);
+            }
+            affine = __builtin_amdgcn_readfirstlane((int)ok) != 0;
+            A2 = uniform(A2);
+            Q = uniform(fast_exp(-A2));
+        }
         double ssr[CB][4], gmean[DOUT];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
@@ -406,38 +594,86 @@ __global__ __launch_bounds__(256, 1) void k_v2(const Problem pr, int64_t lo, int
         for (int dd = 0; dd < DOUT; ++dd) gmean[dd] = 0.0;
         const int npanels = n_pad / RP;
         for (int pan = 0; pan < npanels; ++pan) {
-            double acc[R][CB][4];
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                    for (int rot = 0; rot < 4; ++rot) acc[r][cb][rot] = 0.0;
+            AccLoop<0, R * CB * 4>::zero();
             int rowblk[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int wsel = (r & 1) ? (W - 1 - wave) : wave;     // balance the triangle
+                const int wsel = (r & 1) ? (W - 1 - wave) : wave;
                 rowblk[r] = pan * RB + r * W + wsel;
             }
             const int nchunks = (pan + 1) * (RP / 64);
             const int first_new_chunk = pan * (RP / 64);
             auto generate = [&](int ch, int buf) {
                 if (GEN == 0) return;
+                double* kxw = kx_l + buf * KXBUF;
+                if (GEN == 2 && affine) {
+                    const int j = 64 * ch + lane;
+                    double z = 0.0, bj = 0.0;
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        const double d = xs_l[q * n_pad + j] - x0[q];
+                        z = fma(d, d, z);
+                        bj = fma(d, dlt[q], bj);
+                    }
+                    double e = pr.variance * fast_exp(-0.5 * z);
+                    double rho = fast_exp(bj - 0.5 * A2);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        kxw[wbase + 2 * (c ^ (4 * (lane & 3)))] = e;
+                        e *= rho;
+                        rho *= Q;
+                    }
+                    return;
+                }
+                if (GEN == 2) {                    // not affine: one exp per (point, cell), lane = point
+                    const int j = 64 * ch + lane;
+                    for (int c = 0; c < 16; ++c) {
+                        double z = 0.0;
+#pragma unroll
+                        for (int q = 0; q < P; ++q) {
+                            const double d = xs_l[q * n_pad + j] - cin[(16 * wave + c) * P + q];
+                            z = fma(d, d, z);
+                        }
+                        kxw[wbase + 2 * (c ^ (4 * (lane & 3)))] = pr.variance * fast_exp(-0.5 * z);
+                    }
+                    return;
+                }
                 const bool add_mean = ch >= first_new_chunk;
                 for (int s = 0; s < 16; ++s) {
                     const int j = 64 * ch + 4 * s + lk;
                     double z = 0.0;
 #pragma unroll
                     for (int q = 0; q < P; ++q) {
-                        const double dlt = xs_l[q * n_pad + j] - xg[q];
-                        z = fma(dlt, dlt, z);
+                        const double d = xs_l[q * n_pad + j] - xg[q];
+                        z = fma(d, d, z);
                     }
-                    const double kx = pr.variance * exp(-0.5 * z);
+                    const double kx = pr.variance * (GEN == 3 ? fast_exp(-0.5 * z) : exp(-0.5 * z));
                     if (add_mean) {
 #pragma unroll
                         for (int dd = 0; dd < DOUT; ++dd) gmean[dd] = fma(kx, alpha_l[j * DOUT + dd], gmean[dd]);
                     }
-                    kx_l[buf * KXBUF + ((((s >> 1) * CB + wave) * 64 + lane) << 1) + (s & 1)] = kx;
+                    kxw[(s >> 1) * KXS2 + wave * 128 + own + (s & 1)] = kx;
+                }
+            };
+            // GEN 2: posterior mean from the LDS copy of a freshly generated chunk (lane = (k, cell))
+            auto mean_pass = [&](int ch, int buf) {
+                const double* kxr = kx_l + buf * KXBUF + wave * 128 + own;
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) {
+                    const d2 kx = *reinterpret_cast<const d2*>(kxr + s2 * KXS2);
+                    const int j = 64 * ch + 8 * s2 + lk;
+                    const d2 a0 = *reinterpret_cast<const d2*>(alpha_l + j * DOUT);
+                    const d2 a1 = *reinterpret_cast<const d2*>(alpha_l + j * DOUT + 2);
+                    const d2 b0 = *reinterpret_cast<const d2*>(alpha_l + (j + 4) * DOUT);
+                    const d2 b1 = *reinterpret_cast<const d2*>(alpha_l + (j + 4) * DOUT + 2);
+                    gmean[0] = fma(kx.x, a0.x, gmean[0]);
+                    gmean[1] = fma(kx.x, a0.y, gmean[1]);
+                    gmean[2] = fma(kx.x, a1.x, gmean[2]);
+                    gmean[3] = fma(kx.x, a1.y, gmean[3]);
+                    gmean[0] = fma(kx.y, b0.x, gmean[0]);
+                    gmean[1] = fma(kx.y, b0.y, gmean[1]);
+                    gmean[2] = fma(kx.y, b1.x, gmean[2]);
+                    gmean[3] = fma(kx.y, b1.y, gmean[3]);
                 }
             };
             generate(0, 0);
@@ -445,25 +681,15 @@ __global__ __launch_bounds__(256, 1) void k_v2(const Problem pr, int64_t lo, int
             for (int ch = 0; ch < nchunks; ++ch) {
                 const int buf = ch & 1;
                 const double* kxb = kx_l + buf * KXBUF;
-                // row block r of this wave has its diagonal in chunk 8 pan + r: blocks r >= q run
-                // all 8 slab pairs of the chunk (the diagonal block's fragments are zero above
-                // the diagonal), blocks r < q lie above the diagonal
-                const int q = ch - 8 * pan;
-                const int r0 = __builtin_amdgcn_readfirstlane(q < 0 ? 0 : q);
-                K::chunk(acc, pr, kxb, rowblk, r0, ch, lane, boff);
+                if (GEN == 2 && ch >= first_new_chunk) mean_pass(ch, buf);
+                const int q = __builtin_amdgcn_readfirstlane(ch - 8 * pan);
+                K::chunk_any(pr, kxb, rowblk, q, ch, lane, boff, wave, pan);
                 if (ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
                 __syncthreads();
             }
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                    for (int rot = 0; rot < 4; ++rot)
-                        ssr[cb][rot] = fma(acc[r][cb][rot], acc[r][cb][rot], ssr[cb][rot]);
+            asm volatile("s_nop 15\n\ts_nop 15");       // MFMA results -> accumulator reads
+            K::template squares<0>(ssr);
         }
-        // rows of a block live in the four lane groups (row = lane >> 4): fold them, then every
-        // (wave, rotation) plane holds one partial sum per cell
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -511,7 +737,6 @@ static double time_ms(F launch, int reps) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    launch();
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
     for (int k = 0; k < reps; ++k) launch();
@@ -547,11 +772,35 @@ int main(int argc, char** argv) {
                         (row < n && col <= row) ? linv[(size_t)row * n_pad + col] : 0.0;
                 }
         }
+    // stream-ordered copy for V3 (W = 4, R = 8): [panel][chunk][wave][slab pair][r][lane][2]
+    std::vector<double> mstream;
+    {
+        const int W = 4, R = 8, RB = 32;
+        const int npan = n_pad / (16 * RB);
+        size_t total = 0;
+        for (int pan = 0; pan < npan; ++pan) total += (size_t)8 * (pan + 1);
+        mstream.assign(total * W * 8 * R * 128, 0.0);
+        size_t rec = 0;
+        for (int pan = 0; pan < npan; ++pan)
+            for (int ch = 0; ch < 8 * (pan + 1); ++ch, ++rec)
+                for (int w = 0; w < W; ++w)
+                    for (int s2 = 0; s2 < 8; ++s2)
+                        for (int r = 0; r < R; ++r) {
+                            const int wsel = (r & 1) ? (W - 1 - w) : w;
+                            const int I = pan * RB + r * W + wsel, S2 = 8 * ch + s2;
+                            const double* src = &mpack[((size_t)I * nslab2 + S2) * 128];
+                            double* dst = &mstream[(((rec * W + w) * 8 + s2) * R + r) * 128];
+                            memcpy(dst, src, 128 * sizeof(double));
+                        }
+    }
     Problem pr;
     pr.n = n; pr.n_pad = n_pad; pr.nslab2 = nslab2; pr.variance = 0.03 * 0.03;
     const double kg[4] = {0.9, 2.1, 0.7, 0.4};
     for (int q = 0; q < 4; ++q) pr.kgain[q] = kg[q];
     for (int q = 0; q < P; ++q) pr.inv_ls[q] = 1.0 / 1.5;
+    double* d_mstream;
+    CK(hipMalloc(&d_mstream, mstream.size() * 8));
+    CK(hipMemcpy(d_mstream, mstream.data(), mstream.size() * 8, hipMemcpyHostToDevice));
     double *d_xs, *d_alpha, *d_mpack, *d_linv, *d_ss, *d_mean, *d_ss_ref, *d_mean_ref;
     CK(hipMalloc(&d_xs, xs.size() * 8));
     CK(hipMalloc(&d_alpha, alpha.size() * 8));
@@ -565,7 +814,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_alpha, alpha.data(), alpha.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_mpack, mpack.data(), mpack.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_linv, linv.data(), linv.size() * 8, hipMemcpyHostToDevice));
-    pr.xs = d_xs; pr.alpha = d_alpha; pr.mpack = d_mpack; pr.linv = d_linv;
+    pr.xs = d_xs; pr.alpha = d_alpha; pr.mpack = d_mpack; pr.linv = d_linv; pr.mstream = d_mstream;
 
     const int64_t lo = (int64_t)GRIDN * GRIDN * GRIDN * 60 + 12345 * 64;     // somewhere inside the grid
     hipLaunchKernelGGL(k_naive, dim3(ncheck), dim3(256), (n_pad + 256) * 8, 0, pr, lo, d_ss_ref, d_mean_ref);
@@ -584,9 +833,19 @@ int main(int argc, char** argv) {
     printf("device %s, %d CUs, clock %d MHz; ntiles %lld (%lld cells), reps %d\n", prop.name, ncu,
            prop.clockRate / 1000, (long long)ntiles, (long long)ntiles * 64, reps);
 
-    auto report = [&](const char* name, double ms, bool check) {
+    struct Variant {
+        const char* name;
+        std::function<void()> launch;
+        bool check;
+        std::vector<double> ms;
+    };
+    std::vector<Variant> variants;
+    auto report = [&](const Variant& v) {
         double err_ss = 0.0, err_m = 0.0;
-        if (check) {
+        if (v.check) {
+            CK(hipMemset(d_ss, 0, (size_t)ntiles * 64 * 8));
+            v.launch();
+            CK(hipDeviceSynchronize());
             std::vector<double> ss(ncheck), mean(ncheck * DOUT);
             CK(hipMemcpy(ss.data(), d_ss, ncheck * 8, hipMemcpyDeviceToHost));
             CK(hipMemcpy(mean.data(), d_mean, ncheck * DOUT * 8, hipMemcpyDeviceToHost));
@@ -597,11 +856,15 @@ int main(int argc, char** argv) {
                                             (fabs(mean_ref[k * DOUT + dd]) + 1e-12));
             }
         }
+        std::vector<double> t = v.ms;
+        std::sort(t.begin(), t.end());
+        const double ms = t[t.size() / 2], best = t[0];
         const double cells = (double)ntiles * 64;
         const double tf = flops_cell * cells / (ms * 1e-3) / 1e12;
         const double cyc = ms * 1e-3 * 2.4e9 * ncu * 4 / ((double)ntiles * mfma_tile);
-        printf("%-34s %9.3f ms  %6.2f TFLOP/s  %5.1f cyc/mfma4(@2.4GHz)  err ss %.1e mean %.1e %s\n", name, ms,
-               tf, cyc, err_ss, err_m, check ? (err_ss < 1e-9 && err_m < 1e-9 ? "OK" : "MISMATCH") : "");
+        printf("%-34s med %8.3f ms  min %8.3f  %6.2f TFLOP/s  %5.1f cyc/mfma4  err ss %.1e mean %.1e %s\n",
+               v.name, ms, best, tf, cyc, err_ss, err_m,
+               v.check ? (err_ss < 1e-9 && err_m < 1e-9 ? "OK" : "MISMATCH") : "");
         fflush(stdout);
     };
 
@@ -609,23 +872,31 @@ int main(int argc, char** argv) {
     if (!only[0] || strstr(NAME, only)) {                                                           \
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN),                                 \
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)));            \
-        CK(hipMemset(d_ss, 0, (size_t)ntiles * 64 * 8));                                            \
         const int blocks = (int)(ntiles < ncu ? ntiles : ncu);                                      \
-        double ms = time_ms([&] { hipLaunchKernelGGL(KERN, dim3(blocks), dim3(THREADS), LDS, 0, pr, \
-                                                     lo, ntiles, d_ss, d_mean); }, reps);          \
-        CK(hipGetLastError());                                                                      \
-        report(NAME, ms, CHECK);                                                                    \
+        const size_t lds_ = (LDS);                                                                  \
+        variants.push_back({NAME, [=] { hipLaunchKernelGGL(KERN, dim3(blocks), dim3(THREADS), lds_, \
+                                                           0, pr, lo, ntiles, d_ss, d_mean); },     \
+                            CHECK, {}});                                                            \
     }
 
     const size_t lds_common = ((size_t)P * n_pad + (size_t)n_pad * DOUT) * 8;
     const size_t lds_v1 = lds_common + (2 * 16 * 4 * 64 + 8 * 64 + 8 * 16 * DOUT) * 8;
-    const size_t lds_v2 = lds_common + (2 * 16 * 4 * 64 + 4 * 4 * 64 + 64 * DOUT) * 8;
+    const size_t lds_v2 = lds_common + (2 * 8 * (4 * 128 + 4) + 4 * 4 * 64 + 64 * DOUT + 64 * P) * 8;
     RUN("v1 16x16x4 W8 R4 CB4", (k_v1<8, 4, 4, 1>), 512, lds_v1, true);
     RUN("v1 16x16x4 W8 R4 CB4 nogen", (k_v1<8, 4, 4, 0>), 512, lds_v1, false);
-    RUN("v2 4x4x4 R8 CB4", (k_v2<8, 4, 1, 0>), 256, lds_v2, true);
-    RUN("v2 4x4x4 R8 CB4 nogen", (k_v2<8, 4, 0, 0>), 256, lds_v2, false);
-    RUN("v2 4x4x4 R8 CB4 nogen noA", (k_v2<8, 4, 0, 1>), 256, lds_v2, false);
-    RUN("v2 4x4x4 R8 CB4 nogen noB", (k_v2<8, 4, 0, 2>), 256, lds_v2, false);
-    RUN("v2 4x4x4 R8 CB4 nogen noA noB", (k_v2<8, 4, 0, 3>), 256, lds_v2, false);
+    RUN("v3 abuf pf2 nogen", (k_v3<8, 4, 0, 0, 9>), 256, lds_v2, false);
+    RUN("v3 abuf pf2 gen2", (k_v3<8, 4, 2, 0, 9>), 256, lds_v2, true);
+    RUN("v3 abuf pf2 nonop nogen", (k_v3<8, 4, 0, 0, 25>), 256, lds_v2, false);
+    RUN("v3 abuf pf2 nonop gen2", (k_v3<8, 4, 2, 0, 25>), 256, lds_v2, true);
+    RUN("v3 abuf nogen noA noB", (k_v3<8, 4, 0, 3, 1>), 256, lds_v2, false);
+    RUN("v3 abuf nonop nogen noA noB", (k_v3<8, 4, 0, 3, 17>), 256, lds_v2, false);
+    // interleaved rounds: every variant once per round, median over the rounds (the chip's
+    // clock follows its power budget, so back-to-back repetitions of one variant are biased)
+    for (auto& v : variants) { v.launch(); }
+    CK(hipDeviceSynchronize());
+    for (int round = 0; round < reps; ++round)
+        for (auto& v : variants) v.ms.push_back(time_ms(v.launch, 1));
+    CK(hipGetLastError());
+    for (auto& v : variants) report(v);
     return 0;
 }
