@@ -22,9 +22,10 @@
 //  * k_x generation: where the GP input [x, policy(x)] / lengthscales is affine in the cell index
 //    along the wavefront's 16 cells (a row of the last grid axis, policy linear or saturated) the
 //    RBF values form a Gaussian sequence e_{c+1} = e_c rho_c, rho_{c+1} = rho_c Q: two
-//    exponentials per (training point, 16 cells) instead of 16 (lane = training point).  The test
-//    is on the values themselves, so any other case (explicit points, kinks of the saturation,
-//    rows that end inside the block) silently takes one exponential per (point, cell).
+//    exponentials per (training point, 16 cells) instead of 16 (lane = training point).  The
+//    cells are split into affine runs by a test on the values themselves (a kink of the
+//    saturation or the end of a grid row restarts the recurrence); inputs that are not
+//    piecewise affine (explicit points, table policies) take one exponential per (point, cell).
 //    The posterior mean k_x . alpha' is accumulated from the LDS copy of each new chunk.
 //
 // Measured in tools/gp_lab.hip (1 Mi cells, 1024 points): 16x16x4 structure 49.5 TFLOP/s, this
@@ -283,21 +284,45 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                     cin[(16 * wave + lcol) * SL_P + q] = (q < p) ? xg[q] * hd.inv_ls[q] : 0.0;
             }
             __syncthreads();
-            // Is the input affine in the cell index over this wavefront's 16 cells?  Then
-            // z_j(c) = |X_j - x(c)|^2 is quadratic in c and k_x a Gaussian sequence.
+            // Where the input is affine in the cell index, z_j(c) = |X_j - x(c)|^2 is quadratic in
+            // c and k_x a Gaussian sequence.  Split the wavefront's 16 cells into maximal affine
+            // runs (second differences vanish inside a run; a saturation kink or the end of a grid
+            // row starts a new one): bit c of `runs` = cell c starts a run.  More than four runs
+            // (curved policies, explicit points): one exponential per (point, cell) instead.
+            unsigned runs = 1u;
+            {
+                bool bend = false;
+                if (lcol >= 2) {
+#pragma unroll
+                    for (int q = 0; q < SL_P; ++q) {
+                        if (q < p) {
+                            const double c0 = cin[(16 * wave + lcol) * SL_P + q];
+                            const double c1 = cin[(16 * wave + lcol - 1) * SL_P + q];
+                            const double c2 = cin[(16 * wave + lcol - 2) * SL_P + q];
+                            bend = bend || fabs((c0 - c1) - (c1 - c2)) > 2e-14 * fmax(1.0, fabs(c0));
+                        }
+                    }
+                }
+                unsigned bends = (unsigned)(__ballot(bend) & 0xffffull);
+                // a bend at c starts a run at c; c + 1 is then its second point, not a new start
+                while (bends) {
+                    const int c = __builtin_ctz(bends);
+                    runs |= 1u << c;
+                    bends &= ~(3u << c);
+                }
+            }
+            runs = (unsigned)__builtin_amdgcn_readfirstlane((int)runs);
+            const bool direct = __builtin_popcount(runs) > 4;
+            // constants of the first run (the only one for most tiles) in scalar registers
             double x0[SL_P], dlt[SL_P], a2 = 0.0;
-            bool ok = true;
 #pragma unroll
             for (int q = 0; q < SL_P; ++q) {
                 if (q < p) {
                     x0[q] = uniform(cin[(16 * wave) * SL_P + q]);
                     dlt[q] = uniform(cin[(16 * wave + 1) * SL_P + q] - x0[q]);
-                    const double end = cin[(16 * wave + 15) * SL_P + q];
-                    ok = ok && fabs(end - fma(15.0, dlt[q], x0[q])) <= 1e-13 * fmax(1.0, fabs(end));
                     a2 = fma(dlt[q], dlt[q], a2);
                 }
             }
-            const bool affine = __builtin_amdgcn_readfirstlane((int)ok) != 0;
             a2 = uniform(a2);
             const double qstep = uniform(sl_exp_nonpos(-a2));
 
@@ -309,13 +334,16 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             auto generate = [&](int ch, int buf) {
                 double* kxw = kx_l + buf * KXBUF + wbase;
                 const int j = 64 * ch + lane;
-                if (affine) {
+                double xv[SL_P];
+#pragma unroll
+                for (int q = 0; q < SL_P; ++q)
+                    if (q < p) xv[q] = XSG ? xs_glob[q * n_pad + j] : xs_l[q * n_pad + j];
+                if (runs == 1u) {                  // one affine run: e_{c+1} = e_c rho_c, rho_{c+1} = rho_c Q
                     double z = 0.0, bj = 0.0;
 #pragma unroll
                     for (int q = 0; q < SL_P; ++q) {
                         if (q < p) {
-                            const double xv = XSG ? xs_glob[q * n_pad + j] : xs_l[q * n_pad + j];
-                            const double dq = xv - x0[q];
+                            const double dq = xv[q] - x0[q];
                             z = fma(dq, dq, z);
                             bj = fma(dq, dlt[q], bj);
                         }
@@ -328,11 +356,35 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                         e *= rho;
                         rho *= qstep;
                     }
-                } else {
-                    double xv[SL_P];
+                } else if (!direct) {              // a few runs: the recurrence restarts at each
+                    unsigned m = runs;
+                    while (m) {
+                        const int c0 = __builtin_ctz(m);
+                        m &= m - 1;
+                        const int c1 = m ? __builtin_ctz(m) : 16;
+                        const double* at = cin + (16 * wave + c0) * SL_P;
+                        const bool single = c1 - c0 < 2;
+                        double z = 0.0, bj = 0.0, a2r = 0.0;
 #pragma unroll
-                    for (int q = 0; q < SL_P; ++q)
-                        if (q < p) xv[q] = XSG ? xs_glob[q * n_pad + j] : xs_l[q * n_pad + j];
+                        for (int q = 0; q < SL_P; ++q) {
+                            if (q < p) {
+                                const double dq = xv[q] - at[q];
+                                const double step = single ? 0.0 : at[SL_P + q] - at[q];
+                                z = fma(dq, dq, z);
+                                bj = fma(dq, step, bj);
+                                a2r = fma(step, step, a2r);
+                            }
+                        }
+                        double e = variance * sl_exp_nonpos(-0.5 * z);
+                        double rho = sl_exp_nonpos(bj - 0.5 * a2r);
+                        const double qr = sl_exp_nonpos(-a2r);
+                        for (int c = c0; c < c1; ++c) {
+                            kxw[2 * (c ^ wswz)] = e;
+                            e *= rho;
+                            rho *= qr;
+                        }
+                    }
+                } else {
                     for (int c = 0; c < 16; ++c) {
                         double z = 0.0;
 #pragma unroll
