@@ -26,7 +26,8 @@
 //    cells are split into affine runs by a test on the values themselves (a kink of the
 //    saturation or the end of a grid row restarts the recurrence); inputs that are not
 //    piecewise affine (explicit points, table policies) take one exponential per (point, cell).
-//    The posterior mean k_x . alpha' is accumulated from the LDS copy of each new chunk.
+//    The posterior mean k_x . alpha' is a 4 x 16 x 64 product per chunk and wavefront: 16 more
+//    MFMAs on the LDS copy of each new chunk.
 //
 // Measured in tools/gp_lab.hip (1 Mi cells, 1024 points): 16x16x4 structure 49.5 TFLOP/s, this
 // one 60.5; profiles/r02_summary.md has the ablation.
@@ -216,7 +217,9 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
-    int xs_doubles, int alpha_doubles, const double* __restrict__ points) {
+    int xs_doubles, int alpha_doubles, const double* __restrict__ points, int skip) {
+    // skip: diagnostics (SL_GP4_SKIP): 1 no k_x generation, 2 no mean pass, 4 no per-cell check,
+    // 8 no MFMA chunks - timing attribution only, the results are then meaningless
     using namespace gp4;
     asm volatile("" ::: SL_ALL_AGPRS);           // the accumulator file belongs to the MFMA groups
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -232,7 +235,6 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
 
     const SlDims nd = sl_dims<DT, MT>(M);
     const int d = nd.d, p = nd.p;
-    constexpr int DOUT_UNROLL = DT > 0 ? DT : SL_MAX_STATE_DIM;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // = cell block this wave generates
     const int lcol = lane & 15, lk = lane >> 4, blk = (lane >> 2) & 3, low = lane & 3;
@@ -326,9 +328,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             a2 = uniform(a2);
             const double qstep = uniform(sl_exp_nonpos(-a2));
 
-            double gmean[DOUT_UNROLL];
-#pragma unroll
-            for (int dd = 0; dd < DOUT_UNROLL; ++dd) gmean[dd] = 0.0;
+            double macc = 0.0;                     // posterior-mean accumulator (see mean_pass)
 
             // k_x chunk `ch` -> LDS buffer `buf` (lane = training point 64 ch + lane)
             auto generate = [&](int ch, int buf) {
@@ -398,21 +398,30 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                     }
                 }
             };
-            // posterior mean k_x . alpha' from the LDS copy of a new chunk (lane = (k, cell))
+            // Posterior mean k_x . alpha' on the matrix cores as well: for the wavefront's own 16
+            // cells, mean[dd][cell] = sum_j alpha'[j][dd] k_x[j][cell] is a 4 x 16 x 64 product per
+            // chunk - A = alpha'^T (row dd = lane & 3, the same for the four blocks), B = the
+            // rotation-0 k_x fragment of cell block `wave`.  Lane (k, blk, low) ends up with the
+            // mean of output dd = k at cell 4 blk + low.  (As FP64-VALU work in the (k, cell)
+            // lane mapping this cost 8 % of the sweep.)
             auto mean_pass = [&](int ch, int buf) {
                 const double* kxr = kx_l + buf * KXBUF + wave * 128 + own;
+                const double* ap = alphap + (64 * ch + lk) * dout + low;
 #pragma unroll
                 for (int s2 = 0; s2 < 8; ++s2) {
                     const sl_d2 kx = *reinterpret_cast<const sl_d2*>(kxr + s2 * KXS2);
-                    const int j = 64 * ch + 8 * s2 + lk;
-#pragma unroll
-                    for (int dd = 0; dd < DOUT_UNROLL; ++dd) {
-                        if (dd < dout) {
-                            gmean[dd] = fma(kx.x, alphap[j * dout + dd], gmean[dd]);
-                            gmean[dd] = fma(kx.y, alphap[(j + 4) * dout + dd], gmean[dd]);
-                        }
-                    }
+                    const double a0 = low < dout ? ap[(8 * s2) * dout] : 0.0;
+                    const double a1 = low < dout ? ap[(8 * s2 + 4) * dout] : 0.0;
+                    // accumulator in a vector register (the builtin would route it through a0:a1);
+                    // the A operands may come fresh from a VALU select: two wait states first
+                    asm volatile("s_nop 1\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %0, %3, %4, %0"
+                                 : "+v"(macc)
+                                 : "v"(a0), "v"(kx.x), "v"(a1), "v"(kx.y)
+                                 : SL_ALL_AGPRS);
                 }
+                asm volatile("s_nop 15\n\ts_nop 3" : "+v"(macc));     // retire before any other reader
             };
 
             const int npanels = n_pad / RP;
@@ -426,14 +435,14 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                 }
                 const int nchunks = (pan + 1) * (RP / 64);
                 const int first_new_chunk = pan * (RP / 64);     // chunks not generated before
-                generate(0, 0);
+                if (!(skip & 1)) generate(0, 0);
                 __syncthreads();
                 for (int ch = 0; ch < nchunks; ++ch) {
                     const int buf = ch & 1;
-                    if (ch >= first_new_chunk) mean_pass(ch, buf);
+                    if (ch >= first_new_chunk && !(skip & 2)) mean_pass(ch, buf);
                     const int q = __builtin_amdgcn_readfirstlane(ch - 8 * pan);
-                    chunk_any(rsrc, kx_l + buf * KXBUF, rowoff, q, ch, lane, boff);
-                    if (ch + 1 < nchunks) generate(ch + 1, buf ^ 1);
+                    if (!(skip & 8)) chunk_any(rsrc, kx_l + buf * KXBUF, rowoff, q, ch, lane, boff);
+                    if (ch + 1 < nchunks && !(skip & 1)) generate(ch + 1, buf ^ 1);
                     __syncthreads();
                 }
                 // |a|^2 of this panel's rows.  The rows of a block live in the four lane groups
@@ -463,16 +472,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                         }
                 }
             }
-#pragma unroll
-            for (int dd = 0; dd < DOUT_UNROLL; ++dd) {
-                gmean[dd] += __shfl_xor(gmean[dd], 16, 64);
-                gmean[dd] += __shfl_xor(gmean[dd], 32, 64);
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int dd = 0; dd < DOUT_UNROLL; ++dd)
-                    if (dd < dout) cell_mean[(16 * wave + lane) * SL_D + hd.col0 + dd] = gmean[dd];
-            }
+            if (lk < dout) cell_mean[(16 * wave + 4 * blk + low) * SL_D + hd.col0 + lk] = macc;
             __syncthreads();
             if (tid < C) {
                 double sumsq = 0.0;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
         const bool valid = (tid < C) && (idx < hi);
         bool negative = false;
         double v_x = 0.0;
-        if (valid) {
+        if (valid && !(skip & 4)) {
             double x[SL_P], u[SL_M], prior[SL_D], mean[SL_D], err[SL_D];
             sl_cell_state(M, d, idx, points, x);
             sl_policy_any<false>(M, nd, aux.tri, idx, x, u);
@@ -578,9 +578,11 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
     if (blocks > SL_MAX_GRID) blocks = SL_MAX_GRID;
     *nblocks = (int)blocks;
     SlAux aux{ctx->d_tri, ctx->d_net};
+    const char* env = getenv("SL_GP4_SKIP");
+    const int skip = env ? atoi(env) : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(gp4::W * 64), lds, ctx->stream, model,
                        ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,
-                       ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, d_points);
+                       ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, d_points, skip);
     SL_HIP_CHECK(ctx, hipGetLastError());
     return SL_OK;
 }
