@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             a2 = uniform(a2);
             const double qstep = uniform(sl_exp_nonpos(-a2));
 
-            double macc = 0.0;                     // posterior-mean accumulator (see mean_pass)
+            double macc[4] = {0.0, 0.0, 0.0, 0.0};   // posterior-mean accumulators (see mean_pass)
 
             // k_x chunk `ch` -> LDS buffer `buf` (lane = training point 64 ch + lane)
             auto generate = [&](int ch, int buf) {
@@ -406,22 +406,27 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             // lane mapping this cost 8 % of the sweep.)
             auto mean_pass = [&](int ch, int buf) {
                 const double* kxr = kx_l + buf * KXBUF + wave * 128 + own;
-                const double* ap = alphap + (64 * ch + lk) * dout + low;
+                // rows dd >= dout of A are zero: every lane loads a valid column, then selects
+                const bool row = low < dout;
+                const double* ap = alphap + (64 * ch + lk) * dout + (row ? low : 0);
 #pragma unroll
                 for (int s2 = 0; s2 < 8; ++s2) {
                     const sl_d2 kx = *reinterpret_cast<const sl_d2*>(kxr + s2 * KXS2);
-                    const double a0 = low < dout ? ap[(8 * s2) * dout] : 0.0;
-                    const double a1 = low < dout ? ap[(8 * s2 + 4) * dout] : 0.0;
-                    // accumulator in a vector register (the builtin would route it through a0:a1);
-                    // the A operands may come fresh from a VALU select: two wait states first
-                    asm volatile("s_nop 1\n\t"
-                                 "v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\t"
-                                 "v_mfma_f64_4x4x4_4b_f64 %0, %3, %4, %0"
-                                 : "+v"(macc)
-                                 : "v"(a0), "v"(kx.x), "v"(a1), "v"(kx.y)
-                                 : SL_ALL_AGPRS);
+                    const double t0 = ap[(8 * s2) * dout], t1 = ap[(8 * s2 + 4) * dout];
+                    const double a0 = row ? t0 : 0.0, a1 = row ? t1 : 0.0;
+                    // Accumulators in vector registers (the builtin would route them through
+                    // a0:a1).  A dependent FP64 MFMA must not issue right behind its producer
+                    // (no interlock: measured, the second product was lost): four accumulators
+                    // in rotation keep three MFMAs and the loads between a write and its reuse.
+                    // The A operands may come fresh from a VALU select: wait states first.
+                    asm volatile("s_nop 3\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %0, %2, %3, %0\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %1, %4, %5, %1"
+                                 : "+v"(macc[2 * (s2 & 1)]), "+v"(macc[2 * (s2 & 1) + 1])
+                                 : "v"(a0), "v"(kx.x), "v"(a1), "v"(kx.y));
                 }
-                asm volatile("s_nop 15\n\ts_nop 3" : "+v"(macc));     // retire before any other reader
+                // retired before any other reader (a register copy, the final sum)
+                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(macc[0]), "+v"(macc[1]), "+v"(macc[2]), "+v"(macc[3]));
             };
 
             const int npanels = n_pad / RP;
@@ -472,7 +477,9 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                         }
                 }
             }
-            if (lk < dout) cell_mean[(16 * wave + 4 * blk + low) * SL_D + hd.col0 + lk] = macc;
+            if (lk < dout)
+                cell_mean[(16 * wave + 4 * blk + low) * SL_D + hd.col0 + lk] =
+                    (macc[0] + macc[1]) + (macc[2] + macc[3]);
             __syncthreads();
             if (tid < C) {
                 double sumsq = 0.0;
