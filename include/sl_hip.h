@@ -101,13 +101,17 @@ typedef struct sl_value_desc {
     double  matrix[SL_MAX_INPUT_DIM][SL_MAX_INPUT_DIM];    /* QUADRATIC                     */
 } sl_value_desc;
 
+enum { SL_LF_CONST = 0, SL_LF_AFFINE_NORM1 = 1 };
+
 typedef struct sl_lipschitz_desc {
     int32_t lv_kind, lv_cols;            /* columns of L_v(x): 1 or d                       */
     double  lv_const;
     double  lv_matrix[SL_MAX_STATE_DIM][SL_MAX_STATE_DIM]; /* rows = outputs                */
-    double  lf_const;                    /* L_f (closed loop), scalar                       */
+    double  lf_const;                    /* L_f (closed loop): the scalar, or the constant c */
     double  tau;
-} sl_lipschitz_desc;
+    int32_t lf_kind, lf_reserved;        /* SL_LF_CONST, or SL_LF_AFFINE_NORM1:              */
+    double  lf_matrix[SL_MAX_STATE_DIM][SL_MAX_STATE_DIM]; /* L_f(x) = c + ||lf_matrix x||_1  */
+} sl_lipschitz_desc;                     /* (state-dependent L_f, lyapunov.py:227-244)       */
 
 typedef struct sl_model_desc {
     sl_grid_desc      grid;

@@ -25,6 +25,7 @@ POLICY_LINEAR, POLICY_CONST, POLICY_TABLE, POLICY_TRI = 1, 2, 3, 4
 DYN_LINEAR, DYN_PENDULUM, DYN_CARTPOLE, DYN_GP = 1, 2, 3, 4
 V_QUADRATIC, V_TRI, V_NETWORK = 1, 2, 3
 LIP_CONST, LIP_ABS_LINEAR, LIP_NORM_LINEAR, LIP_ABS_GRAD, LIP_NORM_GRAD = 0, 1, 2, 3, 4
+LF_CONST, LF_AFFINE_NORM1 = 0, 1
 EVAL_VALUE, EVAL_POLICY, EVAL_DYNAMICS, EVAL_DECREASE, EVAL_LV = 1, 2, 3, 4, 5
 
 c_double_p = C.POINTER(C.c_double)
@@ -63,7 +64,9 @@ class ValueDesc(C.Structure):
 class LipschitzDesc(C.Structure):
     _fields_ = [("lv_kind", C.c_int32), ("lv_cols", C.c_int32), ("lv_const", C.c_double),
                 ("lv_matrix", (C.c_double * MAX_STATE_DIM) * MAX_STATE_DIM),
-                ("lf_const", C.c_double), ("tau", C.c_double)]
+                ("lf_const", C.c_double), ("tau", C.c_double),
+                ("lf_kind", C.c_int32), ("lf_reserved", C.c_int32),
+                ("lf_matrix", (C.c_double * MAX_STATE_DIM) * MAX_STATE_DIM)]
 
 
 class ModelDesc(C.Structure):

@@ -140,6 +140,8 @@ class ModelBuilder(object):
 
     def _write_lipschitz(self, ld, lipschitz_lyapunov, lipschitz_dynamics, tau):
         d = self.grid.ndim
+        if isinstance(lipschitz_lyapunov, Norm1Function) and lipschitz_lyapunov.constant != 0.0:
+            raise TypeError('a constant offset is only supported for lipschitz_dynamics')
         if (isinstance(lipschitz_lyapunov, (AbsFunction, Norm1Function))
                 and isinstance(lipschitz_lyapunov.fun, Gradient)):
             ld.lv_kind = (_hip.LIP_ABS_GRAD if isinstance(lipschitz_lyapunov, AbsFunction)
@@ -160,9 +162,27 @@ class ModelBuilder(object):
             raise TypeError('lipschitz_lyapunov must be a float, AbsFunction(LinearSystem), '
                             'Norm1Function(LinearSystem), AbsFunction/Norm1Function(Gradient(V)); arbitrary Python '
                             'callables cannot run inside a GPU kernel')
-        if not np.isscalar(lipschitz_dynamics):
-            raise TypeError('lipschitz_dynamics must be a scalar')
-        ld.lf_const = float(lipschitz_dynamics)
+        if np.isscalar(lipschitz_dynamics):
+            ld.lf_kind = _hip.LF_CONST
+            ld.lf_const = float(lipschitz_dynamics)
+        elif (isinstance(lipschitz_dynamics, Norm1Function)
+              and isinstance(lipschitz_dynamics.fun, LinearSystem)
+              and lipschitz_dynamics.fun.matrix.shape[1] == d
+              and lipschitz_dynamics.fun.matrix.shape[0] <= _hip.MAX_STATE_DIM):
+            # state-dependent L_f(x) = c + ||M x||_1 (lyapunov.py:227-244 allows a callable)
+            mat = np.zeros((d, d))
+            rows = lipschitz_dynamics.fun.matrix
+            if rows.shape[0] > d:
+                raise TypeError('the L_f matrix may have at most %d rows' % d)
+            mat[:rows.shape[0]] = rows
+            ld.lf_kind = _hip.LF_AFFINE_NORM1
+            ld.lf_const = float(lipschitz_dynamics.constant)
+            for i in range(d):
+                for j in range(d):
+                    ld.lf_matrix[i][j] = float(mat[i, j])
+        else:
+            raise TypeError('lipschitz_dynamics must be a scalar or c + Norm1Function(LinearSystem(M)) '
+                            '(arbitrary Python callables cannot run inside a GPU kernel)')
         ld.tau = float(tau)
 
     # ---- whole model -----------------------------------------------------------------------

@@ -268,7 +268,7 @@ __device__ __forceinline__ SlCellCheck sl_cell_check(const SlDevModel& M, int d,
     if (M.uncertain) v_next = sl_value_and_lv<GENERAL>(M, d, aux, next_mean, lv_n);
     else v_next = sl_value_any<GENERAL>(M, d, aux, next_mean);
     r.decrease = sl_decrease(M, d, r.v_x, v_next, lv_n, err);
-    r.threshold = sl_threshold(M, d, lv_x, M.m.lipschitz.tau);
+    r.threshold = sl_threshold(M, d, lv_x, M.m.lipschitz.tau, x);
     r.negative = r.decrease < r.threshold;
     return r;
 }

@@ -609,15 +609,26 @@ SL_HD void sl_lv(const SlDevModel& M, int d, const double* z, double* lv) {
 }
 
 // lyapunov.py:282-288
-SL_HD double sl_threshold(const SlDevModel& M, int d, const double* lv_x, double tau) {
+// -|L_v(x)|_1 (1 + L_f(x)) tau, lyapunov.py:265-288; L_f a scalar or c + ||M x||_1 (:227-244)
+SL_HD double sl_threshold(const SlDevModel& M, int d, const double* lv_x, double tau,
+                          const double* x) {
     const sl_lipschitz_desc& l = M.m.lipschitz;
+    double lf = l.lf_const;
+    if (l.lf_kind == SL_LF_AFFINE_NORM1) {
+        double t[SL_D];
+        sl_rows_dot<SL_D, SL_D>(l.lf_matrix, d, d, x, t);
+        double acc = fabs(t[0]);
+#pragma unroll
+        for (int j = 1; j < SL_D; ++j) if (j < d) acc = acc + fabs(t[j]);
+        lf = lf + acc;
+    }
     double l1 = lv_x[0];
     if ((l.lv_kind == SL_LIP_ABS_LINEAR || l.lv_kind == SL_LIP_ABS_GRAD) && d > 1) {
         l1 = fabs(lv_x[0]);
 #pragma unroll
         for (int j = 1; j < SL_D; ++j) if (j < d) l1 = l1 + fabs(lv_x[j]);
     }
-    double t = (-l1) * (1.0 + l.lf_const);
+    double t = (-l1) * (1.0 + lf);
     return t * tau;
 }
 

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64 * SL_NNM_WAVES) void k_nn_check_mfma(
             if (M.uncertain) { if (grad_lv) nn_lv_from_grad(lvk, d, g, lv_n); else sl_lv(M, d, nxt, lv_n); }
             if (M.m.value.negate) { v_x = v_x * -1.0; v_n = v_n * -1.0; }
             const double decrease = sl_decrease(M, d, v_x, v_n, lv_n, err);
-            const double threshold = sl_threshold(M, d, lv_x, M.m.lipschitz.tau);
+            const double threshold = sl_threshold(M, d, lv_x, M.m.lipschitz.tau, x);
             const bool negative = valid && (decrease < threshold);
             if (valid && dbg && lane < 16) {
                 double* o = dbg + (idx - lo) * (2 + 2 * d);

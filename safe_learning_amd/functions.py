@@ -272,10 +272,21 @@ class AbsFunction(DeterministicFunction):
 
 
 class Norm1Function(DeterministicFunction):
-    """``||fun(x)||_1`` - replaces ``lambda x: tf.norm(grad(x), ord=1, axis=1, keepdims=True)``."""
+    """``||fun(x)||_1`` - replaces ``lambda x: tf.norm(grad(x), ord=1, axis=1, keepdims=True)``.
 
-    def __init__(self, fun):
+    ``constant + Norm1Function(LinearSystem(M))`` gives the affine form ``c + ||M x||_1`` that the
+    engine accepts as a state-dependent ``lipschitz_dynamics`` (``lyapunov.py:227-244``)."""
+
+    def __init__(self, fun, constant=0.0):
         self.fun = fun
+        self.constant = float(constant)
+
+    def __add__(self, constant):
+        if not np.isscalar(constant):
+            return NotImplemented
+        return Norm1Function(self.fun, self.constant + float(constant))
+
+    __radd__ = __add__
 
 
 class Gradient(DeterministicFunction):

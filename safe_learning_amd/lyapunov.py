@@ -134,8 +134,21 @@ class Lyapunov(object):
         self._init_version = None
 
     def lipschitz_dynamics(self, states):
-        """The (scalar) Lipschitz constant of the dynamics (``lyapunov.py:227-244``)."""
-        return self._lipschitz_dynamics
+        """Lipschitz constant of the dynamics at ``states`` (``lyapunov.py:227-244``): the scalar,
+        or ``[n, 1]`` for the state-dependent spec ``c + Norm1Function(LinearSystem(M))``
+        (host arithmetic in the kernels' operation order)."""
+        lf = self._lipschitz_dynamics
+        if np.isscalar(lf):
+            return lf
+        states = np.atleast_2d(np.asarray(states, dtype=np.float64))
+        rows = lf.fun.matrix
+        acc = None
+        for r in range(rows.shape[0]):
+            t = states[:, 0] * rows[r, 0]
+            for k in range(1, states.shape[1]):
+                t = t + states[:, k] * rows[r, k]
+            acc = np.abs(t) if acc is None else acc + np.abs(t)
+        return (lf.constant + acc)[:, None]
 
     def lipschitz_lyapunov(self, states):
         """``L_v`` at explicit states (``lyapunov.py:246-263``): the scalar, or ``[n, cols]``."""
@@ -154,7 +167,7 @@ class Lyapunov(object):
             for k in range(1, lv.shape[1]):
                 acc = acc + np.abs(lv[:, k])
             lv = acc[:, None]
-        return (-lv) * (1. + self._lipschitz_dynamics) * tau
+        return (-lv) * (1. + self.lipschitz_dynamics(states)) * tau
 
     def v_decrease_confidence(self, states, next_states):
         """``(V(next) - V(states), sum_j L_v(next)_j error_j)`` (``lyapunov.py:324-354``)."""

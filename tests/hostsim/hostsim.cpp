@@ -45,7 +45,7 @@ int hs_det_cells(const sl_model_desc* desc, int64_t lo, int64_t hi, double* valu
         const double v_n = sl_quadratic(M.m.value, d, nxt);
         const double dec = sl_decrease(M, d, v_x, v_n, lv_n, err);
         sl_lv(M, d, x, lv_x);
-        const double thr = sl_threshold(M, d, lv_x, M.m.lipschitz.tau);
+        const double thr = sl_threshold(M, d, lv_x, M.m.lipschitz.tau, x);
         values[idx - lo] = v_x;
         negative[idx - lo] = dec < thr ? 1 : 0;
         if (dbg) {

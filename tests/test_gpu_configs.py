@@ -44,7 +44,7 @@ def test_c2_pendulum_256_every_cell():
     values, neg, rec = _engine_records(lyap)
     ref_rec, ref_neg = _oracle_all(olyap)
     assert_array_equal(values, olyap.values)
-    assert_allclose(rec[:, 2:4], ref_rec[:, 2:4], rtol=1e-9, atol=1e-13)
+    assert_allclose(rec[:, 2:4], ref_rec[:, 2:4], rtol=1e-9, atol=1e-12)
     assert_allclose(rec[:, 4:], ref_rec[:, 4:], rtol=1e-7, atol=1e-12)
     assert_allclose(rec[:, :2], ref_rec[:, :2], rtol=1e-7, atol=1e-12)
     flips, _ = _check_masks(neg, ref_neg, rec, ref_rec)
