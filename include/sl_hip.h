@@ -233,6 +233,27 @@ enum sl_eval_what {
 int  sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_points /* [n][d] */,
                     double* d_out);
 
+/* ---- multi-GPU collectives directly on RCCL ----------------------------- *
+ * For callers without torch.distributed (the Python package issues the same exchanges through
+ * torch.distributed, backend "nccl" = RCCL).  One communicator per context, one rank per GPU; every
+ * call is asynchronous on the context's stream.  RCCL is bound at run time: on a system without
+ * librccl.so the calls return SL_ERR_UNSUPPORTED.
+ *   sl_comm_unique_id: rank 0 creates the 128-byte id and hands it to the other ranks out of band.
+ *   sl_allreduce_result: the per-shard record of sl_lyap_sweep / sl_lyap_finalize becomes the record
+ *     of the whole grid IN PLACE: lexicographic min of `fail`, lexicographic max of `last_safe`
+ *     and `max_key`, sums of the counters (the reductions of lyapunov.py:512-606 over shards).
+ *   sl_allgather: value-table shards of equal size after a Bellman sweep
+ *     (reinforcement_learning.py:135-140); sl_allreduce_max_f64: its residual;
+ *   sl_allreduce_sum_u64: the radix-select histograms of sl_select_pass.                        */
+#define SL_COMM_ID_BYTES 128
+int  sl_comm_unique_id(unsigned char* id_out /* [SL_COMM_ID_BYTES] */);
+int  sl_comm_init(sl_ctx* ctx, const unsigned char* id /* [SL_COMM_ID_BYTES] */, int rank, int world);
+int  sl_comm_destroy(sl_ctx* ctx);
+int  sl_allreduce_result(sl_ctx* ctx, sl_sweep_result* d_result);
+int  sl_allgather(sl_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank);
+int  sl_allreduce_sum_u64(sl_ctx* ctx, uint64_t* d_values, int64_t count);
+int  sl_allreduce_max_f64(sl_ctx* ctx, double* d_values, int64_t count);
+
 /* ---- diagnostics -------------------------------------------------------------------------- */
 /* D = A(16x4) * B(4x16) through v_mfma_f64_16x16x4_f64 with this library's fragment maps. */
 int  sl_debug_mfma(sl_ctx* ctx, const double* h_a, const double* h_b, double* h_d);

@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["sl_kernels.hip", "sl_gp.hip", "sl_gp4.hip", "sl_bellman.hip", "sl_nn.hip"]
+SOURCES = ["sl_kernels.hip", "sl_gp.hip", "sl_gp4.hip", "sl_bellman.hip", "sl_nn.hip", "sl_comm.hip"]
 LIB = os.path.join(HERE, "libslhip.so")
 
 
@@ -78,7 +78,7 @@ def build(verbose=False, force=False):
     if failed:
         raise RuntimeError("hipcc failed")
     _audit_gp4(objdir, verbose)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [obj for obj, _ in jobs]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [obj for obj, _ in jobs] + ["-ldl"]
     res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         sys.stderr.write(res.stdout)

@@ -88,6 +88,8 @@ EXPORTS = [
     "sl_model_set", "sl_gp_set_head", "sl_gp_configure", "sl_tri_set", "sl_tri_set_table",
     "sl_network_set", "sl_values", "sl_lyap_sweep", "sl_lyap_finalize", "sl_select_pass",
     "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_eval_points",
+    "sl_comm_unique_id", "sl_comm_init", "sl_comm_destroy", "sl_allreduce_result", "sl_allgather",
+    "sl_allreduce_sum_u64", "sl_allreduce_max_f64",
     "sl_debug_mfma", "sl_debug_mfma4", "sl_debug_fp64_rate",
 ]
 
@@ -139,6 +141,13 @@ def load_library():
     lib.sl_bellman_sweep.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, c_double_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sl_eval_points.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.sl_comm_unique_id.argtypes = [C.c_char_p]
+    lib.sl_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    lib.sl_comm_destroy.argtypes = [C.c_void_p]
+    lib.sl_allreduce_result.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sl_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.sl_allreduce_sum_u64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.sl_allreduce_max_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.sl_debug_mfma.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
     lib.sl_debug_fp64_rate.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p]
     lib.sl_debug_mfma4.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int,
@@ -283,6 +292,37 @@ class Context(object):
 
     def synchronize(self):
         self.check(self.lib.sl_ctx_synchronize(self.handle), "sl_ctx_synchronize")
+
+    # ---- RCCL collectives of the C ABI (the package itself uses torch.distributed) ---------
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.sl_comm_unique_id(buf)
+        if rc != 0:
+            raise HipEngineError("sl_comm_unique_id failed: %s" % lib.sl_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        self.check(self.lib.sl_comm_init(self.handle, unique_id, rank, world), "sl_comm_init")
+
+    def comm_destroy(self):
+        self.check(self.lib.sl_comm_destroy(self.handle), "sl_comm_destroy")
+
+    def allreduce_result(self, d_result):
+        self.check(self.lib.sl_allreduce_result(self.handle, _ptr(d_result)), "sl_allreduce_result")
+
+    def allgather(self, d_send, d_recv, nbytes):
+        self.check(self.lib.sl_allgather(self.handle, _ptr(d_send), _ptr(d_recv), nbytes),
+                   "sl_allgather")
+
+    def allreduce_sum_u64(self, d_values, count):
+        self.check(self.lib.sl_allreduce_sum_u64(self.handle, _ptr(d_values), count),
+                   "sl_allreduce_sum_u64")
+
+    def allreduce_max_f64(self, d_values, count):
+        self.check(self.lib.sl_allreduce_max_f64(self.handle, _ptr(d_values), count),
+                   "sl_allreduce_max_f64")
 
     # ---- diagnostics ---------------------------------------------------------------------
     def debug_mfma(self, a, b):

@@ -50,6 +50,9 @@ struct sl_ctx {
     int64_t* d_partial_counts = nullptr;
     double* d_actions = nullptr;       // bellman action list
     int num_cu = 256;
+    void* comm = nullptr;              // RCCL communicator (sl_comm.hip), optional
+    void* d_comm_records = nullptr;    // [world] gathered sl_sweep_result records
+    int comm_rank = 0, comm_world = 1;
 };
 
 extern thread_local std::string g_sl_last_error;

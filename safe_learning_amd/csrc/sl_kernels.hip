@@ -71,6 +71,7 @@ extern "C" int sl_ctx_create(int device, void* hip_stream, sl_ctx** out) {
 
 extern "C" int sl_ctx_destroy(sl_ctx* ctx) {
     if (!ctx) return SL_OK;
+    (void)sl_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int h = 0; h < SL_MAX_GP_HEADS; ++h) {
@@ -423,7 +424,11 @@ __device__ __forceinline__ void sl_constants_to_vgprs(SlDevModel& L) {
 #undef SL_TO_VGPR
 }
 
-template <bool GENERAL, int DT, int MT, int DYN>
+// POW2: every grid axis has a power-of-two length and the grid fewer than 2^32 cells (128^4):
+// the cell state comes from 32-bit shifts and masks held in vector registers - the generic decode
+// (three code paths, 64-bit shifts, operands read back from spilled scalar registers with
+// v_readlane) cost as much as the FP64 arithmetic of the check.  No explicit points, no records.
+template <bool GENERAL, int DT, int MT, int DYN, bool POW2 = false>
 __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
     const SlDevModel M_arg, SlAux aux, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
     const double* __restrict__ values, uint64_t* __restrict__ neg_bits,
@@ -432,6 +437,16 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
     __shared__ int64_t si[SL_BLOCK / 64];
     SlDevModel M = M_arg;
     if (!GENERAL && DT > 0 && DYN != 0) sl_constants_to_vgprs<DT, MT, DYN>(M);
+    uint32_t axis_mask[DT > 0 ? DT : 1], axis_shift[DT > 0 ? DT : 1];
+    if (POW2) {
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+            axis_shift[k] = (uint32_t)M.gf.shift[k];
+            axis_mask[k] = (1u << axis_shift[k]) - 1u;
+            asm volatile("" : "+v"(axis_mask[k]));
+            asm volatile("" : "+v"(axis_shift[k]));
+        }
+    }
     const SlDims n = sl_dims<DT, MT>(M);
     const int d = n.d;
     const int lane = threadIdx.x & 63;
@@ -445,14 +460,25 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
         double v_x = 0.0;
         if (valid) {
             double x[SL_P], u[SL_M], nxt[SL_D], err[SL_D];
-            sl_cell_state(M, d, idx, points, x);
+            if (POW2) {
+                uint32_t r = (uint32_t)idx;
+#pragma unroll
+                for (int k = DT - 1; k >= 0; --k) {
+                    const int ijk = (int)(r & axis_mask[k]);
+                    r >>= axis_shift[k];
+                    const double t = (double)ijk * M.m.grid.unit_maxes[k];     // functions.py:731
+                    x[k] = t + M.m.grid.offset[k];
+                }
+            } else {
+                sl_cell_state(M, d, idx, points, x);
+            }
             sl_policy_any<GENERAL>(M, n, aux.tri, idx, x, u);
             sl_append_action(n, u, x);
             sl_dynamics_det<DYN>(M, n, x, nxt);
             SlCellCheck c = sl_cell_check<GENERAL>(M, d, aux, x, nxt, err);
             negative = c.negative;
             v_x = values ? values[idx - lo] : c.v_x;       // ordering key: lyapunov.py:512
-            if (dbg) {
+            if (!POW2 && dbg) {
                 double* o = dbg + (idx - lo) * (2 + 2 * d);
                 o[0] = c.decrease; o[1] = c.threshold;
 #pragma unroll
@@ -539,10 +565,20 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
         blocks = sl_grid_blocks(hi - lo);
         SlAux aux{ctx->d_tri, ctx->d_net};
         const int dyn = ctx->h_model.m.dynamics.kind;
+        const bool pow2 = ctx->h_model.gf.all_pow2 && ctx->h_model.gf.nindex <= 0xffffffffll &&
+                          !d_dbg && !d_points;
 #define SL_LAUNCH_DET(G, D_, M_, DYN_)                                                          \
-    hipLaunchKernelGGL((k_det_sweep<G, D_, M_, DYN_>), dim3(blocks), dim3(SL_BLOCK), 0,         \
-                       ctx->stream, ctx->h_model, aux, lo, hi, d_init_bits, d_values,          \
-                       d_neg_bits, ctx->d_partials, d_dbg, d_points)
+    do {                                                                                        \
+        if (pow2 && !(G) && (D_) > 0 && (DYN_) != 0)                                            \
+            hipLaunchKernelGGL((k_det_sweep<G, D_, M_, DYN_, (!(G) && (D_) > 0 && (DYN_) != 0)>), \
+                               dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream, ctx->h_model, aux, \
+                               lo, hi, d_init_bits, d_values, d_neg_bits, ctx->d_partials,      \
+                               d_dbg, d_points);                                                \
+        else                                                                                    \
+            hipLaunchKernelGGL((k_det_sweep<G, D_, M_, DYN_>), dim3(blocks), dim3(SL_BLOCK), 0, \
+                               ctx->stream, ctx->h_model, aux, lo, hi, d_init_bits, d_values,  \
+                               d_neg_bits, ctx->d_partials, d_dbg, d_points);                   \
+    } while (0)
 #define SL_CALL(G, D_, M_)                                                                     \
     do {                                                                                       \
         if (!(G) && (D_) > 0 && dyn == SL_DYN_LINEAR) SL_LAUNCH_DET(G, D_, M_, SL_DYN_LINEAR); \

@@ -137,3 +137,50 @@ def test_rccl_collectives_world_one():
     results = mp.get_context("spawn").Manager().dict()    # never fork a process that holds a HIP context
     mp.spawn(_worker, args=(1, port, results, "nccl"), nprocs=1, join=True)
     assert results[0] == [], results[0]
+
+
+def _abi_comm_worker(rank, world, results):
+    """The RCCL entry points of the C ABI (no torch.distributed): communicator of `world` ranks."""
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    from safe_learning_amd import _hip
+    ctx = _hip.Context()
+    uid = _hip.Context.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, rank, world)
+    dev = ctx.torch_device
+    # result record: folded in place (world 1: unchanged)
+    rec = torch.tensor([5, 7, 3, 2, 9, 11, 4, 6], dtype=torch.int64, device=dev)
+    ctx.allreduce_result(rec)
+    hist = torch.arange(256, dtype=torch.int64, device=dev)
+    ctx.allreduce_sum_u64(hist, 256)
+    res = torch.tensor([0.25, 3.5], dtype=torch.float64, device=dev)
+    ctx.allreduce_max_f64(res, 2)
+    shard = torch.arange(1000, dtype=torch.float64, device=dev)
+    full = torch.empty(1000 * world, dtype=torch.float64, device=dev)
+    ctx.allgather(shard, full, shard.numel() * 8)
+    ctx.synchronize()
+    ok = (rec.cpu().tolist() == [5, 7, 3, 2, 9, 11, 4, 6]
+          and torch.equal(hist.cpu(), torch.arange(256, dtype=torch.int64) * world)
+          and res.cpu().tolist() == [0.25, 3.5]
+          and torch.equal(full.cpu()[:1000], shard.cpu()))
+    # errors: a second communicator on the same context, collectives after destroy
+    try:
+        ctx.comm_init(uid, rank, world)
+        ok = False
+    except _hip.HipEngineError:
+        pass
+    ctx.comm_destroy()
+    try:
+        ctx.allreduce_max_f64(res, 2)
+        ok = False
+    except _hip.HipEngineError:
+        pass
+    results[rank] = ok
+
+
+def test_c_abi_rccl_collectives_world_one():
+    """sl_comm_init / sl_allreduce_result / sl_allgather / sl_allreduce_* through RCCL itself."""
+    results = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_abi_comm_worker, args=(1, results), nprocs=1, join=True)
+    assert results[0] is True
