@@ -446,6 +446,71 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
             asm volatile("" : "+v"(axis_mask[k]));
             asm volatile("" : "+v"(axis_shift[k]));
         }
+        // The check is one long chain of dependent (unfused) FP64 operations per cell and the
+        // ~70 vector-resident constants leave room for two wavefronts per SIMD only: every
+        // thread of the linear-dynamics variant handles TWO cells (cell and cell + 64) whose chains
+        // interleave (the Euler variants have no registers left for that: one cell).  No branches
+        // on `valid`: out-of-range lanes compute the last cell and are masked afterwards.
+        constexpr int CPT = (DYN == SL_DYN_LINEAR) ? 2 : 1;
+        const SlDims n2 = sl_dims<DT, MT>(M);
+        const int lane2 = threadIdx.x & 63;
+        uint64_t bv = ~0ull;
+        int64_t bi = INT64_MAX;
+        const int64_t wave_off = (int64_t)(threadIdx.x >> 6) * (64 * CPT);
+        for (int64_t base = lo + (int64_t)blockIdx.x * (CPT * SL_BLOCK); base < hi;
+             base += (int64_t)gridDim.x * (CPT * SL_BLOCK)) {
+            const int64_t wbase = base + wave_off;               // first of this wavefront's 64 CPT cells
+            bool neg2[CPT];
+            double vx2[CPT];
+            int64_t idx2[CPT];
+            uint64_t init2[CPT];
+            // everything this iteration reads from memory is requested first: the ~1000 cycles
+            // of arithmetic below hide the latency (measured before: 53 % of the wave time
+            // in s_waitcnt on the initial-set word, which was loaded after the ballot)
+#pragma unroll
+            for (int t = 0; t < CPT; ++t) {
+                const int64_t w0 = wbase + 64 * t;
+                const int64_t raw = w0 + lane2;
+                const int64_t idx = raw < hi ? raw : hi - 1;
+                init2[t] = (init_bits && w0 < hi) ? init_bits[(w0 - lo) >> 6] : 0ull;
+                vx2[t] = values ? values[idx - lo] : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < CPT; ++t) {
+                const int64_t raw = wbase + 64 * t + lane2;
+                const int64_t idx = raw < hi ? raw : hi - 1;
+                idx2[t] = raw;
+                double x[SL_P], u[SL_M], nxt[SL_D], err[SL_D];
+                uint32_t r = (uint32_t)idx;
+#pragma unroll
+                for (int k = DT - 1; k >= 0; --k) {
+                    const int ijk = (int)(r & axis_mask[k]);
+                    r >>= axis_shift[k];
+                    const double tt = (double)ijk * M.m.grid.unit_maxes[k];     // functions.py:731
+                    x[k] = tt + M.m.grid.offset[k];
+                }
+                sl_policy_any<GENERAL>(M, n2, aux.tri, idx, x, u);
+                sl_append_action(n2, u, x);
+                sl_dynamics_det<DYN>(M, n2, x, nxt);
+                SlCellCheck c = sl_cell_check<GENERAL>(M, n2.d, aux, x, nxt, err);
+                neg2[t] = c.negative && raw < hi;
+                if (!values) vx2[t] = c.v_x;                     // ordering key: lyapunov.py:512
+            }
+#pragma unroll
+            for (int t = 0; t < CPT; ++t) {
+                const uint64_t word = __ballot(neg2[t]);
+                const int64_t w0 = wbase + 64 * t;
+                if (w0 < hi) {
+                    const int64_t widx = (w0 - lo) >> 6;
+                    if (lane2 == 0) neg_bits[widx] = word;
+                    const bool ok = neg2[t] || ((init2[t] >> lane2) & 1ull);
+                    if (idx2[t] < hi && !ok) sl_key_min(bv, bi, sl_vbits(vx2[t]), idx2[t]);
+                }
+            }
+        }
+        sl_block_reduce_key<true>(bv, bi, sv, si);
+        if (threadIdx.x == 0) { partials[blockIdx.x].vbits = bv; partials[blockIdx.x].index = bi; }
+        return;
     }
     const SlDims n = sl_dims<DT, MT>(M);
     const int d = n.d;
@@ -458,27 +523,20 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
         const bool valid = idx < hi;
         bool negative = false;
         double v_x = 0.0;
+        // the initial-set word of this wavefront is requested before the arithmetic, not after
+        // the ballot (its latency was fully exposed there)
+        const int64_t wbase = base + (threadIdx.x & ~63);        // first cell of this wavefront
+        const uint64_t init = (init_bits && wbase < hi) ? init_bits[(wbase - lo) >> 6] : 0ull;
         if (valid) {
             double x[SL_P], u[SL_M], nxt[SL_D], err[SL_D];
-            if (POW2) {
-                uint32_t r = (uint32_t)idx;
-#pragma unroll
-                for (int k = DT - 1; k >= 0; --k) {
-                    const int ijk = (int)(r & axis_mask[k]);
-                    r >>= axis_shift[k];
-                    const double t = (double)ijk * M.m.grid.unit_maxes[k];     // functions.py:731
-                    x[k] = t + M.m.grid.offset[k];
-                }
-            } else {
-                sl_cell_state(M, d, idx, points, x);
-            }
+            sl_cell_state(M, d, idx, points, x);
             sl_policy_any<GENERAL>(M, n, aux.tri, idx, x, u);
             sl_append_action(n, u, x);
             sl_dynamics_det<DYN>(M, n, x, nxt);
             SlCellCheck c = sl_cell_check<GENERAL>(M, d, aux, x, nxt, err);
             negative = c.negative;
             v_x = values ? values[idx - lo] : c.v_x;       // ordering key: lyapunov.py:512
-            if (!POW2 && dbg) {
+            if (dbg) {
                 double* o = dbg + (idx - lo) * (2 + 2 * d);
                 o[0] = c.decrease; o[1] = c.threshold;
 #pragma unroll
@@ -486,11 +544,9 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
             }
         }
         const uint64_t word = __ballot(negative);
-        const int64_t wbase = base + (threadIdx.x & ~63);        // first cell of this wavefront
         if (wbase < hi) {
             const int64_t widx = (wbase - lo) >> 6;
             if (lane == 0) neg_bits[widx] = word;
-            const uint64_t init = init_bits ? init_bits[widx] : 0ull;
             const bool ok = negative || ((init >> lane) & 1ull);
             if (valid && !ok) sl_key_min(best_v, best_i, sl_vbits(v_x), idx);
         }
