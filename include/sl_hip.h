@@ -155,6 +155,15 @@ int  sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model);
 int  sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
                     const double* h_X, const double* h_Linv, const double* h_alpha,
                     double variance, const double* h_lengthscales);
+/* One more training point for an uploaded head (GaussianProcess.add_data_point,
+ * functions.py:525-546) without re-packing: the rank-one extension of the cached factors touches
+ * one new row of L^-1, so only that row is scattered into the fragment layout.
+ *   h_x [p], h_linv_row [n+1] = row n of the extended L^-1 (lower triangle incl. the diagonal),
+ *   h_alpha_new [dout] = the new last row of alpha = L^-1 (Y - m(X)).
+ * alpha' = Linv^T alpha gets the rank-one term linv_row * alpha_new.  Returns SL_ERR_UNSUPPORTED
+ * when the padded capacity of the head is exhausted (then call sl_gp_set_head again). */
+int  sl_gp_append_point(sl_ctx* ctx, int head, const double* h_x, const double* h_linv_row,
+                        const double* h_alpha_new);
 int  sl_gp_configure(sl_ctx* ctx, int nheads, double beta);
 
 /* Auxiliary grid #slot with a per-vertex table (Triangulation: functions.py:1002-1032,

@@ -26,8 +26,19 @@ def _dummy_grid(d):
 
 
 def _to_device(ctx, array):
+    """float64 device tensor of a NumPy array or tensor ([n, k])."""
     import torch
-    return torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64)).to(ctx.torch_device)
+    if isinstance(array, torch.Tensor):
+        t = array.to(device=ctx.torch_device, dtype=torch.float64)
+        return (t if t.dim() == 2 else t.reshape(len(t), -1)).contiguous()
+    array = np.atleast_2d(np.asarray(array, dtype=np.float64))
+    return torch.from_numpy(np.ascontiguousarray(array)).to(ctx.torch_device)
+
+
+def _on_device(x):
+    """Inputs given as device tensors keep the results on the device (no host round trip)."""
+    import torch
+    return isinstance(x, torch.Tensor)
 
 
 def _builder(d):
@@ -39,36 +50,38 @@ def value(spec, points, lipschitz=None):
     """``V(points)`` -> ``[n, 1]``; with ``lipschitz`` also returns ``L_v(points)``."""
     import torch
     from .functions import ConstantFunction, LinearSystem
-    points = np.atleast_2d(np.asarray(points, dtype=np.float64))
-    n, d = points.shape
+    keep = _on_device(points)
+    ctx = _ctx()
+    d_pts = _to_device(ctx, points)
+    n, d = d_pts.shape
     ctx, builder = _builder(d)
     builder.upload(ConstantFunction(np.zeros(1)), LinearSystem((np.eye(d), np.zeros((d, 1)))),
                    spec, 0.0 if lipschitz is None else lipschitz, 0.0, 0.0)
-    d_pts = _to_device(ctx, points)
     out = torch.empty((n, 1), dtype=torch.float64, device=ctx.torch_device)
     ctx.eval_points(_hip.EVAL_VALUE, n, d_pts, out)
     if lipschitz is None:
-        return out.cpu().numpy()
+        return out if keep else out.cpu().numpy()
     cols = 1 if builder._desc.lipschitz.lv_kind in (_hip.LIP_CONST, _hip.LIP_NORM_LINEAR,
                                                     _hip.LIP_NORM_GRAD) else d
     lv = torch.empty((n, cols), dtype=torch.float64, device=ctx.torch_device)
     ctx.eval_points(_hip.EVAL_LV, n, d_pts, lv)
-    return out.cpu().numpy(), lv.cpu().numpy()
+    return (out, lv) if keep else (out.cpu().numpy(), lv.cpu().numpy())
 
 
 def policy(spec, points):
     """``policy(points)`` -> ``[n, m]``."""
     import torch
     from .functions import LinearSystem, QuadraticFunction
-    points = np.atleast_2d(np.asarray(points, dtype=np.float64))
-    n, d = points.shape
+    keep = _on_device(points)
+    ctx = _ctx()
+    d_pts = _to_device(ctx, points)
+    n, d = d_pts.shape
     ctx, builder = _builder(d)
     m = _policy_output_dim(spec)
-    desc = builder.upload(spec, LinearSystem((np.eye(d), np.zeros((d, m)))),
-                          QuadraticFunction(np.eye(d)))
+    builder.upload(spec, LinearSystem((np.eye(d), np.zeros((d, m)))), QuadraticFunction(np.eye(d)))
     out = torch.empty((n, m), dtype=torch.float64, device=ctx.torch_device)
-    ctx.eval_points(_hip.EVAL_POLICY, n, _to_device(ctx, points), out)
-    return out.cpu().numpy()
+    ctx.eval_points(_hip.EVAL_POLICY, n, d_pts, out)
+    return out if keep else out.cpu().numpy()
 
 
 def _policy_output_dim(spec):
@@ -80,15 +93,17 @@ def dynamics(spec, states, actions):
     """``dynamics(states, actions)`` -> next states, or ``(mean, error)`` for uncertain specs."""
     import torch
     from .functions import QuadraticFunction, UncertainFunction
-    states = np.atleast_2d(np.asarray(states, dtype=np.float64))
-    actions = np.atleast_2d(np.asarray(actions, dtype=np.float64))
-    n, d = states.shape
+    keep = _on_device(states)
+    ctx = _ctx()
+    d_states = _to_device(ctx, states)
+    d_actions = _to_device(ctx, actions)
+    n, d = d_states.shape
     ctx, builder = _builder(d)
     builder.grid.nindex = n                      # the action table is indexed by the point index
-    builder.upload(np.ascontiguousarray(actions), spec, QuadraticFunction(np.eye(d)))
+    builder.upload(d_actions, spec, QuadraticFunction(np.eye(d)))
     out = torch.empty((n, 2 + 2 * d), dtype=torch.float64, device=ctx.torch_device)
-    ctx.eval_points(_hip.EVAL_DYNAMICS, n, _to_device(ctx, states), out)
-    rec = out.cpu().numpy()
+    ctx.eval_points(_hip.EVAL_DYNAMICS, n, d_states, out)
+    rec = out if keep else out.cpu().numpy()
     mean, err = rec[:, 2:2 + d], rec[:, 2 + d:]
     return (mean, err) if isinstance(spec, UncertainFunction) else mean
 

@@ -85,7 +85,7 @@ R_FAIL_V, R_FAIL_I, R_LAST_V, R_LAST_I, R_MAX_V, R_MAX_I, R_BELOW, R_SAFE = rang
 
 EXPORTS = [
     "sl_version", "sl_ctx_create", "sl_ctx_destroy", "sl_last_error", "sl_ctx_synchronize",
-    "sl_model_set", "sl_gp_set_head", "sl_gp_configure", "sl_tri_set", "sl_tri_set_table",
+    "sl_model_set", "sl_gp_set_head", "sl_gp_append_point", "sl_gp_configure", "sl_tri_set", "sl_tri_set_table",
     "sl_network_set", "sl_values", "sl_lyap_sweep", "sl_lyap_finalize", "sl_select_pass",
     "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_eval_points",
     "sl_comm_unique_id", "sl_comm_init", "sl_comm_destroy", "sl_allreduce_result", "sl_allgather",
@@ -122,6 +122,7 @@ def load_library():
     lib.sl_model_set.argtypes = [C.c_void_p, C.POINTER(ModelDesc)]
     lib.sl_gp_set_head.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    c_double_p, c_double_p, c_double_p, C.c_double, c_double_p]
+    lib.sl_gp_append_point.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]
     lib.sl_gp_configure.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.sl_tri_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(GridDesc), C.c_int,
                                C.POINTER(C.c_int32), c_double_p, c_double_p, C.c_int, C.c_int,
@@ -221,6 +222,17 @@ class Context(object):
         n, p = X.shape
         self.check(self.lib.sl_gp_set_head(self.handle, head, n, p, alpha.shape[1], col0, pX, pL,
                                            pA, float(variance), pls), "sl_gp_set_head")
+
+    def gp_append_point(self, head, x, linv_row, alpha_new):
+        """One more training point for an uploaded head; False if the head has to be re-packed."""
+        x, px = _as_c(x)
+        row, pr = _as_c(linv_row)
+        a, pa = _as_c(alpha_new)
+        rc = self.lib.sl_gp_append_point(self.handle, head, px, pr, pa)
+        if rc == -3:                                   # SL_ERR_UNSUPPORTED: capacity exhausted
+            return False
+        self.check(rc, "sl_gp_append_point")
+        return True
 
     def gp_configure(self, nheads, beta):
         self.check(self.lib.sl_gp_configure(self.handle, nheads, float(beta)), "sl_gp_configure")

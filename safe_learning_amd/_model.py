@@ -54,11 +54,17 @@ class ModelBuilder(object):
             # (policy(states) in reinforcement_learning.py:92 / lyapunov.py:436)
             pd.kind = _hip.POLICY_TRI
             self._upload_tri(1, inner)
-        elif isinstance(inner, np.ndarray):
-            table = np.ascontiguousarray(inner, dtype=np.float64).reshape(self.grid.nindex, -1)
+        elif isinstance(inner, (np.ndarray, torch.Tensor)):
+            # one action row per vertex / point; a device tensor is used in place
+            if isinstance(inner, torch.Tensor):
+                table = inner.to(device=self.ctx.torch_device, dtype=torch.float64)
+                table = table.reshape(self.grid.nindex, -1).contiguous()
+            else:
+                table = torch.from_numpy(np.ascontiguousarray(inner, dtype=np.float64).reshape(
+                    self.grid.nindex, -1)).to(self.ctx.torch_device)
             m = table.shape[1]
             pd.kind = _hip.POLICY_TABLE
-            self._policy_table = torch.from_numpy(table).to(self.ctx.torch_device)
+            self._policy_table = table
             pd.d_table = self._policy_table.data_ptr()
         else:
             raise TypeError('unsupported policy spec %r: use LinearSystem, Saturation(LinearSystem), '
@@ -105,14 +111,38 @@ class ModelBuilder(object):
         signature = tuple((gp._version, col0) for gp, _, col0 in heads) + (beta,)
         if signature == self._gp_signature:
             return
+        old = self._gp_signature
+        same_heads = (old is not None and len(old) == len(signature) and old[-1] == beta
+                      and all(o[1] == s[1] for o, s in zip(old[:-1], signature[:-1])))
         for h, (gp, _, col0) in enumerate(heads):
             if gp.X.shape[1] != p:
                 raise ValueError('GP inputs have %d columns, expected state+action = %d'
                                  % (gp.X.shape[1], p))
+            if same_heads and old[h][0] == gp._version:
+                continue                                # this head is already on the device
+            if same_heads and self._follow_appends(h, gp, old[h][0]):
+                continue                                # add_data_point: new rows only
             self.ctx.gp_set_head(h, gp.X, gp.cholesky_inverse, gp.alpha, col0, gp.kern.variance,
                                  gp.kern.lengthscales)
         self.ctx.gp_configure(len(heads), beta)
         self._gp_signature = signature
+
+    def _follow_appends(self, head, gp, uploaded_version):
+        """Bring an uploaded head up to date through ``GPRCached.append_data``'s log: one new row
+        of L^-1, one alpha row and one input per point (O(n) bytes) instead of re-packing and
+        re-uploading the whole factor (8 MB at n = 1024).  False when the log does not lead from
+        the uploaded state to the current one or the head's padded capacity is exhausted."""
+        chain, version = [], uploaded_version
+        for before, after, x, row, alpha_new in gp._append_log:
+            if before == version:
+                chain.append((x, row, alpha_new))
+                version = after
+        if version != gp._version or not chain:
+            return False
+        for x, row, alpha_new in chain:
+            if not self.ctx.gp_append_point(head, x, row, alpha_new):
+                return False
+        return True
 
     def _upload_tri(self, slot, tri):
         signature = (tri._table_version, tri.project)

@@ -419,6 +419,64 @@ extern "C" int sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int
     return SL_OK;
 }
 
+// row n of the extended L^-1 into the A-fragment layout, the rank-one term of alpha', the new
+// scaled input column
+__global__ void k_gp_append(const double* __restrict__ row, int n, int n_pad, int nslab2, int p,
+                            int dout, const double* __restrict__ x_scaled,
+                            const double* __restrict__ alpha_new, double* __restrict__ mpack,
+                            double* __restrict__ alphap, double* __restrict__ xs) {
+    const int I = n >> 4, r16 = n & 15;
+    const int count = n + 1 > p ? n + 1 : p;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < count; c += gridDim.x * blockDim.x) {
+        if (c <= n) {
+            const double v = row[c];
+            const int S2 = c >> 3, e = (c >> 2) & 1, k = c & 3;
+            mpack[(((size_t)I * nslab2 + S2) * 64 + 16 * k + r16) * 2 + e] = v;
+            for (int dd = 0; dd < dout; ++dd) alphap[(size_t)c * dout + dd] += v * alpha_new[dd];
+        }
+        if (c < p) xs[(size_t)c * n_pad + n] = x_scaled[c];
+    }
+}
+
+extern "C" int sl_gp_append_point(sl_ctx* ctx, int head, const double* h_x, const double* h_linv_row,
+                                  const double* h_alpha_new) {
+    if (!ctx || !h_x || !h_linv_row || !h_alpha_new)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_append_point: NULL argument");
+    if (head < 0 || head >= SL_MAX_GP_HEADS || !ctx->gp_heads[head].set)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_append_point: head %d not set", head);
+    SlGpHeadHost& hh = ctx->gp_heads[head];
+    SlGpHeadDev& dv = ctx->h_gp.head[head];
+    const int n = hh.n;
+    if (n + 1 > hh.n_pad)
+        return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_gp_append_point: capacity %d of head %d is "
+                                                "exhausted (upload the head again)", hh.n_pad, head);
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t need = sizeof(double) * (size_t)(n + 1 + hh.p + hh.dout);
+    if (need > ctx->scratch_bytes) {
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    std::vector<double> stage((size_t)(n + 1 + hh.p + hh.dout));
+    for (int c = 0; c <= n; ++c) stage[c] = h_linv_row[c];
+    for (int q = 0; q < hh.p; ++q) stage[n + 1 + q] = h_x[q] * dv.inv_ls[q];
+    for (int dd = 0; dd < hh.dout; ++dd) stage[n + 1 + hh.p + dd] = h_alpha_new[dd];
+    double* d_stage = reinterpret_cast<double*>(ctx->d_scratch);
+    SL_HIP_CHECK(ctx, hipMemcpy(d_stage, stage.data(), need, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_gp_append, dim3((n + hh.p + 256) / 256), dim3(256), 0, ctx->stream, d_stage, n,
+                       hh.n_pad, dv.nslab2, hh.p, hh.dout, d_stage + n + 1, d_stage + n + 1 + hh.p,
+                       hh.d_mpack, hh.d_alpha, hh.d_xs);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    hh.n = n + 1;
+    dv.n = n + 1;
+    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_gp, &ctx->h_gp, sizeof(SlGpDev), hipMemcpyHostToDevice));
+    return SL_OK;
+}
+
 extern "C" int sl_gp_configure(sl_ctx* ctx, int nheads, double beta) {
     if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_gp_configure: NULL context");
     if (nheads < 1 || nheads > SL_MAX_GP_HEADS)

@@ -467,13 +467,17 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
             // everything this iteration reads from memory is requested first: the ~1000 cycles
             // of arithmetic below hide the latency (measured before: 53 % of the wave time
             // in s_waitcnt on the initial-set word, which was loaded after the ballot)
+            // (the Euler variants keep their loads behind the long arithmetic: requesting them
+            // first costs registers there - 10.7 -> 13.2 ms at 128^4)
+            if (CPT > 1) {
 #pragma unroll
-            for (int t = 0; t < CPT; ++t) {
-                const int64_t w0 = wbase + 64 * t;
-                const int64_t raw = w0 + lane2;
-                const int64_t idx = raw < hi ? raw : hi - 1;
-                init2[t] = (init_bits && w0 < hi) ? init_bits[(w0 - lo) >> 6] : 0ull;
-                vx2[t] = values ? values[idx - lo] : 0.0;
+                for (int t = 0; t < CPT; ++t) {
+                    const int64_t w0 = wbase + 64 * t;
+                    const int64_t raw = w0 + lane2;
+                    const int64_t idx = raw < hi ? raw : hi - 1;
+                    init2[t] = (init_bits && w0 < hi) ? init_bits[(w0 - lo) >> 6] : 0ull;
+                    vx2[t] = values ? values[idx - lo] : 0.0;
+                }
             }
 #pragma unroll
             for (int t = 0; t < CPT; ++t) {
@@ -495,6 +499,8 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
                 SlCellCheck c = sl_cell_check<GENERAL>(M, n2.d, aux, x, nxt, err);
                 neg2[t] = c.negative && raw < hi;
                 if (!values) vx2[t] = c.v_x;                     // ordering key: lyapunov.py:512
+                else if (CPT == 1) vx2[t] = values[idx - lo];
+                if (CPT == 1) init2[t] = (init_bits && wbase < hi) ? init_bits[(wbase - lo) >> 6] : 0ull;
             }
 #pragma unroll
             for (int t = 0; t < CPT; ++t) {

@@ -362,6 +362,7 @@ class GPRCached(object):
         self.cholesky_inverse = scipy.linalg.solve_triangular(self.cholesky, np.eye(n), lower=True)
         self.cholesky_inverse = np.tril(self.cholesky_inverse)
         self._version = next(_TOKENS)
+        self._append_log = []          # rank-one extensions since the last full rebuild
 
     def append_data(self, x, y):
         """Add observations with a rank-one extension of the cached factors, O(n^2) per point
@@ -392,7 +393,10 @@ class GPRCached(object):
             self.cholesky, self.cholesky_inverse = chol, inv
             self.X = np.vstack((self.X, xi))
             self.Y = np.vstack((self.Y, yi))
-        self._version = next(_TOKENS)
+            # what the engine needs to follow without re-packing L^-1: the new row and alpha row
+            before, self._version = self._version, next(_TOKENS)
+            self._append_log.append((before, self._version, xi[0].copy(), inv[n, :n + 1].copy(),
+                                     self.alpha[n].copy()))
 
 
 class GaussianProcess(UncertainFunction):

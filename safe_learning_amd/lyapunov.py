@@ -222,6 +222,19 @@ class Lyapunov(object):
             self._safe_dev_valid = False
         return self._safe_host
 
+    def _safe_bytes_device(self):
+        """The safe set as ``uint8[nindex]`` on the device (no host copy): the mask words every
+        rank holds after ``update_safe_set``, or the host array if the caller edited it."""
+        import torch
+        n = self.discretization.nindex
+        dev = self._ctx.torch_device
+        if self._safe_host_valid and not self._safe_dev_valid:
+            return torch.from_numpy(self._safe_host.view(np.uint8)).to(dev)
+        words = self._d_safe_full if self._d_safe_full is not None else self._d_safe
+        d_bytes = torch.empty(max(-(-n // 8) * 8, 8), dtype=torch.uint8, device=dev)
+        self._ctx.bits_to_bytes(n, words, d_bytes)
+        return d_bytes[:n]
+
     @safe_set.setter
     def safe_set(self, value):
         self._safe_host[:] = value
@@ -571,52 +584,113 @@ def perturb_actions(states, actions, perturbations, limits=None):
     return pairs
 
 
+def _index_to_state_device(grid, idx):
+    """``GridWorld.index_to_state`` (functions.py:714-731) for a device tensor of flat indices."""
+    import torch
+    dev = idx.device
+    rem, cols = idx, []
+    for n in reversed([int(v) for v in grid.num_points]):
+        cols.append(rem % n)
+        rem = torch.div(rem, n, rounding_mode='floor')
+    ijk = torch.stack(cols[::-1], dim=1).to(torch.float64)
+    unit = torch.from_numpy(np.asarray(grid.unit_maxes, dtype=np.float64)).to(dev)
+    offset = torch.from_numpy(np.asarray(grid.offset, dtype=np.float64)).to(dev)
+    return ijk * unit + offset                                   # multiply, then add
+
+
+def _state_to_index_device(grid, states):
+    """``GridWorld.state_to_index`` (functions.py:733-752) on the device (round half to even)."""
+    import torch
+    dev = states.device
+    lo = torch.from_numpy(np.asarray(grid.limits[:, 0], dtype=np.float64)).to(dev)
+    hi = torch.from_numpy(np.asarray(grid.limits[:, 1], dtype=np.float64)).to(dev)
+    inv = torch.from_numpy(1. / np.asarray(grid.unit_maxes, dtype=np.float64)).to(dev)
+    offset = torch.from_numpy(np.asarray(grid.offset, dtype=np.float64)).to(dev)
+    ijk = torch.round((torch.minimum(torch.maximum(states, lo), hi) - offset) * inv).to(torch.int64)
+    flat = torch.zeros(len(states), dtype=torch.int64, device=dev)
+    for k, n in enumerate(int(v) for v in grid.num_points):
+        flat = flat * n + ijk[:, k]
+    return flat
+
+
+def _unique_rows_device(rows):
+    """Unique rows in the byte-wise order of ``safe_learning/utilities.py:496-516`` (memcmp of the
+    raw float64 bytes) on the device."""
+    import torch
+    n, k = rows.shape
+    as_bytes = rows.contiguous().view(torch.uint8).reshape(n, 8 * k)
+    return torch.unique(as_bytes, dim=0).contiguous().view(torch.float64).reshape(-1, k)
+
+
 def get_safe_sample(lyapunov, perturbations=None, limits=None, positive=False,
                     num_samples=None, actions=None):
     """Most uncertain safe state-action pair for the next measurement (``lyapunov.py:657-797``).
 
-    The candidate bookkeeping is host-side NumPy as in the reference; the GP posterior, ``V`` and
-    ``L_v`` at the candidates are evaluated by the HIP kernels (explicit-point mode of the sweep
-    kernels).  Returns ``(state_action[1, d+m], bound)``."""
+    Everything that scales with the safe set stays on the GPU: the safe cells come from the
+    device mask, their states / perturbed actions / duplicate removal are tensor operations, the
+    GP posterior, ``V`` and ``L_v`` at the candidates come from the HIP kernels (explicit-point
+    mode), the membership test ``safe_set[state_to_index(mean)]`` and the arg-max run on the
+    device.  Only the winning row travels to the host.  Returns ``(state_action[1, d+m], bound)``."""
     import warnings
+    import torch
     from . import _evaluate
     grid = lyapunov.discretization
-    safe_states = grid.index_to_state(np.where(lyapunov.safe_set)[0])
-    if num_samples is not None and len(safe_states) > num_samples:
-        safe_states = safe_states[np.random.choice(len(safe_states), num_samples, replace=True)]
+    d = grid.ndim
+    safe_bytes = lyapunov._safe_bytes_device()                   # uint8[nindex] on the device
+    safe_idx = torch.nonzero(safe_bytes, as_tuple=False).reshape(-1)
+    if num_samples is not None and len(safe_idx) > num_samples:
+        pick = np.random.choice(len(safe_idx), num_samples, replace=True)     # the reference's draw
+        safe_idx = safe_idx[torch.from_numpy(pick).to(safe_idx.device)]
+    safe_states = _index_to_state_device(grid, safe_idx)
     safe_actions = None
     if perturbations is None:
-        mesh = np.meshgrid(safe_states, actions, indexing='ij')
-        state_actions = np.column_stack([m.ravel() for m in mesh])
+        host_states = safe_states.cpu().numpy()
+        mesh = np.meshgrid(host_states, actions, indexing='ij')
+        state_actions = torch.from_numpy(np.column_stack([m.ravel() for m in mesh])).to(safe_states.device)
     else:
         safe_actions = _evaluate.policy(lyapunov.policy, safe_states)
-        state_actions = perturb_actions(safe_states, safe_actions, perturbations, limits)
-    d = grid.ndim
+        state_actions = _perturb_actions_device(safe_states, safe_actions, perturbations, limits)
 
     def evaluate(pairs):
-        mean, std = _evaluate.dynamics(lyapunov.dynamics, pairs[:, :d], pairs[:, d:])
-        value, lv = _evaluate.value(lyapunov.lyapunov_function, mean, lyapunov._lipschitz_lyapunov)
-        bound = std[:, [0]].copy()
+        mean, std = _evaluate.dynamics(lyapunov.dynamics, pairs[:, :d].contiguous(),
+                                       pairs[:, d:].contiguous())
+        value, lv = _evaluate.value(lyapunov.lyapunov_function, mean.contiguous(),
+                                    lyapunov._lipschitz_lyapunov)
+        bound = std[:, [0]].clone()
         scaled = lv * std
-        error = scaled[:, [0]].copy()
-        for k in range(1, std.shape[1]):
+        error = scaled[:, [0]].clone()
+        for k in range(1, std.shape[1]):                         # left to right like the oracle
             bound = bound + std[:, [k]]
             error = error + scaled[:, [k]]
         return mean, bound, ((value + error) < lyapunov.c_max)[:, 0]
 
     mean, bound, maps_inside = evaluate(state_actions)
     if not positive:
-        maps_inside &= lyapunov.safe_set[grid.state_to_index(mean)]
-    if not maps_inside.any():
+        maps_inside &= safe_bytes[_state_to_index_device(grid, mean)].to(torch.bool)
+    if not bool(maps_inside.any()):
         warnings.warn("No safe state-action pairs found! Using backup policy ...", RuntimeWarning)
-        state_actions = perturb_actions(safe_states, safe_actions, np.array([[0.]]), limits)
+        state_actions = _perturb_actions_device(safe_states, safe_actions, np.array([[0.]]), limits)
         _, bound, _ = evaluate(state_actions)
-        best = int(np.argmax(bound))
-        return state_actions[[best]], float(bound[best, 0])
+        best = int(torch.argmax(bound[:, 0]))
+        return state_actions[[best]].cpu().numpy(), float(bound[best, 0])
     candidates = state_actions[maps_inside]
     bound = bound[maps_inside]
-    best = int(np.argmax(bound))
-    return candidates[[best]], float(bound[best, 0])
+    best = int(torch.argmax(bound[:, 0]))
+    return candidates[[best]].cpu().numpy(), float(bound[best, 0])
+
+
+def _perturb_actions_device(states, actions, perturbations, limits):
+    """``perturb_actions`` (``lyapunov.py:609-651``) on device tensors."""
+    import torch
+    dev = states.device
+    pert = torch.from_numpy(np.atleast_2d(np.asarray(perturbations, dtype=np.float64))).to(dev)
+    count, state_dim = len(pert), states.shape[1]
+    acts = actions.repeat_interleave(count, dim=0) + pert.repeat(len(states), 1)
+    if limits is not None:
+        lim = torch.from_numpy(np.asarray(limits, dtype=np.float64)).to(dev)
+        acts = torch.minimum(torch.maximum(acts, lim[:, 0]), lim[:, 1])
+    pairs = torch.cat((states.repeat_interleave(count, dim=0), acts), dim=1)
+    return _unique_rows_device(pairs) if limits is not None else pairs
 
 
 def get_lyapunov_region(lyapunov, discretization, init_node):
