@@ -245,6 +245,8 @@ class Lyapunov(object):
     def _refinement(self):
         """Refinement N(x) per cell (``lyapunov.py:220-225``): the array kept by the adaptive
         branch, otherwise 1 on safe cells and 0 elsewhere (``:531, 586, 601-606``)."""
+        if self._refinement_host is None and getattr(self, '_refinement_dev', None) is not None:
+            self._refinement_host = self._refinement_dev.cpu().numpy().astype(int)
         if self._refinement_host is not None:
             return self._refinement_host
         return self.safe_set.astype(int)
@@ -337,6 +339,7 @@ class Lyapunov(object):
         if self.adaptive and max_refinement > 1:
             return self._update_safe_set_adaptive(can_shrink, max_refinement, safety_factor)
         self._refinement_host = None
+        self._refinement_dev = None
         self._upload_model()
         self._refresh_init_bits()
         if not can_shrink and not self._safe_dev_valid:          # lyapunov.py:507-510
@@ -355,50 +358,92 @@ class Lyapunov(object):
             self._d_safe_full = dist_utils.allgather_concat(self._d_safe[:sizes[self._rank]], sizes)
 
 
+    def _threshold_base_device(self):
+        """``-|L_v(x)|_1 (1 + L_f(x))`` at every grid cell as a device tensor (the refined
+        threshold of the adaptive branch is this times ``tau / N(x)``): ``threshold(x, tau=1)``
+        with the same operation order, ``L_v`` from the point-evaluation kernels."""
+        import torch
+        from . import _evaluate
+        n = self.discretization.nindex
+        dev = self._ctx.torch_device
+        lvs, lfs = self._lipschitz_lyapunov, self._lipschitz_dynamics
+        states = None
+        if not (np.isscalar(lvs) and np.isscalar(lfs)):
+            states = _index_to_state_device(self.discretization,
+                                            torch.arange(n, dtype=torch.int64, device=dev))
+        if np.isscalar(lvs):
+            lv = torch.full((n,), float(lvs), dtype=torch.float64, device=dev)
+        else:
+            lv = _evaluate.value(self.lyapunov_function, states, lvs)[1]
+            if lv.shape[1] > 1:
+                acc = lv[:, 0].abs()
+                for k in range(1, lv.shape[1]):
+                    acc = acc + lv[:, k].abs()
+                lv = acc
+            else:
+                lv = lv[:, 0]
+        if np.isscalar(lfs):
+            lf = float(lfs)
+        else:
+            rows = torch.from_numpy(np.asarray(lfs.fun.matrix, dtype=np.float64)).to(dev)
+            acc = None
+            for r in range(rows.shape[0]):
+                t = states[:, 0] * rows[r, 0]
+                for k in range(1, states.shape[1]):
+                    t = t + states[:, k] * rows[r, k]
+                acc = t.abs() if acc is None else acc + t.abs()
+            lf = lfs.constant + acc
+        return (-lv) * (1. + lf) * 1.0
+
     def _update_safe_set_adaptive(self, can_shrink, max_refinement, safety_factor):
         """Adaptive discretisation (``lyapunov.py:445-487, 540-582``), bug-compatible: as written
         in the reference the refined check compares the decrease of every cell of the candidate
         run with each cell's refined threshold ``threshold(x, tau / N(x))`` (the refined points
-        themselves are never evaluated), see DESIGN.md."""
+        themselves are never evaluated), see DESIGN.md.
+
+        Everything of grid size stays on the GPU: the per-cell quantities come from one sweep of
+        this rank's shard, the ascending-V order from a stable device sort (no host ``argsort``),
+        and the batch loop of the reference runs over device slices with a few scalar read-backs
+        per batch; it ends at the first batch that cannot be refined, like the reference's."""
         import torch
-        grid, n, d = self.discretization, self.discretization.nindex, self.discretization.ndim
+        n, d = self.discretization.nindex, self.discretization.ndim
+        dev = self._ctx.torch_device
         batch = int(config.gp_batch_size)
         safety_factor = max(float(safety_factor), 1.)
         self._upload_model()
         self._refresh_init_bits()
-        # one sweep of this rank's shard: negative mask and the per-cell [decrease, threshold]
-        # records; every rank then gathers them and runs the same (sequential) refinement pass
         lo, hi = self._lo, self._hi
         count = hi - lo
         sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
-        records = torch.empty((max(count, 1), 2 + 2 * d), dtype=torch.float64,
-                              device=self._ctx.torch_device)
+        records = torch.empty((max(count, 1), 2 + 2 * d), dtype=torch.float64, device=dev)
         self._ctx.lyap_sweep(lo, hi, self._d_init, self._d_values, self._d_neg, self._d_result, records)
-        decrease = dist_utils.allgather_concat(records[:count, 0].contiguous(), sizes).cpu().numpy()
-        threshold = dist_utils.allgather_concat(records[:count, 1].contiguous(), sizes).cpu().numpy()
-        d_bytes = torch.empty(max(-(-count // 8) * 8, 8), dtype=torch.uint8, device=self._ctx.torch_device)
+        decrease = dist_utils.allgather_concat(records[:count, 0].contiguous(), sizes)
+        threshold = dist_utils.allgather_concat(records[:count, 1].contiguous(), sizes)
+        d_bytes = torch.empty(max(-(-count // 8) * 8, 8), dtype=torch.uint8, device=dev)
         self._ctx.bits_to_bytes(count, self._d_neg, d_bytes)
-        negative = dist_utils.allgather_concat(d_bytes[:count], sizes).cpu().numpy().astype(bool)
-        values = self.values
-        # -|L_v(x)|_1 (1 + L_f): the refined threshold is this times tau / N(x)
-        base = self.threshold(grid.index_to_state(np.arange(n)), tau=1.0)
-        base = np.broadcast_to(np.asarray(base, dtype=np.float64).reshape(-1), (n,)) \
-            if np.ndim(base) else np.full(n, float(base))
-        init_mask = np.zeros(n, dtype=bool)
+        negative = dist_utils.allgather_concat(d_bytes[:count], sizes).to(torch.bool)
+        values = self._d_values_full if self._d_values_full is not None else self._d_values[:count]
+        base = self._threshold_base_device()
+        init_mask = torch.zeros(n, dtype=torch.bool, device=dev)
         if self._initial_safe_set is not None:
-            init_mask[self._initial_safe_set] = True
+            init = np.asarray(self._initial_safe_set)
+            if init.dtype == bool and init.shape == (n,):
+                init_mask = torch.from_numpy(init).to(dev)
+            else:
+                init_mask[torch.from_numpy(np.atleast_1d(init).astype(np.int64)).to(dev)] = True
 
         if can_shrink:
-            safe_src = init_mask.copy()
-            refine_src = init_mask.astype(int)
+            safe_src = init_mask.clone()
+            refine_src = init_mask.to(torch.int64)
         else:
-            safe_src = self.safe_set.copy()
-            refine_src = np.array(self._refinement, dtype=int)
-        order = np.argsort(values, kind='stable')
+            safe_src = self._safe_bytes_device().to(torch.bool).clone()
+            refine_src = self._refinement_device().clone()
+        order = torch.sort(values, stable=True).indices          # ascending (V, flat index)
         safe_sorted, refinement = safe_src[order], refine_src[order]
-        with np.errstate(divide='ignore', invalid='ignore'):
-            ratio = safety_factor * threshold / decrease
-        n_req_all = np.ceil(np.maximum(np.where(np.isnan(ratio), 0., ratio), 0.))
+        ratio = safety_factor * threshold / decrease
+        n_req_all = torch.ceil(torch.clamp(torch.where(torch.isnan(ratio), torch.zeros_like(ratio),
+                                                       ratio), min=0.))
+        n_req_all = torch.clamp(n_req_all, max=float(1 << 40)).to(torch.int64)   # inf -> "too many"
 
         start = bound = refine_bound = 0
         for start in range(0, n, batch):
@@ -407,21 +452,21 @@ class Lyapunov(object):
             neg_b = negative[idx]
             safe_b |= neg_b
             ref_b[neg_b] = 1
-            unsafe = np.flatnonzero(~safe_b)
+            unsafe = torch.nonzero(~safe_b, as_tuple=False)
             bound, refine_bound = (int(unsafe[0]) if len(unsafe) else 0), 0
             if not len(unsafe):
                 continue
             ref_b[bound:] = n_req_all[idx[bound:]]
             ref_b[neg_b | init_mask[idx]] = 1
             checkable = ((ref_b >= 1) & (ref_b <= max_refinement))[bound:]
-            stop = len(checkable) if checkable.all() else int(np.argmin(checkable))
+            stop = len(checkable) if bool(checkable.all()) else int(torch.argmin(checkable.to(torch.uint8)))
             if stop > 0:
                 run = idx[bound:bound + stop]
                 run_dec = decrease[run]
-                refined_thr = base[run] * (self.tau / ref_b[bound:bound + stop])
-                worst = np.max(run_dec) if not np.isnan(run_dec).any() else np.inf
+                refined_thr = base[run] * (self.tau / ref_b[bound:bound + stop].to(torch.float64))
+                worst = float(run_dec.max()) if not bool(torch.isnan(run_dec).any()) else float('inf')
                 refined_safe = worst < refined_thr
-                refine_bound = stop if refined_safe.all() else int(np.argmin(refined_safe))
+                refine_bound = stop if bool(refined_safe.all()) else int(torch.argmin(refined_safe.to(torch.uint8)))
                 safe_b[bound:bound + refine_bound] = True
             if stop < len(checkable) or refine_bound < stop:
                 safe_b[bound + refine_bound:] = False
@@ -429,15 +474,33 @@ class Lyapunov(object):
                 break
 
         self.c_max = float(values[order[start + bound + refine_bound - 1]])
-        self._safe_host[:] = False
-        self._safe_host[order[safe_sorted]] = True
-        self._refinement_host = np.zeros(n, dtype=int)
-        self._refinement_host[order] = refinement
-        if self._initial_safe_set is not None:
-            self._safe_host[self._initial_safe_set] = True
-            self._refinement_host[self._initial_safe_set] = 1
-        self._safe_host_valid = True
-        self._safe_dev_valid = False
+        safe = torch.zeros(n, dtype=torch.bool, device=dev)
+        safe[order[safe_sorted]] = True
+        refine = torch.zeros(n, dtype=torch.int64, device=dev)
+        refine[order] = refinement
+        safe |= init_mask
+        refine[init_mask] = 1
+        self._refinement_dev = refine
+        self._refinement_host = None
+        self.safe_count = int(safe.sum())
+        # the mask goes straight into this rank's bit words (and the gathered copy)
+        full_bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+        self._ctx.bytes_to_bits(n, safe.to(torch.uint8).contiguous(), full_bits)
+        nwords = (count + 63) // 64
+        self._d_safe[:nwords] = full_bits[lo // 64:lo // 64 + nwords]
+        self._d_safe_full = full_bits if self._world > 1 else None
+        self._safe_host_valid = False
+        self._safe_dev_valid = True
+
+    def _refinement_device(self):
+        """Refinement N(x) per cell as a device tensor (int64[nindex])."""
+        import torch
+        if getattr(self, '_refinement_dev', None) is not None:
+            return self._refinement_dev
+        if self._refinement_host is not None:
+            return torch.from_numpy(np.asarray(self._refinement_host, dtype=np.int64)).to(
+                self._ctx.torch_device)
+        return self._safe_bytes_device().to(torch.int64)
 
 
 class _HipShardEngine(object):
