@@ -173,6 +173,28 @@ def headline_case(num_points=128, n_gp=1024, family='cartpole', stack=False, var
                      tau_scale=HEADLINE_TAU_SCALE, **hyper)
 
 
+def table_case(num_points=(2001, 1501), table_points=(101, 101), n_gp=128, tau_scale=0.0005):
+    """The table-V / table-policy Lyapunov sweep of ``inverted_pendulum.ipynb`` (cell 14:
+    ``lyapunov_function = -rl.value_function``, ``L_v = |gradient|``, the policy a Triangulation
+    on the value grid; ``:112`` runs it on 2001 x 1501 cells): pendulum, RBF GP dynamics, V a
+    piecewise-linear table (a quadratic plus a smooth bump, so the simplices differ), policy the
+    saturated LQR law sampled on the same table grid."""
+    case = make_case('pendulum', num_points=list(num_points), n_gp=n_gp, tau_scale=tau_scale,
+                     **GP_VARIANTS['informed'])
+    axes = [np.linspace(lo, hi, n) for (lo, hi), n in zip(case['limits'], table_points)]
+    pts = np.stack(np.meshgrid(*axes, indexing='ij'), axis=-1).reshape(-1, case['d'])
+    vals = np.einsum('ij,jk,ik->i', pts, case['P'], pts)
+    vals = vals * (1.0 + 0.05 * np.sin(3.0 * pts[:, 0]) * np.cos(2.0 * pts[:, 1]))
+    case['V'] = {'kind': 'table', 'values': vals[:, None], 'project': True,
+                 'num_points': list(table_points)}
+    case['lv'] = ('abs_grad',)
+    act = pts @ case['K'].T
+    if case['saturate'] is not None:
+        act = np.clip(act, *case['saturate'])
+    case['policy_table'] = {'num_points': list(table_points), 'values': act}
+    return case
+
+
 def initial_safe_mask(case):
     """``||x||_2 <= radius`` on the grid without materialising all points
     (``adaptive_safety_verification.ipynb`` cell 11)."""
@@ -188,7 +210,12 @@ def initial_safe_mask(case):
 def build_specs(case):
     """Engine specs (policy, dynamics, V, L_v) of a case."""
     from . import functions as F
-    policy = F.LinearSystem((case['K'],))
+    if 'policy_table' in case:
+        # piecewise-linear policy of the RL loop (inverted_pendulum.ipynb cells 9-13)
+        tab = case['policy_table']
+        policy = F.Triangulation(F.GridWorld(case['limits'], tab['num_points']), tab['values'])
+    else:
+        policy = F.LinearSystem((case['K'],))
     if case['saturate'] is not None:
         policy = F.Saturation(policy, *case['saturate'])
     dyn = case['dynamics']
@@ -223,8 +250,9 @@ def build_specs(case):
         value = F.LyapunovNetwork(case['d'], vspec['layer_dims'], vspec['activations'],
                                   vspec['eps'], vspec['weights'])
     else:
-        value = F.Triangulation(F.GridWorld(case['limits'], case['num_points']), vspec['values'],
-                                project=vspec.get('project', False))
+        value = F.Triangulation(F.GridWorld(case['limits'],
+                                            vspec.get('num_points', case['num_points'])),
+                                vspec['values'], project=vspec.get('project', False))
     kind, arg = (case['lv'] + (None,))[:2]
     if kind == 'const':
         lv = arg

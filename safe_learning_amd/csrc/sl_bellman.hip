@@ -910,7 +910,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_eval_simple(const SlDevModel M, Sl
 #pragma unroll
         for (int k = 0; k < SL_D; ++k) if (k < d) x[k] = points[i * d + k];
         if (what == SL_EVAL_VALUE) {
-            out[i] = sl_value_any<true>(M, d, aux, x);
+            out[i] = sl_value_any<SL_FULL>(M, d, aux, x);
         } else if (what == SL_EVAL_POLICY) {
             double u[SL_M];
             sl_policy_any<true>(M, nd, aux.tri, 0, x, u);
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_eval_simple(const SlDevModel M, Sl
             for (int a = 0; a < SL_M; ++a) if (a < nd.m) out[i * nd.m + a] = u[a];
         } else {   // SL_EVAL_LV
             double lv[SL_D];
-            sl_lv_any<true>(M, d, aux, x, lv);
+            sl_lv_any<SL_FULL>(M, d, aux, x, lv);
             const int cols = M.m.lipschitz.lv_cols;
 #pragma unroll
             for (int k = 0; k < SL_D; ++k) if (k < cols) out[i * cols + k] = lv[k];

@@ -197,12 +197,21 @@ __device__ inline double sl_network_value(const SlNet& net, const double* z, int
 }
 
 
-// V(z).  GENERAL = false: quadratic only.
-template <bool GENERAL>
+// Flavours of the value / L_v code: SL_FAST quadratic V only (no scratch), SL_TABLES adds the
+// interpolated table (V = -value_function of the RL loop, |tri.gradient| as L_v), SL_FULL also the
+// per-thread LyapunovNetwork (4.6 KB of private arrays per lane).  The grid sweeps never need
+// SL_FULL: a network V is routed to the matrix-core kernels of sl_nn.hip, so their "general"
+// instantiations are compiled as SL_TABLES and carry no network scratch; only the point
+// evaluation of sl_eval_points uses SL_FULL.
+enum { SL_FAST = 0, SL_FULL = 1, SL_TABLES = 2 };
+template <bool GENERAL> struct SlSweepFlavour { static constexpr int value = GENERAL ? SL_TABLES : SL_FAST; };
+
+// V(z)
+template <int G>
 __device__ __forceinline__ double sl_value_any(const SlDevModel& M, int d, const SlAux& aux,
                                                const double* z) {
-    if (!GENERAL || M.m.value.kind == SL_V_QUADRATIC) return sl_quadratic(M.m.value, d, z);
-    if (M.m.value.kind == SL_V_TRI) {
+    if (G == SL_FAST || M.m.value.kind == SL_V_QUADRATIC) return sl_quadratic(M.m.value, d, z);
+    if (G == SL_TABLES || M.m.value.kind == SL_V_TRI) {
         double v = sl_tri_eval(aux.tri[0], z, 0, nullptr);
         return M.m.value.negate ? (v * -1.0) : v;
     }
@@ -211,13 +220,13 @@ __device__ __forceinline__ double sl_value_any(const SlDevModel& M, int d, const
 }
 
 // L_v(z) including |grad V|
-template <bool GENERAL>
+template <int G>
 __device__ __forceinline__ void sl_lv_any(const SlDevModel& M, int d, const SlAux& aux,
                                           const double* z, double* lv) {
     const int kind = M.m.lipschitz.lv_kind;
-    if (!GENERAL || (kind != SL_LIP_ABS_GRAD && kind != SL_LIP_NORM_GRAD)) { sl_lv(M, d, z, lv); return; }
+    if (G == SL_FAST || (kind != SL_LIP_ABS_GRAD && kind != SL_LIP_NORM_GRAD)) { sl_lv(M, d, z, lv); return; }
     double g[SL_D];
-    if (M.m.value.kind == SL_V_TRI) sl_tri_eval(aux.tri[0], z, 0, g);
+    if (G == SL_TABLES || M.m.value.kind == SL_V_TRI) sl_tri_eval(aux.tri[0], z, 0, g);
     else sl_network_value(*aux.net, z, d, g);
     if (M.m.value.negate) {
 #pragma unroll
@@ -236,11 +245,11 @@ __device__ __forceinline__ void sl_lv_any(const SlDevModel& M, int d, const SlAu
 
 // V(z) and L_v(z) together: a network value function shares one forward pass between the value
 // and its input gradient (lyapunov_function_learning.ipynb cell 19: L_v = |grad V|_1).
-template <bool GENERAL>
+template <int G>
 __device__ __forceinline__ double sl_value_and_lv(const SlDevModel& M, int d, const SlAux& aux,
                                                   const double* z, double* lv) {
     const int kind = M.m.lipschitz.lv_kind;
-    if (GENERAL && M.m.value.kind == SL_V_NETWORK &&
+    if (G == SL_FULL && M.m.value.kind == SL_V_NETWORK &&
         (kind == SL_LIP_ABS_GRAD || kind == SL_LIP_NORM_GRAD)) {
         double g[SL_D];
         double v = sl_network_value(*aux.net, z, d, g);
@@ -256,20 +265,20 @@ __device__ __forceinline__ double sl_value_and_lv(const SlDevModel& M, int d, co
         }
         return v;
     }
-    sl_lv_any<GENERAL>(M, d, aux, z, lv);
-    return sl_value_any<GENERAL>(M, d, aux, z);
+    sl_lv_any<G>(M, d, aux, z, lv);
+    return sl_value_any<G>(M, d, aux, z);
 }
 
-template <bool GENERAL>
+template <int G>
 __device__ __forceinline__ SlCellCheck sl_cell_check(const SlDevModel& M, int d, const SlAux& aux,
                                                      const double* x, const double* next_mean,
                                                      const double* err) {
     SlCellCheck r;
     double lv_x[SL_D], lv_n[SL_D];
-    r.v_x = sl_value_and_lv<GENERAL>(M, d, aux, x, lv_x);
+    r.v_x = sl_value_and_lv<G>(M, d, aux, x, lv_x);
     double v_next;
-    if (M.uncertain) v_next = sl_value_and_lv<GENERAL>(M, d, aux, next_mean, lv_n);
-    else v_next = sl_value_any<GENERAL>(M, d, aux, next_mean);
+    if (M.uncertain) v_next = sl_value_and_lv<G>(M, d, aux, next_mean, lv_n);
+    else v_next = sl_value_any<G>(M, d, aux, next_mean);
     r.decrease = sl_decrease(M, d, r.v_x, v_next, lv_n, err);
     r.threshold = sl_threshold(M, d, lv_x, M.m.lipschitz.tau, x);
     r.negative = r.decrease < r.threshold;

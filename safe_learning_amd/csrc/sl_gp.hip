@@ -305,7 +305,7 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                     err[k] = cell_err[tid * SL_D + k];
                 }
             }
-            SlCellCheck c = sl_cell_check<GENERAL>(M, d, aux, x, mean, err);
+            SlCellCheck c = sl_cell_check<SlSweepFlavour<GENERAL>::value>(M, d, aux, x, mean, err);
             negative = c.negative;
             v_x = values ? values[idx - lo] : c.v_x;       // ordering key: lyapunov.py:512
             if (dbg) {

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                     err[k] = cell_err[tid * SL_D + k];
                 }
             }
-            SlCellCheck c = sl_cell_check<false>(M, d, aux, x, mean, err);
+            SlCellCheck c = sl_cell_check<SL_FAST>(M, d, aux, x, mean, err);
             negative = c.negative;
             v_x = values ? values[idx - lo] : c.v_x;       // ordering key: lyapunov.py:512
             if (dbg) {

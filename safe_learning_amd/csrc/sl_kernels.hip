@@ -357,7 +357,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_values(const SlDevModel M_arg, SlA
          idx += (int64_t)gridDim.x * SL_BLOCK) {
         double x[SL_P];
         sl_index_to_grid_point(M.m.grid, M.gf, n.d, idx, x);
-        values[idx - lo] = sl_value_any<GENERAL>(M, n.d, aux, x);
+        values[idx - lo] = sl_value_any<SlSweepFlavour<GENERAL>::value>(M, n.d, aux, x);
     }
 }
 
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
                 sl_policy_any<GENERAL>(M, n2, aux.tri, idx, x, u);
                 sl_append_action(n2, u, x);
                 sl_dynamics_det<DYN>(M, n2, x, nxt);
-                SlCellCheck c = sl_cell_check<GENERAL>(M, n2.d, aux, x, nxt, err);
+                SlCellCheck c = sl_cell_check<SlSweepFlavour<GENERAL>::value>(M, n2.d, aux, x, nxt, err);
                 neg2[t] = c.negative && raw < hi;
                 if (!values) vx2[t] = c.v_x;                     // ordering key: lyapunov.py:512
                 else if (CPT == 1) vx2[t] = values[idx - lo];
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
             sl_policy_any<GENERAL>(M, n, aux.tri, idx, x, u);
             sl_append_action(n, u, x);
             sl_dynamics_det<DYN>(M, n, x, nxt);
-            SlCellCheck c = sl_cell_check<GENERAL>(M, d, aux, x, nxt, err);
+            SlCellCheck c = sl_cell_check<SlSweepFlavour<GENERAL>::value>(M, d, aux, x, nxt, err);
             negative = c.negative;
             v_x = values ? values[idx - lo] : c.v_x;       // ordering key: lyapunov.py:512
             if (dbg) {

@@ -8,7 +8,12 @@ from safe_learning_amd.benchmarks import initial_safe_mask, make_case  # noqa: F
 
 
 def oracle_specs(case):
-    policy = oracle.LinearSystem((case['K'],))
+    if 'policy_table' in case:
+        tab = case['policy_table']
+        policy = oracle.Triangulation(oracle.GridWorld(case['limits'], tab['num_points']),
+                                      tab['values'])
+    else:
+        policy = oracle.LinearSystem((case['K'],))
     if case['saturate'] is not None:
         policy = oracle.Saturation(policy, *case['saturate'])
     dyn = case['dynamics']
@@ -45,7 +50,8 @@ def oracle_specs(case):
                                        vspec['eps'], vspec['weights'])
         gradient = value.gradient
     else:
-        value = oracle.Triangulation(oracle.GridWorld(case['limits'], case['num_points']),
+        value = oracle.Triangulation(oracle.GridWorld(case['limits'],
+                                                      vspec.get('num_points', case['num_points'])),
                                      vspec['values'], project=vspec.get('project', False))
         gradient = value.gradient
     kind, arg = (case['lv'] + (None,))[:2]

@@ -47,5 +47,5 @@ def test_reference_faithful_leg_small():
     assert "central slab of 10 of the 40 layers" in slab["reference_faithful_sample"]
     done, seconds = bench._oracle_batches(case, 0.2, threads=2)
     assert done >= 1600 and seconds > 0
-    model, blas = bench._cpu_info()
-    assert isinstance(model, str) and isinstance(blas, str)
+    model, blas, threads = bench._cpu_info()
+    assert isinstance(model, str) and isinstance(blas, str) and threads >= 1

@@ -395,6 +395,39 @@ def test_table_lyapunov_function(sl, lv_kind):
     assert np.array_equal(neg[ok], ref_neg[ok])
 
 
+def _on_table_face(otri, pts):
+    from test_gpu_rl import ambiguous_points
+    g = otri.discretization
+    frac = (g._center_states(pts, clip=True) % g.unit_maxes) / g.unit_maxes
+    on_face = (np.abs(frac) < 1e-9).any(axis=1) | (np.abs(frac - 1) < 1e-9).any(axis=1)
+    on_face |= np.abs(frac.sum(axis=1) - 1) < 1e-9
+    return on_face | ambiguous_points(otri, pts)
+
+
+def test_table_value_and_table_policy_with_gp(sl):
+    """The sweep of inverted_pendulum.ipynb cell 14 (bench config C2-table): V and the policy are
+    piecewise-linear tables on a coarser grid than the Lyapunov discretization, the dynamics a
+    GP, L_v = |grad V| at the cell's own state, tau > 0."""
+    from safe_learning_amd.benchmarks import build_lyapunov, table_case
+    case = table_case(num_points=(45, 37), table_points=(11, 9), n_gp=60, tau_scale=0.01)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    values, neg, rec = _engine_records(lyap)
+    ref_rec, ref_neg = _oracle_all(olyap)
+    otri = olyap.lyapunov_function
+    states = olyap.discretization.all_points
+    # gradients (hence thresholds) are simplex dependent on faces of the table grid
+    ok_x = ~_on_table_face(otri, states)
+    ok_n = ~_on_table_face(otri, ref_rec[:, 2:4])
+    assert ok_x.sum() > 800 and (ok_x & ok_n).sum() > 800
+    assert_allclose(values, olyap.values, rtol=1e-12, atol=1e-14)
+    assert_allclose(rec[:, 2:], ref_rec[:, 2:], rtol=RTOL_GP, atol=1e-12)      # mean, error
+    assert_allclose(rec[ok_x][:, 1], ref_rec[ok_x][:, 1], rtol=1e-9, atol=1e-14)
+    both = ok_x & ok_n
+    assert_allclose(rec[both][:, 0], ref_rec[both][:, 0], rtol=1e-7, atol=1e-12)
+    assert (ref_rec[:, 1] < 0).all() and 10 < ref_neg.sum() < len(ref_neg) - 10
+    _check_masks(neg[both], ref_neg[both], rec[both], ref_rec[both])
+
+
 def test_gp_known_answer_through_engine(sl, golden):
     """tests/test_functions.py:237-261 evaluated by the MFMA kernel (explicit points)."""
     import torch
