@@ -24,7 +24,9 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
     constexpr bool ACTIONS = AMAX > 0;
     const int A = ACTIONS ? n_actions : 1;
     const bool is_gp = M.m.dynamics.kind == SL_DYN_GP;
-    const SlTri& vt = aux.tri[0];
+    __shared__ SlTri vt_lds;
+    sl_stage_tri(&vt_lds, &aux.tri[0]);
+    const SlTri& vt = vt_lds;
 
     // ---- per-workgroup table of action factors E_j(u_a) -------------------------------------
     int e_off[SL_MAX_GP_HEADS];
@@ -224,7 +226,8 @@ typedef double sl_bd4 __attribute__((ext_vector_type(4)));
 #define SL_BM_WAVES 8
 #define SL_BM_T 4                         // cell tiles per wavefront
 // cells per epilogue step of a wavefront (bounded by the LDS the staged means need)
-#define SL_BM_SUB_OF(COLBLOCKS) ((COLBLOCKS) > 3 ? 16 : 32)
+#define SL_BM_SUB_OF(COLBLOCKS) ((COLBLOCKS) > 3 ? 16 : ((COLBLOCKS) == 3 ? 32 : 64))
+#define SL_BM_NAPS 16                     // x 8128 cycles of initial delay for wavefronts 4..7
 #define SL_BM_HEADS 4                     // GP heads (FunctionStack members) on the matrix-core path
 
 struct SlBellmanPack {
@@ -292,7 +295,9 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
     const SlDevModel M, const SlGpDev gp, SlAux aux, SlBellmanPack pk, int64_t lo, int64_t hi,
     int n_actions, const double* __restrict__ actions, const double* __restrict__ pack,
     double* __restrict__ v_new, int32_t* __restrict__ argmax, double* __restrict__ q_out,
-    double* __restrict__ stats) {
+    double* __restrict__ stats, int flags) {
+    // flags (SL_BM_FLAGS, diagnostics): 1 no GEMM, 2 no (cell, action) epilogue, 4 workgroup
+    // barriers instead of wavefront-local ordering, 8 no phase offset of the upper wavefronts
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red_max[SL_BM_WAVES], red_sum[SL_BM_WAVES];
     constexpr int SL_BM_SUB = SL_BM_SUB_OF(NCB * NH);
@@ -303,12 +308,27 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
     const int lc = lane & 15, lk = lane >> 4;
     const int rowlen = pk.rowlen;
     double* my_mean = smem + (size_t)wave * SL_BM_SUB * rowlen;                 // [32 cells][rowlen]
-    double* my_q = smem + (size_t)SL_BM_WAVES * SL_BM_SUB * rowlen + wave * SL_BM_SUB * SL_MAX_ACTIONS;
-    const SlTri& vt = aux.tri[0];
+    __shared__ SlTri vt_lds;
+    sl_stage_tri(&vt_lds, &aux.tri[0]);
+    const SlTri& vt = vt_lds;
     const int n_last = M.m.grid.num_points[d - 1];
     double lmax = 0.0, lsum = 0.0;
     const int64_t wg_cells = 16 * SL_BM_T * SL_BM_WAVES;
     const int64_t ntiles = (hi - lo + wg_cells - 1) / wg_cells;
+    // The staged means and q values are private to a wavefront, whose LDS accesses complete in
+    // order: the stages need no workgroup barrier, and the two wavefronts of a SIMD can run one
+    // the GEMM and the other the epilogue (integer decode, table gathers) of different tiles.
+#define SL_BM_SYNC()                                                                             \
+    do {                                                                                         \
+        if (flags & 4) __syncthreads();                                                          \
+        else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } \
+    } while (0)
+    // Phase offset: the second wavefront of each SIMD starts about half a GEMM late, so that from
+    // then on its epilogues fall into the other one's GEMMs instead of coinciding with them.
+    if (!(flags & 8) && wave >= SL_BM_WAVES / 2) {
+        const int naps = (flags >> 8) ? (flags >> 8) : SL_BM_NAPS;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t wbase = lo + tile * wg_cells + 16 * SL_BM_T * wave;   // first cell of the wavefront
         sl_bd4 acc[NH][SL_BM_T][NCB];
@@ -382,7 +402,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
                     acc[h][t][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(SSRC[t], BSRC[cb],     \
                                                                          acc[h][t][cb], 0, 0, 0); \
         } while (0)
-        for (int s = 0; s < nslab; s += 2) {
+        for (int s = (flags & 1) ? nslab : 0; s < nslab; s += 2) {
             double raw_a[SL_BM_T][SL_D], raw_b[SL_BM_T][SL_D];
             SL_BM_REQUEST(raw_a, b_odd, s + 1);
             SL_BM_MFMAS(s_cur, b_cur);
@@ -414,48 +434,58 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
                     }
                 }
             }
-            __syncthreads();
+            SL_BM_SYNC();
             // ---- (cell, action) pairs: prior mean, reward, value lookup --------------------------
-            for (int t = lane; t < SL_BM_SUB * A; t += 64) {
-                const int cell = t / A, a = t - cell * A;
+            // lane = (cell of the step, group of actions): the cell's index decode and state are
+            // computed once, each group walks its share of the actions in ascending order
+            {
+                constexpr int NG = 64 / SL_BM_SUB;
+                const int cell = lane & (SL_BM_SUB - 1), grp = lane / SL_BM_SUB;
+                const int apg = (A + NG - 1) / NG;
                 int64_t idx = sbase + cell;
-                idx = idx < hi ? idx : hi - 1;
+                const bool live = idx < hi;
+                idx = live ? idx : hi - 1;
                 double x[SL_P], u[SL_M], prior[SL_D], nxt[SL_D];
                 sl_index_to_state(M.m.grid, M.gf, d, idx, x);
+                double best_q = 0.0;
+                int best_a = -1;
+                for (int ai = (flags & 2) ? apg : 0; ai < apg; ++ai) {
+                    const int a = grp * apg + ai;
+                    if (a < A) {
 #pragma unroll
-                for (int c = 0; c < SL_M; ++c) if (c < nd.m) u[c] = actions[a * nd.m + c];
-                sl_append_action(nd, u, x);
-                sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
+                        for (int c = 0; c < SL_M; ++c) if (c < nd.m) u[c] = actions[a * nd.m + c];
+                        sl_append_action(nd, u, x);
+                        sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
 #pragma unroll
-                for (int k = 0; k < SL_D; ++k) {
-                    if (k < d) {
-                        double mu = 0.0;
+                        for (int k = 0; k < SL_D; ++k) {
+                            if (k < d) {
+                                double mu = 0.0;
 #pragma unroll
-                        for (int h = 0; h < NH; ++h) {
-                            const int dd = k - gp.head[h].col0, dout = gp.head[h].dout;
-                            if (dd >= 0 && dd < dout)
-                                mu = my_mean[cell * rowlen + 16 * NCB * h + a * dout + dd];
+                                for (int h = 0; h < NH; ++h) {
+                                    const int dd = k - gp.head[h].col0, dout = gp.head[h].dout;
+                                    if (dd >= 0 && dd < dout)
+                                        mu = my_mean[cell * rowlen + 16 * NCB * h + a * dout + dd];
+                                }
+                                nxt[k] = mu + prior[k];
+                            }
                         }
-                        nxt[k] = mu + prior[k];
+                        const double r = sl_quadratic(M.m.reward, p, x);
+                        double v = sl_tri_value_fast<DT>(vt, nxt);
+                        if (M.m.value.negate) v = v * -1.0;
+                        const double tq = M.m.gamma * v;
+                        const double q = r + tq;
+                        if (q_out && live) q_out[(idx - lo) * A + a] = q;
+                        if (best_a < 0 || q > best_q) { best_q = q; best_a = a; }
                     }
                 }
-                const double r = sl_quadratic(M.m.reward, p, x);
-                double v = sl_tri_value_fast<DT>(vt, nxt);
-                if (M.m.value.negate) v = v * -1.0;
-                const double tq = M.m.gamma * v;
-                my_q[cell * SL_MAX_ACTIONS + a] = r + tq;
-            }
-            __syncthreads();
-            if (lane < SL_BM_SUB) {
-                const int64_t idx = sbase + lane;
-                if (idx < hi) {
-                    double best_q = my_q[lane * SL_MAX_ACTIONS];
-                    int best_a = 0;
-                    for (int a = 0; a < A; ++a) {
-                        const double q = my_q[lane * SL_MAX_ACTIONS + a];
-                        if (q_out) q_out[(idx - lo) * A + a] = q;
-                        if (q > best_q) { best_q = q; best_a = a; }
-                    }
+                // first maximum over the groups in ascending action order
+#pragma unroll
+                for (int g = 1; g < NG; ++g) {
+                    const double oq = __shfl(best_q, cell + g * SL_BM_SUB, 64);
+                    const int oa = __shfl(best_a, cell + g * SL_BM_SUB, 64);
+                    if (oa >= 0 && (best_a < 0 || oq > best_q)) { best_q = oq; best_a = oa; }
+                }
+                if (grp == 0 && live) {
                     v_new[idx - lo] = best_q;
                     if (argmax) argmax[idx - lo] = best_a;
                     double v_old = vt.table[idx * vt.ncols];         // stats[1] is policy-mode only
@@ -463,7 +493,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
                     lmax = fmax(lmax, fabs(best_q - v_old));
                 }
             }
-            __syncthreads();
+            SL_BM_SYNC();
         }
     }
     for (int o = 32; o >= 1; o >>= 1) {
@@ -479,6 +509,8 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
         atomicAdd(&stats[1], lsum);
     }
 }
+
+#undef SL_BM_SYNC
 
 // ---------------------------------------------------------------------------------------------
 // Policy-evaluation sweep on the matrix cores (V <- r(x, pi(x)) + gamma V(f(x, pi(x))))
@@ -503,7 +535,9 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_policy_mfma(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lc = lane & 15, lk = lane >> 4;
-    const SlTri& vt = aux.tri[0];
+    __shared__ SlTri vt_lds;
+    sl_stage_tri(&vt_lds, &aux.tri[0]);
+    const SlTri& vt = vt_lds;
     const int n_last = M.m.grid.num_points[d - 1];
     const int npad_max = pk.npad_max;
     double* p_l = smem + (size_t)wave * (npad_max + 64 * 16 + SL_BP_MAXG); // [n_pad] of the current head
@@ -731,7 +765,7 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
     pk.ncb = ncb_t;
     pk.nheads = nheads;
     pk.npad_max = n_pad_max;
-    pk.rowlen = 16 * ncb_t * nheads;
+    pk.rowlen = 16 * ncb_t * nheads + 1;          // odd: the epilogue reads one row per lane
     int64_t cursor = 0;
     for (int h = 0; h < nheads; ++h) {
         const int n_pad = ctx->gp_heads[h].n_pad;
@@ -748,8 +782,8 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
     }
     const size_t lds = policy_mode
         ? sizeof(double) * (size_t)SL_BM_WAVES * (n_pad_max + 64 * 16 + SL_BP_MAXG)
-        : sizeof(double) * (size_t)SL_BM_WAVES * SL_BM_SUB_OF(ncb_t * nheads) * (pk.rowlen + SL_MAX_ACTIONS);
-    if (lds > 158 * 1024) return SL_OK;
+        : sizeof(double) * (size_t)SL_BM_WAVES * SL_BM_SUB_OF(ncb_t * nheads) * pk.rowlen;
+    if (lds + sizeof(SlTri) + 512 > 160 * 1024) return SL_OK;
     const size_t need = sizeof(double) * (size_t)cursor;
     if (need > ctx->scratch_bytes) {
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -782,6 +816,8 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
         *done = 1;
         return SL_OK;
     }
+    const char* bm_env = getenv("SL_BM_FLAGS");
+    const int bm_flags = bm_env ? atoi(bm_env) : 0;
 #define SL_BM_LAUNCH(D_, N_, H_)                                                                  \
     do {                                                                                          \
         auto kern = k_bellman_mfma<D_, N_, H_>;                                                   \
@@ -790,7 +826,7 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
                                               (int)lds));                                         \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * SL_BM_WAVES), lds, ctx->stream,          \
                            ctx->h_model, ctx->h_gp, aux, pk, lo, hi, n_actions, ctx->d_actions,   \
-                           pack, d_v_new, d_argmax, d_q, d_stats);                                \
+                           pack, d_v_new, d_argmax, d_q, d_stats, bm_flags);                      \
     } while (0)
 #define SL_BM_DIMS(N_)                                  \
     do {                                                \

@@ -197,6 +197,17 @@ __device__ inline double sl_network_value(const SlNet& net, const double* z, int
 }
 
 
+// Copy a table descriptor (simplices, hyperplanes, grid: ~6 KB) into the workgroup's LDS.  The
+// lookups walk every unit-cell simplex; read from global memory each walk is a chain of load
+// round trips that the compiler cannot hoist (the kernels store in between).
+__device__ __forceinline__ void sl_stage_tri(SlTri* dst, const SlTri* src) {
+    static_assert(sizeof(SlTri) % 4 == 0, "SlTri is copied word by word");
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(SlTri) / 4); i += blockDim.x) d[i] = s[i];
+    __syncthreads();
+}
+
 // Flavours of the value / L_v code: SL_FAST quadratic V only (no scratch), SL_TABLES adds the
 // interpolated table (V = -value_function of the RL loop, |tri.gradient| as L_v), SL_FULL also the
 // per-thread LyapunovNetwork (4.6 KB of private arrays per lane).  The grid sweeps never need

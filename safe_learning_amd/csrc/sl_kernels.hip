@@ -212,7 +212,7 @@ extern "C" int sl_tri_set(sl_ctx* ctx, int slot, const sl_grid_desc* h_grid, int
                                 hipMemcpyHostToDevice));
     t.points = ctx->d_tri_points[slot];
     t.table = d_table;
-    sl_tri_finish(t);
+    sl_tri_finish(t, h_discrete_points);
     SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_tri + slot, &t, sizeof(SlTri), hipMemcpyHostToDevice));
     return SL_OK;
 }

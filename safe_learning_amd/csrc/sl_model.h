@@ -40,6 +40,10 @@ struct SlTri {
     int64_t stride[SL_D];                            // flat-index stride per dimension
     const double* points;                            // concatenated linspace tables (device)
     int32_t points_off[SL_D];
+    // 1: points[k][i] == (double)i * unit_maxes[k] + offset[k] bit for bit (np.linspace's own
+    // formula, checked by sl_tri_finish) - the lookups then compute the points instead of loading
+    int32_t affine_points, reserved;
+    double  inv_unit[SL_D];                          // 1 / unit_maxes (first guesses only)
     const double* table;                             // [nindex][ncols] (device)
 };
 
@@ -314,6 +318,30 @@ SL_HD int64_t sl_rectangle_1d(const double* pts, int64_t n, double offset, doubl
     return r;
 }
 
+// The same with the linspace values recomputed (SlTri::affine_points) instead of loaded - no
+// dependent memory round trips - in 32-bit indices, the first guess by the reciprocal of the
+// spacing (any guess is corrected by the two loops, which then run zero or one step).
+SL_HD int64_t sl_rectangle_1d(const SlTri& t, int k, double x) {
+    if (!t.affine_points)
+        return sl_rectangle_1d(t.points + t.points_off[k], t.grid.num_points[k], t.grid.offset[k],
+                               t.grid.unit_maxes[k], x);
+    const int n = (int)t.grid.num_points[k];
+    const double offset = t.grid.offset[k], unit = t.grid.unit_maxes[k];
+    const double g = (x - offset) * t.inv_unit[k];
+    int i;
+    if (!(g > 0.0)) i = 0; else if (g >= (double)(n - 1)) i = n - 1; else i = (int)g;
+#define SL_PT(I) ((double)(I) * unit + offset)
+    while (i + 1 < n && SL_PT(i + 1) <= x) ++i;
+    while (i > 0 && SL_PT(i) > x) --i;
+    int cnt = (SL_PT(i) <= x) ? (i + 1) : 0;
+#undef SL_PT
+    if (x != x) cnt = n;
+    int r = cnt - 1;
+    if (r < 0) r = 0;
+    if (r > n - 2) r = n - 2;
+    return r;
+}
+
 SL_HD double sl_fmod_pos(double a, double b) {     // numpy `%` for a >= 0, b > 0
     double r = fmod(a, b);
     return r;
@@ -329,9 +357,7 @@ SL_HD double sl_tri_eval(const SlTri& t, const double* x, int col, double* grad)
 #pragma unroll
     for (int k = 0; k < SL_D; ++k) {
         if (k < d) {
-            const double* pts = t.points + t.points_off[k];
-            int64_t r = sl_rectangle_1d(pts, t.grid.num_points[k], t.grid.offset[k],
-                                        t.grid.unit_maxes[k], x[k]);
+            int64_t r = sl_rectangle_1d(t, k, x[k]);
             rk[k] = r;
             corner += r * t.stride[k];
             // _center_states(clip=True): functions.py:705-712
@@ -451,8 +477,19 @@ SL_HD double sl_exp_nonpos(double x) {
 }
 
 // Derived constants of a triangulation; call after filling simplices / hyper / grid.
-inline void sl_tri_finish(SlTri& t) {
+inline void sl_tri_finish(SlTri& t, const double* h_points) {
     const int d = t.grid.d;
+    // are the discrete points np.linspace's `i * step + start` (functions.py:565-567)?
+    t.affine_points = 1;
+    for (int k = 0; k < d; ++k) {
+        t.inv_unit[k] = 1.0 / t.grid.unit_maxes[k];
+        if (t.grid.num_points[k] >= (1ll << 31)) t.affine_points = 0;
+    }
+    for (int k = 0; k < d && t.affine_points; ++k)
+        for (int64_t i = 0; i < t.grid.num_points[k]; ++i) {
+            const double pt = (double)i * t.grid.unit_maxes[k] + t.grid.offset[k];
+            if (!(pt == h_points[t.points_off[k] + i])) { t.affine_points = 0; break; }
+        }
     for (int s = 0; s < t.nsimplex; ++s)
         for (int j = 0; j < d; ++j) {
             double c = 0.0;
@@ -471,6 +508,14 @@ SL_HD double sl_fmod_exact(double a, double b) {
     else if (r >= b) { q += 1.0; r = fma(-q, b, a); }
     return r;
 }
+// the quotient guessed with a reciprocal (inv_b ~ 1 / b) and corrected until 0 <= r < b
+SL_HD double sl_fmod_exact(double a, double b, double inv_b) {
+    double q = floor(a * inv_b);
+    double r = fma(-q, b, a);
+    while (r < 0.0) { q -= 1.0; r = fma(-q, b, a); }
+    while (r >= b) { q += 1.0; r = fma(-q, b, a); }
+    return r;
+}
 
 // Column 0 of the interpolant at x for a compile-time dimension (the Bellman sweeps evaluate it
 // A times per vertex).  Same rule as sl_tri_eval - the unit-cell simplex whose smallest
@@ -485,16 +530,14 @@ SL_HD double sl_tri_value_fast(const SlTri& t, const double* x) {
     double base[D], unitc[D], xc[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        const double* pts = t.points + t.points_off[k];
-        const int64_t r = sl_rectangle_1d(pts, t.grid.num_points[k], t.grid.offset[k],
-                                          t.grid.unit_maxes[k], x[k]);
+        const int64_t r = sl_rectangle_1d(t, k, x[k]);
         corner += r * t.stride[k];
         base[k] = (double)r;
         double c = x[k] - t.grid.offset[k];
         const double lo = 0.0 + eps2, hi = (t.grid.upper[k] - t.grid.offset[k]) - eps2;
         c = (c < lo) ? lo : c;
         c = (c > hi) ? hi : c;
-        unitc[k] = sl_fmod_exact(c, t.grid.unit_maxes[k]);
+        unitc[k] = sl_fmod_exact(c, t.grid.unit_maxes[k], t.inv_unit[k]);
         double pp = x[k];
         if (t.project) {
             pp = (pp > t.grid.offset[k]) ? pp : t.grid.offset[k];
@@ -504,6 +547,7 @@ SL_HD double sl_tri_value_fast(const SlTri& t, const double* x) {
     }
     int best = 0;
     double best_min = -1e300;
+#pragma unroll 2
     for (int s = 0; s < t.nsimplex; ++s) {
         double w0 = 1.0, wmin = 1e300;
 #pragma unroll

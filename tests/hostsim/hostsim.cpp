@@ -3,6 +3,7 @@
 // The HIP kernels and this file include the very same header; compiling it with g++ lets the CPU
 // test-suite check index->state, policy, dynamics, V, L_v, threshold and decrease bit-for-bit
 // against the oracle without a GPU.  It is never imported by the product package.
+#include <cstdlib>
 #include <cstring>
 #include "sl_model.h"
 
@@ -77,7 +78,8 @@ int hs_tri_eval(const sl_grid_desc* grid, int nsimplex, const int32_t* simplices
     for (int k = 0; k < d; ++k) { t.points_off[k] = (int32_t)total; total += grid->num_points[k]; }
     t.points = discrete_points;
     t.table = table;
-    sl_tri_finish(t);
+    sl_tri_finish(t, discrete_points);
+    if (getenv("SL_HOSTSIM_LOAD_POINTS")) t.affine_points = 0;
     if (col == -1) {             // the Bellman sweeps' lookup (column 0, compile-time dimension)
         for (int64_t i = 0; i < npts; ++i) {
             const double* x = pts + i * d;

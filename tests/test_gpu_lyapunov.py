@@ -416,11 +416,13 @@ def test_table_value_and_table_policy_with_gp(sl):
     otri = olyap.lyapunov_function
     states = olyap.discretization.all_points
     # gradients (hence thresholds) are simplex dependent on faces of the table grid
-    ok_x = ~_on_table_face(otri, states)
+    opol = olyap.policy.fun if hasattr(olyap.policy, "fun") else olyap.policy
+    ok_x = ~(_on_table_face(otri, states) | _on_table_face(opol, states))
     ok_n = ~_on_table_face(otri, ref_rec[:, 2:4])
     assert ok_x.sum() > 800 and (ok_x & ok_n).sum() > 800
-    assert_allclose(values, olyap.values, rtol=1e-12, atol=1e-14)
-    assert_allclose(rec[:, 2:], ref_rec[:, 2:], rtol=RTOL_GP, atol=1e-12)      # mean, error
+    # (cells on table grid lines: the reference's value there depends on scipy's search history)
+    assert_allclose(values[ok_x], olyap.values[ok_x], rtol=1e-12, atol=1e-14)
+    assert_allclose(rec[ok_x][:, 2:], ref_rec[ok_x][:, 2:], rtol=RTOL_GP, atol=1e-12)  # mean, error
     assert_allclose(rec[ok_x][:, 1], ref_rec[ok_x][:, 1], rtol=1e-9, atol=1e-14)
     both = ok_x & ok_n
     assert_allclose(rec[both][:, 0], ref_rec[both][:, 0], rtol=1e-7, atol=1e-12)
