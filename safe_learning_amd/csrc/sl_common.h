@@ -208,6 +208,23 @@ __device__ __forceinline__ void sl_stage_tri(SlTri* dst, const SlTri* src) {
     __syncthreads();
 }
 
+// Both table slots in LDS for the "general" flavours of the sweeps (nothing for the others).
+template <bool ON> struct SlTriLds { SlTri t[2]; };
+template <> struct SlTriLds<false> { int unused; };
+template <bool ON>
+__device__ __forceinline__ SlAux sl_stage_aux(SlTriLds<ON>& lds, const SlAux& aux) {
+    if constexpr (ON) {
+        static_assert(sizeof(SlTri) % 4 == 0, "SlTri is copied word by word");
+        const uint32_t* s = reinterpret_cast<const uint32_t*>(aux.tri);
+        uint32_t* d = reinterpret_cast<uint32_t*>(lds.t);
+        for (int i = threadIdx.x; i < (int)(2 * sizeof(SlTri) / 4); i += blockDim.x) d[i] = s[i];
+        __syncthreads();
+        return SlAux{lds.t, aux.net};
+    } else {
+        return aux;
+    }
+}
+
 // Flavours of the value / L_v code: SL_FAST quadratic V only (no scratch), SL_TABLES adds the
 // interpolated table (V = -value_function of the RL loop, |tri.gradient| as L_v), SL_FULL also the
 // per-thread LyapunovNetwork (4.6 KB of private arrays per lane).  The grid sweeps never need

@@ -50,10 +50,12 @@ static inline int cfg_panel_rows(int cfg) { return 16 * kCfgR[cfg] * kCfgW[cfg];
 // during generation (instantiated for the 64-cell-tile configuration only).
 template <int W, int R, int CB, bool GENERAL, int DT, int MT, bool XSG = false>
 __global__ __launch_bounds__(W * 64) void k_gp_sweep(
-    const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
+    const SlDevModel M, const SlGpDev gp, SlAux aux_arg, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
-    int xs_doubles, int alpha_doubles, const double* __restrict__ points) {
+    int xs_doubles, int alpha_doubles, const double* __restrict__ points, int nb_arg) {
+    __shared__ SlTriLds<GENERAL> tri_lds;
+    const SlAux aux = sl_stage_aux<GENERAL>(tri_lds, aux_arg);
     constexpr int C = 16 * CB;
     constexpr int RP = 16 * R * W;                 // rows per panel
     constexpr int RB = R * W;                      // row blocks per panel
@@ -68,10 +70,15 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
     double* kx_l = alpha_l + alpha_doubles;        // [2][KXBUF]
     double* part_ss = kx_l + 2 * KXBUF;            // [W][C]
     double* part_m = part_ss + W * C;              // [W][16][DOUT_MAX]
-    double* cell_mean = part_m + W * 16 * SL_GP_DOUT_MAX;    // [C][SL_D]
-    double* cell_err = cell_mean + C * SL_D;                 // [C][SL_D]
-    uint64_t* sv = reinterpret_cast<uint64_t*>(cell_err + C * SL_D);   // [W]
+    // The table flavours check NB tiles at a time with one cell per lane: a table-V / table-
+    // policy check costs thousands of cycles, and with one tile per check only C of the W * 64
+    // lanes would work (measured 23 ms against 6.5 ms for the same sweep with a quadratic V).
+    const int NB = GENERAL ? nb_arg : 1;
+    double* cell_mean = part_m + W * 16 * SL_GP_DOUT_MAX;    // [NB][C][SL_D]
+    double* cell_err = cell_mean + NB * C * SL_D;            // [NB][C][SL_D]
+    uint64_t* sv = reinterpret_cast<uint64_t*>(cell_err + NB * C * SL_D);   // [W]
     int64_t* si = reinterpret_cast<int64_t*>(sv + W);                  // [W]
+    int64_t* slot_tile = si + W;                                       // [NB] tiles of the batch
 
     const SlDims nd = sl_dims<DT, MT>(M);
     const int d = nd.d, p = nd.p;
@@ -83,17 +90,21 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
     uint64_t best_v = ~0ull;
     int64_t best_i = INT64_MAX;
     int staged_head = -1;
+    int nslots = 0;                                // tiles waiting for their check
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t tile_base = lo + tile * C;
+        const bool last_tile = tile + gridDim.x >= ntiles;
         if (tile_base >= hi) {                     // padding tile: only clears mask bits
             if (tid == 0) {
                 if (C == 64) neg_bits[(tile_base - lo) >> 6] = 0ull;
                 else if (C == 32) reinterpret_cast<uint32_t*>(neg_bits)[(tile_base - lo) >> 5] = 0u;
                 else reinterpret_cast<uint16_t*>(neg_bits)[(tile_base - lo) >> 4] = 0;
             }
-            continue;
-        }
+            if (!(last_tile && nslots > 0)) continue;
+        } else {
+        double* slot_mean = cell_mean + nslots * C * SL_D;
+        double* slot_err = cell_err + nslots * C * SL_D;
 
         for (int h = 0; h < gp.nheads; ++h) {
             const SlGpHeadDev& hd = gp.head[h];
@@ -271,6 +282,8 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                     part_m[(wave * 16 + lane) * SL_GP_DOUT_MAX + dd] = gmean[dd];
             }
             __syncthreads();
+            // (written behind this tile's barriers: every wavefront has left the previous check)
+            if (tid == 0) slot_tile[nslots] = tile;
             if (tid < C) {
                 double sumsq = 0.0;
                 for (int w = 0; w < W; ++w) sumsq += part_ss[w * C + tid];
@@ -280,16 +293,24 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                 for (int dd = 0; dd < dout; ++dd) {
                     double mu = 0.0;
                     for (int w = cb; w < W; w += CB) mu += part_m[(w * 16 + cc) * SL_GP_DOUT_MAX + dd];
-                    cell_mean[tid * SL_D + hd.col0 + dd] = mu;
-                    cell_err[tid * SL_D + hd.col0 + dd] = e;
+                    slot_mean[tid * SL_D + hd.col0 + dd] = mu;
+                    slot_err[tid * SL_D + hd.col0 + dd] = e;
                 }
             }
             __syncthreads();
         }
 
+        ++nslots;
+        }
+        if (nslots < NB && !last_tile) continue;
+
         // ---- per-cell decrease check, mask word, failing-cell key -------------------------------
-        const int64_t idx = tile_base + tid;
-        const bool valid = (tid < C) && (idx < hi);
+        // lane t of the workgroup: cell t % C of the batch's tile t / C
+        const int slot = tid / C, cell = tid - slot * C;
+        const bool in_batch = slot < nslots;
+        const int64_t cbase = lo + slot_tile[in_batch ? slot : 0] * C;
+        const int64_t idx = cbase + cell;
+        const bool valid = in_batch && (idx < hi);
         bool negative = false;
         double v_x = 0.0;
         if (valid) {
@@ -315,22 +336,20 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                 for (int k = 0; k < SL_D; ++k) if (k < d) { o[2 + k] = mean[k]; o[2 + d + k] = err[k]; }
             }
         }
-        if (wave == 0) {
+        if (wave * 64 < nslots * C) {              // wavefronts that hold cells of the batch
             const uint64_t word = __ballot(negative);
-            uint64_t init = 0ull;
-            if (init_bits) {
-                const uint64_t iw = init_bits[(tile_base - lo) >> 6];
-                init = iw >> ((tile_base - lo) & 63);
+            bool init = false;
+            if (init_bits && valid) init = (init_bits[(idx - lo) >> 6] >> ((idx - lo) & 63)) & 1ull;
+            if (cell == 0 && in_batch) {               // first lane of a tile's piece of the word
+                if (C == 64) neg_bits[(cbase - lo) >> 6] = word;
+                else if (C == 32) reinterpret_cast<uint32_t*>(neg_bits)[(cbase - lo) >> 5] = (uint32_t)(word >> (lane & 32));
+                else reinterpret_cast<uint16_t*>(neg_bits)[(cbase - lo) >> 4] = (uint16_t)(word >> (lane & 48));
             }
-            if (lane == 0) {
-                if (C == 64) neg_bits[(tile_base - lo) >> 6] = word;
-                else if (C == 32) reinterpret_cast<uint32_t*>(neg_bits)[(tile_base - lo) >> 5] = (uint32_t)word;
-                else reinterpret_cast<uint16_t*>(neg_bits)[(tile_base - lo) >> 4] = (uint16_t)word;
-            }
-            const bool ok = negative || ((init >> lane) & 1ull);
+            const bool ok = negative || init;
             if (valid && !ok) sl_key_min(best_v, best_i, sl_vbits(v_x), idx);
         }
-        // (cell_mean / cell_err are rewritten only after the next tile's barriers)
+        nslots = 0;
+        // (the batch buffers are rewritten only after the next tile's barriers)
     }
     __syncthreads();
     sl_block_reduce_key<true>(best_v, best_i, sv, si);
@@ -518,8 +537,15 @@ static int launch_cfg(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t 
     }
     xs_doubles = (xs_doubles + 1) & ~1;            // keep the k_x buffers 16-byte aligned
     if (XSG) xs_doubles = 0;                       // training inputs stay in global memory / L2
-    size_t lds = sizeof(double) * ((size_t)xs_doubles + 2 * SL_GP_SLABS_PER_CHUNK * CB * 64 +
-                                   W * C + W * 16 * SL_GP_DOUT_MAX + 2 * C * SL_D + 2 * W);
+    constexpr size_t LDS_CAP = 160 * 1024 - (GENERAL ? sizeof(SlTriLds<true>) + 64 : 0);
+    const auto lds_for = [&](int nb) {
+        return sizeof(double) * ((size_t)xs_doubles + 2 * SL_GP_SLABS_PER_CHUNK * CB * 64 + W * C +
+                                 W * 16 * SL_GP_DOUT_MAX + 2 * (size_t)nb * C * SL_D + 2 * W + nb);
+    };
+    // tiles per check of the table flavours: one cell per lane when LDS has the room
+    int nb = GENERAL ? (W * 64) / C : 1;
+    while (nb > 1 && lds_for(nb) > LDS_CAP) nb /= 2;
+    size_t lds = lds_for(nb);
     // alpha' next to the training inputs when LDS has room (the mean accumulation of the k_x
     // generation then reads LDS instead of L2)
     int alpha_doubles = 0;
@@ -528,9 +554,10 @@ static int launch_cfg(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t 
         alpha_doubles = v > alpha_doubles ? v : alpha_doubles;
     }
     alpha_doubles = (alpha_doubles + 1) & ~1;
-    if (lds + sizeof(double) * alpha_doubles <= 160 * 1024) lds += sizeof(double) * alpha_doubles;
+    // (the general flavours also hold both table descriptors in static LDS)
+    if (lds + sizeof(double) * alpha_doubles <= LDS_CAP) lds += sizeof(double) * alpha_doubles;
     else alpha_doubles = 0;
-    if (lds > 160 * 1024)
+    if (lds > LDS_CAP)
         return sl_fail(ctx, SL_ERR_UNSUPPORTED, "GP training set too large for LDS staging "
                                                 "(%zu bytes needed)", lds);
     auto kern = k_gp_sweep<W, R, CB, GENERAL, DT, MT, XSG>;
@@ -542,7 +569,7 @@ static int launch_cfg(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t 
     SlAux aux{ctx->d_tri, ctx->d_net};
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W * 64), lds, ctx->stream, model,
                        ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits, ctx->d_partials, d_dbg,
-                       xs_doubles, alpha_doubles, d_points);
+                       xs_doubles, alpha_doubles, d_points, nb);
     SL_HIP_CHECK(ctx, hipGetLastError());
     return SL_OK;
 }

@@ -339,8 +339,10 @@ static inline int sl_dim_variant(const SlDevModel& M) {
 // values: V(x_i)                                             (lyapunov.py:305-322)
 // =============================================================================================
 template <bool GENERAL, int DT, int MT>
-__global__ __launch_bounds__(SL_BLOCK) void k_values(const SlDevModel M_arg, SlAux aux, int64_t lo,
+__global__ __launch_bounds__(SL_BLOCK) void k_values(const SlDevModel M_arg, SlAux aux_arg, int64_t lo,
                                                      int64_t hi, double* __restrict__ values) {
+    __shared__ SlTriLds<GENERAL> tri_lds;
+    const SlAux aux = sl_stage_aux<GENERAL>(tri_lds, aux_arg);
     SlDevModel M = M_arg;
     if (!GENERAL && DT > 0) {            // quadratic form and grid constants as vector operands
 #pragma unroll
@@ -430,11 +432,13 @@ __device__ __forceinline__ void sl_constants_to_vgprs(SlDevModel& L) {
 // v_readlane) cost as much as the FP64 arithmetic of the check.  No explicit points, no records.
 template <bool GENERAL, int DT, int MT, int DYN, bool POW2 = false>
 __global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
-    const SlDevModel M_arg, SlAux aux, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
+    const SlDevModel M_arg, SlAux aux_arg, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
     const double* __restrict__ values, uint64_t* __restrict__ neg_bits,
     sl_key* __restrict__ partials, double* __restrict__ dbg, const double* __restrict__ points) {
     __shared__ uint64_t sv[SL_BLOCK / 64];
     __shared__ int64_t si[SL_BLOCK / 64];
+    __shared__ SlTriLds<GENERAL> tri_lds;
+    const SlAux aux = sl_stage_aux<GENERAL>(tri_lds, aux_arg);
     SlDevModel M = M_arg;
     if (!GENERAL && DT > 0 && DYN != 0) sl_constants_to_vgprs<DT, MT, DYN>(M);
     uint32_t axis_mask[DT > 0 ? DT : 1], axis_shift[DT > 0 ? DT : 1];
