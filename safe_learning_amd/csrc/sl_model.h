@@ -31,6 +31,8 @@
 #define SL_P SL_MAX_INPUT_DIM
 
 // Device-side view of one auxiliary grid with a vertex table (Triangulation).
+#define SL_TRI_CODES   64      // 2^(pairs of coordinates), d <= 4
+#define SL_TRI_MAXCAND 12
 struct SlTri {
     sl_grid_desc grid;
     int32_t nsimplex, project, ncols, set;
@@ -44,6 +46,11 @@ struct SlTri {
     // formula, checked by sl_tri_finish) - the lookups then compute the points instead of loading
     int32_t affine_points, reserved;
     double  inv_unit[SL_D];                          // 1 / unit_maxes (first guesses only)
+    // Point location shortcut (sl_tri_regions): the order of the unit-cell coordinates puts a point
+    // into one of d! Kuhn regions; only the simplices that overlap that region can contain it.
+    // region_code = one bit per coordinate pair (i < j): z_i < z_j.  ncand[code] == 0: no table.
+    uint8_t ncand[SL_TRI_CODES];
+    uint8_t cand[SL_TRI_CODES][SL_TRI_MAXCAND];
     const double* table;                             // [nindex][ncols] (device)
 };
 
@@ -477,6 +484,155 @@ SL_HD double sl_exp_nonpos(double x) {
 }
 
 // Derived constants of a triangulation; call after filling simplices / hyper / grid.
+// ---- candidate simplices per coordinate-order region (host) -----------------------------------
+// Both the unit-cell simplices and the d! Kuhn regions {z : z_pi(0) >= z_pi(1) >= ...} are
+// simplices with 0/1 vertices.  Simplex S can contain a point of region K in its interior only if
+// S and K overlap in a set of positive volume; that is decided exactly enough by enumerating the
+// vertices of S n K (all d-subsets of the 2(d+1) facet planes) and testing their affine rank.
+namespace sl_tri_detail {
+inline bool solve(int n, double a[5][6]) {         // Gauss-Jordan on [A | b], false if singular
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (fabs(a[piv][c]) < 1e-9) return false;
+        for (int k = 0; k <= n; ++k) { const double tmp = a[c][k]; a[c][k] = a[piv][k]; a[piv][k] = tmp; }
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c] / a[c][c];
+            for (int k = c; k <= n; ++k) a[r][k] -= f * a[c][k];
+        }
+    }
+    for (int r = 0; r < n; ++r) a[r][n] /= a[r][r];
+    return true;
+}
+// facet planes g . z + h >= 0 of the simplex with vertices v[0..d] (barycentric coordinates)
+inline bool facets(int d, const double v[5][4], double g[5][4], double h[5]) {
+    for (int i = 0; i <= d; ++i) {
+        // lambda_i(z) = g_i . z + h_i with lambda_i(v_j) = delta_ij
+        double a[5][6];
+        for (int j = 0; j <= d; ++j) {
+            for (int k = 0; k < d; ++k) a[j][k] = v[j][k];
+            a[j][d] = 1.0;
+            a[j][d + 1] = (i == j) ? 1.0 : 0.0;
+        }
+        if (!solve(d + 1, a)) return false;
+        for (int k = 0; k < d; ++k) g[i][k] = a[k][d + 1];
+        h[i] = a[d][d + 1];
+    }
+    return true;
+}
+inline bool overlap(int d, const double ga[5][4], const double ha[5], const double gb[5][4],
+                    const double hb[5]) {
+    const int m = 2 * (d + 1);
+    double g[10][4], h[10];
+    for (int i = 0; i <= d; ++i) {
+        for (int k = 0; k < d; ++k) { g[i][k] = ga[i][k]; g[d + 1 + i][k] = gb[i][k]; }
+        h[i] = ha[i]; h[d + 1 + i] = hb[i];
+    }
+    double verts[256][4];
+    int nv = 0;
+    int idx[4] = {0, 1, 2, 3};
+    // all d-subsets of the m planes
+    for (int i = 0; i < d; ++i) idx[i] = i;
+    while (true) {
+        double a[5][6];
+        for (int r = 0; r < d; ++r) {
+            for (int k = 0; k < d; ++k) a[r][k] = g[idx[r]][k];
+            a[r][d] = -h[idx[r]];
+        }
+        if (solve(d, a)) {
+            bool ok = true;
+            for (int q = 0; q < m && ok; ++q) {
+                double val = h[q];
+                for (int k = 0; k < d; ++k) val += g[q][k] * a[k][d];
+                ok = val >= -1e-9;
+            }
+            if (ok && nv < 256) { for (int k = 0; k < d; ++k) verts[nv][k] = a[k][d]; ++nv; }
+        }
+        int r = d - 1;
+        while (r >= 0 && idx[r] == m - d + r) --r;
+        if (r < 0) break;
+        ++idx[r];
+        for (int q = r + 1; q < d; ++q) idx[q] = idx[q - 1] + 1;
+    }
+    if (nv < d + 1) return false;
+    // affine rank of the feasible vertices
+    double b[256][4];
+    for (int i = 1; i < nv; ++i) for (int k = 0; k < d; ++k) b[i - 1][k] = verts[i][k] - verts[0][k];
+    int rank = 0, rows = nv - 1;
+    for (int c = 0; c < d && rank < rows; ++c) {
+        int piv = rank;
+        for (int r = rank + 1; r < rows; ++r) if (fabs(b[r][c]) > fabs(b[piv][c])) piv = r;
+        if (fabs(b[piv][c]) < 1e-7) continue;
+        for (int k = 0; k < d; ++k) { const double tmp = b[rank][k]; b[rank][k] = b[piv][k]; b[piv][k] = tmp; }
+        for (int r = rank + 1; r < rows; ++r) {
+            const double f = b[r][c] / b[rank][c];
+            for (int k = c; k < d; ++k) b[r][k] -= f * b[rank][k];
+        }
+        ++rank;
+    }
+    return rank == d;
+}
+}  // namespace sl_tri_detail
+
+// bit per pair (i < j), pairs in lexicographic order: 1 iff z_i < z_j
+SL_HD int sl_tri_region_code(int d, const double* z) {
+    int code = 0, bit = 0;
+    for (int i = 0; i < d; ++i)
+        for (int j = i + 1; j < d; ++j, ++bit) code |= (z[i] < z[j]) ? (1 << bit) : 0;
+    return code;
+}
+
+inline void sl_tri_regions(SlTri& t) {
+    using namespace sl_tri_detail;
+    const int d = t.grid.d;
+    for (int c = 0; c < SL_TRI_CODES; ++c) t.ncand[c] = 0;
+    if (d < 2 || d > 4 || t.nsimplex < 3) return;           // nothing to prune
+    double sg[SL_MAX_SIMPLICES][5][4], sh[SL_MAX_SIMPLICES][5];
+    for (int s = 0; s < t.nsimplex; ++s) {
+        double v[5][4];
+        for (int q = 0; q <= d; ++q)
+            for (int k = 0; k < d; ++k) v[q][k] = (double)((t.simplices[s][q] >> k) & 1);
+        if (!facets(d, v, sg[s], sh[s])) return;             // degenerate simplex: keep the full walk
+    }
+    int perm[4] = {0, 1, 2, 3};
+    bool more = true;
+    uint8_t ncand[SL_TRI_CODES];
+    for (int c = 0; c < SL_TRI_CODES; ++c) ncand[c] = 0;
+    while (more) {
+        // Kuhn region z_perm[0] >= z_perm[1] >= ... : vertices 0, e_p0, e_p0 + e_p1, ...
+        double v[5][4], kg[5][4], kh[5], centre[4];
+        for (int k = 0; k < d; ++k) v[0][k] = 0.0;
+        for (int q = 1; q <= d; ++q) {
+            for (int k = 0; k < d; ++k) v[q][k] = v[q - 1][k];
+            v[q][perm[q - 1]] = 1.0;
+        }
+        for (int k = 0; k < d; ++k) {
+            centre[k] = 0.0;
+            for (int q = 0; q <= d; ++q) centre[k] += v[q][k] / (d + 1);
+        }
+        const int code = sl_tri_region_code(d, centre);
+        if (!facets(d, v, kg, kh)) return;
+        for (int s = 0; s < t.nsimplex; ++s) {
+            if (!overlap(d, sg[s], sh[s], kg, kh)) continue;
+            if (ncand[code] >= SL_TRI_MAXCAND) return;         // too many: keep the full walk
+            t.cand[code][ncand[code]++] = (uint8_t)s;
+        }
+        if (ncand[code] == 0) return;
+        // next permutation of perm[0..d)
+        int i = d - 2;
+        while (i >= 0 && perm[i] > perm[i + 1]) --i;
+        if (i < 0) more = false;
+        else {
+            int j = d - 1;
+            while (perm[j] < perm[i]) --j;
+            int tmp = perm[i]; perm[i] = perm[j]; perm[j] = tmp;
+            for (int a = i + 1, b = d - 1; a < b; ++a, --b) { tmp = perm[a]; perm[a] = perm[b]; perm[b] = tmp; }
+        }
+    }
+    for (int c = 0; c < SL_TRI_CODES; ++c) t.ncand[c] = ncand[c];
+}
+
 inline void sl_tri_finish(SlTri& t, const double* h_points) {
     const int d = t.grid.d;
     // are the discrete points np.linspace's `i * step + start` (functions.py:565-567)?
@@ -497,6 +653,7 @@ inline void sl_tri_finish(SlTri& t, const double* h_points) {
                 if ((t.simplices[s][0] >> k) & 1) c = fma(t.grid.unit_maxes[k], t.hyper[s][k][j], c);
             t.hyper_c[s][j] = c;
         }
+    sl_tri_regions(t);
 }
 
 // a mod b for a >= 0, b > 0, exactly as fmod: the remainder is representable, so one fused
@@ -521,9 +678,16 @@ SL_HD double sl_fmod_exact(double a, double b, double inv_b) {
 // A times per vertex).  Same rule as sl_tri_eval - the unit-cell simplex whose smallest
 // barycentric weight is largest - with the weights as fused w = G_s u - c_s; where several
 // simplices contain the point (a shared face) the candidates agree on the value.
+// located point: the D + 1 table rows of its simplex and their weights (the origin's weight is
+// 1 - sum of the others, w[0] here)
+template <int D>
+struct SlTriLoc {
+    int64_t row[D + 1];          // row[0] = simplex origin
+    double  w[D + 1];            // w[0] = 1 - (w[1] + ... + w[D])
+};
+
 template <int DT>
-SL_HD double sl_tri_value_fast(const SlTri& t, const double* x) {
-    if (DT == 0) return sl_tri_eval(t, x, 0, nullptr);
+SL_HD void sl_tri_locate_fast(const SlTri& t, const double* x, SlTriLoc<(DT > 0 ? DT : 1)>& loc) {
     constexpr int D = DT > 0 ? DT : 1;
     const double eps2 = 2.0 * 2.220446049250313e-16;
     int64_t corner = 0;
@@ -547,20 +711,39 @@ SL_HD double sl_tri_value_fast(const SlTri& t, const double* x) {
     }
     int best = 0;
     double best_min = -1e300;
-#pragma unroll 2
-    for (int s = 0; s < t.nsimplex; ++s) {
-        double w0 = 1.0, wmin = 1e300;
+#define SL_TRI_TRY(S)                                                                           \
+    do {                                                                                        \
+        const int s_ = (S);                                                                     \
+        double w0 = 1.0, wmin = 1e300;                                                          \
+        _Pragma("unroll") for (int j = 0; j < D; ++j) {                                         \
+            double w = -t.hyper_c[s_][j];                                                       \
+            _Pragma("unroll") for (int k = 0; k < D; ++k) w = fma(unitc[k], t.hyper[s_][k][j], w); \
+            w0 -= w;                                                                            \
+            wmin = fmin(wmin, w);                                                               \
+        }                                                                                       \
+        wmin = fmin(wmin, w0);                                                                  \
+        if (wmin > best_min) { best_min = wmin; best = s_; }                                    \
+    } while (0)
+    // The simplices overlapping the point's coordinate-order region first: a strictly positive
+    // smallest weight means the point is interior to that simplex, which then is the maximiser
+    // over all simplices too.  Anything else (points on faces, exact ties) takes the full walk.
+    bool full = true;
+    if (D >= 2 && D <= 4) {
+        double z[D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            double w = -t.hyper_c[s][j];
-#pragma unroll
-            for (int k = 0; k < D; ++k) w = fma(unitc[k], t.hyper[s][k][j], w);
-            w0 -= w;
-            wmin = fmin(wmin, w);
-        }
-        wmin = fmin(wmin, w0);
-        if (wmin > best_min) { best_min = wmin; best = s; }
+        for (int k = 0; k < D; ++k) z[k] = unitc[k] * t.inv_unit[k];
+        const int code = sl_tri_region_code(D, z);
+        const int nc = t.ncand[code];
+        for (int i = 0; i < nc; ++i) SL_TRI_TRY(t.cand[code][i]);
+        full = !(nc > 0 && best_min > 0.0);
     }
+    if (full) {
+        best = 0;
+        best_min = -1e300;
+#pragma unroll 2
+        for (int s = 0; s < t.nsimplex; ++s) SL_TRI_TRY(s);
+    }
+#undef SL_TRI_TRY
     // weights relative to the simplex origin in physical coordinates (functions.py:1180-1200)
     const int code0 = t.simplices[best][0];
     int64_t v0 = corner;
@@ -572,7 +755,7 @@ SL_HD double sl_tri_value_fast(const SlTri& t, const double* x) {
         const double tt = (base[k] + (double)bit) * t.grid.unit_maxes[k];
         rel[k] = xc[k] - (tt + t.grid.offset[k]);
     }
-    double wsum = 0.0, acc = 0.0;
+    double wsum = 0.0;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         double w = 0.0;
@@ -582,10 +765,38 @@ SL_HD double sl_tri_value_fast(const SlTri& t, const double* x) {
         int64_t vj = corner;
 #pragma unroll
         for (int k = 0; k < D; ++k) vj += ((code >> k) & 1) * t.stride[k];
-        acc = fma(w, t.table[vj * t.ncols], acc);
+        loc.row[j + 1] = vj * t.ncols;
+        loc.w[j + 1] = w;
         wsum += w;
     }
-    return fma(1.0 - wsum, t.table[v0 * t.ncols], acc);
+    loc.row[0] = v0 * t.ncols;
+    loc.w[0] = 1.0 - wsum;
+}
+
+// the table reads of a located point, apart from their use: kernels issue them early
+template <int D>
+SL_HD void sl_tri_gather(const SlTri& t, const SlTriLoc<D>& loc, double* vals) {
+#pragma unroll
+    for (int j = 0; j <= D; ++j) vals[j] = t.table[loc.row[j]];
+}
+
+template <int D>
+SL_HD double sl_tri_combine(const SlTriLoc<D>& loc, const double* vals) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 1; j <= D; ++j) acc = fma(loc.w[j], vals[j], acc);
+    return fma(loc.w[0], vals[0], acc);
+}
+
+template <int DT>
+SL_HD double sl_tri_value_fast(const SlTri& t, const double* x) {
+    if (DT == 0) return sl_tri_eval(t, x, 0, nullptr);
+    constexpr int D = DT > 0 ? DT : 1;
+    SlTriLoc<D> loc;
+    double vals[D + 1];
+    sl_tri_locate_fast<DT>(t, x, loc);
+    sl_tri_gather<D>(t, loc, vals);
+    return sl_tri_combine<D>(loc, vals);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -80,6 +80,11 @@ int hs_tri_eval(const sl_grid_desc* grid, int nsimplex, const int32_t* simplices
     t.table = table;
     sl_tri_finish(t, discrete_points);
     if (getenv("SL_HOSTSIM_LOAD_POINTS")) t.affine_points = 0;
+    if (getenv("SL_HOSTSIM_NO_REGIONS")) std::memset(t.ncand, 0, sizeof(t.ncand));
+    if (col == -2) {             // the candidate table of the point location shortcut
+        for (int c = 0; c < SL_TRI_CODES; ++c) out[c] = (double)t.ncand[c];
+        return 0;
+    }
     if (col == -1) {             // the Bellman sweeps' lookup (column 0, compile-time dimension)
         for (int64_t i = 0; i < npts; ++i) {
             const double* x = pts + i * d;

@@ -175,6 +175,30 @@ def test_triangulation_matches_oracle(hostsim, limits, num, project, col):
     assert_allclose(got[:, None], otri(pts), rtol=1e-10, atol=1e-12)
 
 
+def test_point_location_shortcut(hostsim, monkeypatch):
+    """The coordinate-order regions of sl_tri_regions: every 4-D region lists a handful of the 22
+    unit-cell simplices, and the pruned walk returns the full walk's value bit for bit, also with
+    the linspace points loaded instead of recomputed."""
+    rng = np.random.default_rng(3)
+    grid = F.GridWorld([[-1, 1]] * 4, [5, 4, 6, 3])
+    tri = F.Triangulation(grid, rng.normal(size=(grid.nindex, 1)), project=True)
+    ncand = _tri_eval(hostsim, tri, np.zeros((64, 4)), col=-2).astype(int)
+    assert (ncand > 0).sum() == 24 and ncand.max() <= 8 and ncand[ncand > 0].min() >= 4
+    span = np.diff(grid.limits, axis=1).T
+    pts = np.vstack([rng.uniform(-0.2, 1.2, (4000, 4)) * span + grid.offset, grid.all_points,
+                     0.5 * (grid.all_points[:-1] + grid.all_points[1:])])
+    fast = _tri_eval(hostsim, tri, pts, col=-1)
+    monkeypatch.setenv("SL_HOSTSIM_NO_REGIONS", "1")
+    assert_array_equal(fast, _tri_eval(hostsim, tri, pts, col=-1))
+    monkeypatch.setenv("SL_HOSTSIM_LOAD_POINTS", "1")
+    assert_array_equal(fast, _tri_eval(hostsim, tri, pts, col=-1))
+    monkeypatch.delenv("SL_HOSTSIM_NO_REGIONS")
+    grid3 = F.GridWorld([[0, 1]] * 3, [4, 3, 5])
+    tri3 = F.Triangulation(grid3, rng.normal(size=(grid3.nindex, 1)))
+    n3 = _tri_eval(hostsim, tri3, np.zeros((64, 3)), col=-2).astype(int)
+    assert (n3 > 0).sum() == 6 and n3.max() == 1
+
+
 def test_fmod_exact(hostsim):
     """sl_fmod_exact (one fma with the integer quotient) returns numpy's `%` bit for bit."""
     hostsim.hs_fmod_exact.restype = C.c_double
