@@ -22,6 +22,7 @@ class ModelBuilder(object):
         self.grid = grid
         self._gp_signature = None
         self._tri_signature = [None, None]
+        self._tri_structure = [None, None]
         self._net_signature = None
         self._policy_table = None
 
@@ -146,9 +147,18 @@ class ModelBuilder(object):
 
     def _upload_tri(self, slot, tri):
         signature = (tri._table_version, tri.project)
-        if signature != self._tri_signature[slot]:
+        if signature == self._tri_signature[slot]:
+            return
+        table = tri._device(self.ctx)
+        structure = (tri._structure_token, tri.project, int(table.shape[1]))
+        if structure == self._tri_structure[slot]:
+            # same grid and simplices, new vertex values (every value-iteration sweep): only the
+            # table pointer of the descriptor changes
+            self.ctx.tri_set_table(slot, table)
+        else:
             tri._upload(self.ctx, slot)
-            self._tri_signature[slot] = signature
+            self._tri_structure[slot] = structure
+        self._tri_signature[slot] = signature
 
     def _write_value(self, vd, fun):
         if isinstance(fun, QuadraticFunction):

@@ -227,7 +227,6 @@ typedef double sl_bd4 __attribute__((ext_vector_type(4)));
 #define SL_BM_T 4                         // cell tiles per wavefront
 // cells per epilogue step of a wavefront (bounded by the LDS the staged means need)
 #define SL_BM_SUB_OF(COLBLOCKS) ((COLBLOCKS) > 3 ? 16 : ((COLBLOCKS) == 3 ? 32 : 64))
-#define SL_BM_NAPS 16                     // x 8128 cycles of initial delay for wavefronts 4..7
 #define SL_BM_HEADS 4                     // GP heads (FunctionStack members) on the matrix-core path
 
 struct SlBellmanPack {
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
     double* __restrict__ v_new, int32_t* __restrict__ argmax, double* __restrict__ q_out,
     double* __restrict__ stats, int flags) {
     // flags (SL_BM_FLAGS, diagnostics): 1 no GEMM, 2 no (cell, action) epilogue, 4 workgroup
-    // barriers instead of wavefront-local ordering, 8 no phase offset of the upper wavefronts
+    // barriers instead of wavefront-local ordering
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red_max[SL_BM_WAVES], red_sum[SL_BM_WAVES];
     constexpr int SL_BM_SUB = SL_BM_SUB_OF(NCB * NH);
@@ -323,12 +322,6 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
         if (flags & 4) __syncthreads();                                                          \
         else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } \
     } while (0)
-    // Phase offset: the second wavefront of each SIMD starts about half a GEMM late, so that from
-    // then on its epilogues fall into the other one's GEMMs instead of coinciding with them.
-    if (!(flags & 8) && wave >= SL_BM_WAVES / 2) {
-        const int naps = (flags >> 8) ? (flags >> 8) : SL_BM_NAPS;
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t wbase = lo + tile * wg_cells + 16 * SL_BM_T * wave;   // first cell of the wavefront
         sl_bd4 acc[NH][SL_BM_T][NCB];

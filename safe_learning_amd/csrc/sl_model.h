@@ -18,6 +18,7 @@
 
 #include <stdint.h>
 #include <math.h>
+#include <string.h>
 #include "sl_hip.h"
 
 #if defined(__HIPCC__)
@@ -583,7 +584,29 @@ SL_HD int sl_tri_region_code(int d, const double* z) {
     return code;
 }
 
+inline void sl_tri_regions_compute(SlTri& t);
+// (a few milliseconds of host time in 4-D: the last result is kept and reused while the unit-cell
+// simplices stay the same, e.g. across the uploads of a value-iteration loop)
 inline void sl_tri_regions(SlTri& t) {
+    static thread_local SlTri memo;
+    static thread_local bool have = false;
+    const int d = t.grid.d;
+    if (have && memo.grid.d == d && memo.nsimplex == t.nsimplex &&
+        memcmp(memo.simplices, t.simplices, sizeof(t.simplices)) == 0) {
+        memcpy(t.ncand, memo.ncand, sizeof(t.ncand));
+        memcpy(t.cand, memo.cand, sizeof(t.cand));
+        return;
+    }
+    sl_tri_regions_compute(t);
+    memo.grid.d = d;
+    memo.nsimplex = t.nsimplex;
+    memcpy(memo.simplices, t.simplices, sizeof(t.simplices));
+    memcpy(memo.ncand, t.ncand, sizeof(t.ncand));
+    memcpy(memo.cand, t.cand, sizeof(t.cand));
+    have = true;
+}
+
+inline void sl_tri_regions_compute(SlTri& t) {
     using namespace sl_tri_detail;
     const int d = t.grid.d;
     for (int c = 0; c < SL_TRI_CODES; ++c) t.ncand[c] = 0;

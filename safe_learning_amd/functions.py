@@ -479,6 +479,7 @@ class Triangulation(DeterministicFunction):
         self._parameters = None
         self._device_table = None
         self._table_version = next(_TOKENS)
+        self._structure_token = next(_TOKENS)      # grid + unit-cell simplices never change
         if vertex_values is not None:
             self.parameters = vertex_values
         d = disc.ndim

@@ -9,9 +9,8 @@ run() {
   echo "flags=$1 ($2): kernel_ms $ms" | tee -a $OUT
 }
 for rep in 1 2; do
-  run 0 "wavefront-local ordering + phase offset (shipped)"
-  run 12 "workgroup barriers, no offset"
-  run 8 "wavefront-local ordering, no offset"
-  run 13 "no GEMM (epilogue only), barriers"
-  run 14 "no epilogue (GEMM only), barriers"
+  run 0 "wavefront-local ordering of the LDS stages (shipped)"
+  run 4 "workgroup barriers"
+  run 5 "no GEMM (epilogue only), barriers"
+  run 6 "no epilogue (GEMM only), barriers"
 done
