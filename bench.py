@@ -408,9 +408,15 @@ def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
                     "FETCH_SIZE x2 + WRITE_SIZE of this command, separate passes; not this run)"
         except (OSError, ValueError, KeyError):
             pass
+        # sl_gp4_supports(): the fixed-register 4x4x4 kernel takes closed-form policies with a
+        # quadratic V and more than 256 training points; everything else runs k_gp_sweep
+        plain = case.get("V", {"kind": "quadratic"})["kind"] == "quadratic" and \
+            "policy_table" not in case
+        kernel = "k_gp_sweep4" if (n > 256 and plain and os.environ.get("SL_GP_CFG", "2") == "2") \
+            else "k_gp_sweep"
         return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "traffic_source": source, "kernel": "k_gp_sweep", "kernel_ms": avg_ms,
+                "traffic_source": source, "kernel": kernel, "kernel_ms": avg_ms,
                 "flops_per_check": fpc,
                 "note": "compute-bound: 8.25 algorithmic HBM bytes per check (SURVEY 8d)"}
     # analytic dynamics: SURVEY 8d's 10 B per check (V read 8 + init mask + mask write, states

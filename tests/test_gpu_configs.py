@@ -1,6 +1,7 @@
 """BASELINE.json's other configurations at their full sizes (need an MI355X):
 
   C2  pendulum 256^2, 512-point GP        every cell against the oracle
+  C2-table  pendulum 251^2, 128-point GP, table V and table policy    every cell off the table lines
   C3  pendulum 2048^2, 2048-point GP, LyapunovNetwork [64,64,64]
                                           sub-range records + masks, sampled cells, level set
   C4-det  cart-pole 128^4, Euler dynamics sampled cells, level set
@@ -82,6 +83,30 @@ def _sampled_checks(lyap, olyap, n, neg, rtol, nsample, seed, starts=()):
     assert not np.any((neg[idx] != ref_neg) & (margin > 1e-8))
     assert ref_neg.any() and (~ref_neg).any()
     return both
+
+
+def test_c2_table_251_every_cell():
+    """The notebooks' table-V / table-policy sweep (bench config C2-table, inverted_pendulum.ipynb
+    cell 14) on its 251 x 251 grid: every cell against the oracle, away from the table grid's
+    lines (where the reference's own answer depends on scipy's search history)."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    from test_gpu_lyapunov import _on_table_face
+    case = _workload("C2-table")
+    assert case["num_points"] == [251, 251] and case["V"]["kind"] == "table"
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    values, neg, rec = _engine_records(lyap)
+    ref_rec, ref_neg = _oracle_all(olyap)
+    otri, opol = olyap.lyapunov_function, olyap.policy.fun
+    states = olyap.discretization.all_points
+    ok_x = ~(_on_table_face(otri, states) | _on_table_face(opol, states))
+    both = ok_x & ~_on_table_face(otri, ref_rec[:, 2:4])
+    assert both.sum() > 25000
+    assert_allclose(values[ok_x], olyap.values[ok_x], rtol=1e-12, atol=1e-14)
+    assert_allclose(rec[ok_x][:, 2:], ref_rec[ok_x][:, 2:], rtol=1e-9, atol=1e-12)
+    assert_allclose(rec[ok_x][:, 1], ref_rec[ok_x][:, 1], rtol=1e-9, atol=1e-14)
+    assert_allclose(rec[both][:, 0], ref_rec[both][:, 0], rtol=1e-7, atol=1e-12)
+    assert ref_neg[both].sum() > 1000 and (~ref_neg[both]).sum() > 1000
+    _check_masks(neg[both], ref_neg[both], rec[both], ref_rec[both])
 
 
 def test_c3_pendulum_2048_network():
