@@ -13,7 +13,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["sl_kernels.hip", "sl_gp.hip", "sl_gp4.hip", "sl_bellman.hip", "sl_nn.hip", "sl_comm.hip"]
+SOURCES = ["sl_kernels.hip", "sl_gp.hip", "sl_gp4.hip", "sl_bellman.hip", "sl_bellman4.hip", "sl_nn.hip",
+           "sl_comm.hip"]
+# kernels that own accumulator registers through inline asm: (source, kernel symbol prefix,
+# least number of MFMA loops the audit must recognise, accumulator registers the asm owns)
+FIXED_ACCUMULATOR_SOURCES = [("sl_gp4.hip", "_Z11k_gp_sweep4", 8, 256)]
 LIB = os.path.join(HERE, "libslhip.so")
 
 
@@ -24,20 +28,22 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _audit_gp4(objdir, verbose):
-    """k_gp_sweep4 owns the accumulator registers through inline asm: prove on the generated code
-    that the compiler never uses one and keeps the MFMA loops free of spill traffic."""
+def _audit_fixed_accumulators(objdir, verbose):
+    """k_gp_sweep4 and k_bellman4 own accumulator registers through inline asm: prove on the
+    generated code that the compiler never uses one and keeps the MFMA loops free of spill traffic."""
     import glob
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_gp4
-    listings = [f for f in glob.glob(os.path.join(objdir, "sl_gp4*gfx950*.s"))]
-    if not listings:
-        raise RuntimeError("device assembly of sl_gp4.hip not found in %s" % objdir)
-    report, problems = audit_gp4.audit(listings[0])
-    if verbose:
-        print("\n".join(report))
-    if problems:
-        raise RuntimeError("sl_gp4.hip failed its code audit:\n" + "\n".join(problems))
+    for src, prefix, min_loops, owned in FIXED_ACCUMULATOR_SOURCES:
+        stem = src[:-len(".hip")]
+        listings = [f for f in glob.glob(os.path.join(objdir, stem + "-hip-amdgcn*gfx950*.s"))]
+        if not listings:
+            raise RuntimeError("device assembly of %s not found in %s" % (src, objdir))
+        report, problems = audit_gp4.audit(listings[0], prefix, min_loops, owned)
+        if verbose:
+            print("\n".join(report))
+        if problems:
+            raise RuntimeError("%s failed its code audit:\n" % src + "\n".join(problems))
 
 
 def build(verbose=False, force=False):
@@ -61,7 +67,7 @@ def build(verbose=False, force=False):
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         extra = []
-        if os.path.basename(src) == "sl_gp4.hip":
+        if os.path.basename(src) in [f[0] for f in FIXED_ACCUMULATOR_SOURCES]:
             # fixed accumulator registers in inline asm: the compiler must not spill into the
             # accumulator file; keep the device assembly for the audit below
             extra = ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps=obj"]
@@ -77,7 +83,7 @@ def build(verbose=False, force=False):
         failed = failed or proc.returncode != 0
     if failed:
         raise RuntimeError("hipcc failed")
-    _audit_gp4(objdir, verbose)
+    _audit_fixed_accumulators(objdir, verbose)
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [obj for obj, _ in jobs] + ["-ldl"]
     res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:

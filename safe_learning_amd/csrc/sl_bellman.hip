@@ -737,6 +737,13 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
     SlBellmanPack pk;
     memset(&pk, 0, sizeof(pk));
     const bool policy_mode = n_actions == 0;
+    if (!policy_mode) {
+        // the 4x4x4 kernel (sl_bellman4.hip) takes the sweeps it is built for
+        int done4 = 0;
+        const int rc4 = sl_bellman4_launch(ctx, lo, hi, n_actions, d_v_new, d_argmax, d_q, d_stats, &done4);
+        if (rc4 != SL_OK) return rc4;
+        if (done4) { *done = 1; return SL_OK; }
+    }
     if (policy_mode) {
         // worthwhile for piecewise-constant policies; one shared-input head
         const int pkind = M.m.policy.kind;

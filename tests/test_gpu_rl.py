@@ -300,6 +300,43 @@ def test_future_values_per_vertex_actions(sl):
 
 
 @pytest.mark.parametrize("name,kw,nv,na", [
+    ("pendulum", dict(n_gp=70), [12, 64], 9),          # 18 (action, output) rows: 2 row blocks
+    ("pendulum", dict(n_gp=70), [5, 128], 2),          # 1 row block, two wavefronts per grid row
+    ("pendulum", dict(n_gp=100), [7, 64], 16),         # 32 rows, 100 points padded to 128
+    ("cartpole", dict(n_gp=90), [3, 4, 3, 64], 9),     # 36 rows: the 64^4 x 9 sweep's shape
+    ("cartpole", dict(n_gp=130), [2, 3, 2, 128], 12),  # 48 rows, all three row blocks full
+])
+def test_bellman_sweep_4x4x4_kernel(sl, name, kw, nv, na, monkeypatch):
+    """k_bellman4 (v_mfma_f64_4x4x4_4b_f64, sl_bellman4.hip) takes the max sweeps whose last grid
+    axis is a multiple of 64 cells: its action values against the oracle's
+    (reinforcement_learning.py:266-279) and against k_bellman_mfma's on the same inputs."""
+    case = cases.make_case(name, num_points=nv, **kw)
+    actions = np.linspace(-1, 1, na)[:, None]
+    results = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SL_BELLMAN4", flag)
+        rl, orl, vf, ovf = _rl_pair(sl, case, nv)
+        q = rl.discrete_policy_optimization(actions, return_values=True)
+        results[flag] = (q.cpu().numpy(), rl.policy.parameters[:, 0].copy())
+    orl.policy = oracle.Triangulation(ovf.discretization, np.zeros((ovf.discretization.nindex, 1)))
+    oq, obest = orl.discrete_policy_optimization(actions)
+    x = orl.state_space
+    ok = np.ones(len(x), dtype=bool)
+    for action in actions:
+        nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))
+        ok &= ~ambiguous_points(ovf, nxt[0] if isinstance(nxt, tuple) else nxt)
+    assert ok.mean() > 0.3
+    q4, best4 = results["1"]
+    q16, best16 = results["0"]
+    assert_allclose(q4[ok], oq[ok], rtol=1e-9, atol=1e-12)
+    assert_allclose(q4, q16, rtol=1e-11, atol=1e-13)
+    top2 = np.sort(oq, axis=1)[:, -2:]
+    tie = np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1])
+    assert not np.any((best4 != actions[obest, 0]) & ok & ~tie)
+    assert_array_equal(best4[~tie], best16[~tie])
+
+
+@pytest.mark.parametrize("name,kw,nv,na", [
     ("pendulum", dict(n_gp=70), [12, 64], 9),
     ("cartpole", dict(n_gp=90), 5, 9),
     ("pendulum", dict(dynamics="analytic"), 15, 5),

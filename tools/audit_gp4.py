@@ -1,31 +1,59 @@
 """Audit of sl_gp4.hip's compiled code (run by safe_learning_amd._build after every build).
 
 k_gp_sweep4 keeps its 128 FP64 accumulators at fixed accumulator registers a[0:255] that only
-the inline-asm MFMA groups may touch.  The compiler must therefore never use an accumulator
+the inline-asm MFMA groups may touch (k_bellman4 of sl_bellman4.hip: 48 at a[0:95], same rules).  The compiler must therefore never use an accumulator
 register on its own (VGPR spills to AGPRs are switched off with -amdgpu-spill-vgpr-to-agpr=0, this
-script proves it), and the MFMA loops must be free of scratch and lane-spill traffic.  Usage: python tools/audit_gp4.py <file.s>   (exit code 1 on a violation)."""
+script proves it), and the MFMA loops must be free of scratch and lane-spill traffic.  k_bellman4
+owns a[0:95] only: the compiler may use the accumulator registers above.
+Usage: python tools/audit_gp4.py <file.s> [kernel prefix [min loops [owned registers]]]   (exit code 1 on a violation)."""
 import re
 import sys
 
 
-def audit(path):
+def _touches_owned(code, owned):
+    """Does the instruction name an accumulator register below `owned`?"""
+    for m in re.finditer(r"\ba\[(\d+):(\d+)\]|(?<![\w.])a(\d+)\b", code):
+        first = int(m.group(1) if m.group(1) is not None else m.group(3))
+        if first < owned:
+            return True
+    return False
+
+
+def audit(path, prefix="_Z11k_gp_sweep4", min_loops=8, owned=256):
     text = open(path).read()
-    kernels = re.split(r"\n(?=_Z11k_gp_sweep4)", text)
+    kernels = re.split(r"\n(?=" + prefix + ")", text)
     problems, report = [], []
     for chunk in kernels:
-        m = re.match(r"(_Z11k_gp_sweep4\w+):", chunk)
+        m = re.match(r"(" + prefix + r"\w+):", chunk)
         if not m:
             continue
         name = m.group(1)
         body = chunk.split("s_endpgm")[0].split("\n")
         in_asm, mfma, outside = False, 0, []
-        for line in body:
+        # Kernels that own only part of the file (owned < 256) read their accumulators out after
+        # the MFMA loop: the registers must be left alone from the first zeroing asm block to the
+        # last read-out block; afterwards (epilogue) the compiler may use them.
+        first_zero = last_read = None
+        if owned < 256:
+            inside = False
+            for i, line in enumerate(body):
+                if ";;#ASMSTART" in line:
+                    inside = True
+                elif ";;#ASMEND" in line:
+                    inside = False
+                elif inside and first_zero is None and re.search(r"v_accvgpr_write_b32 a\d+, 0", line):
+                    first_zero = i
+                elif inside and "v_accvgpr_read_b32" in line:
+                    last_read = i
+        for i, line in enumerate(body):
             code = line.split(";")[0] if not line.strip().startswith(";;") else line
+            guarded = owned == 256 or (first_zero is not None and last_read is not None
+                                       and first_zero <= i <= last_read)
             if ";;#ASMSTART" in line:
                 in_asm = True
             elif ";;#ASMEND" in line:
                 in_asm = False
-            elif not in_asm and re.search(r"\bv_accvgpr|\ba\[\d+:\d+\]|[ ,]a\d+\b", code):
+            elif not in_asm and guarded and _touches_owned(code, owned):
                 outside.append(line.strip())
             if "v_mfma_f64_4x4x4" in line:
                 mfma += 1
@@ -59,20 +87,21 @@ def audit(path):
             problems.append("%s: the compiler touches accumulator registers: %s" % (name, outside[:3]))
         if hot_scratch:
             problems.append("%s: %d scratch instructions inside the MFMA loops" % (name, hot_scratch))
-        if len(hot) < 8:
-            problems.append("%s: only %d MFMA loops recognised (expected one per chunk variant)"
-                            % (name, len(hot)))
+        if len(hot) < min_loops:
+            problems.append("%s: only %d MFMA loops recognised (expected at least %d)"
+                            % (name, len(hot), min_loops))
         if lane_ops:
             problems.append("%s: %d v_readlane / v_writelane in the MFMA loops" % (name, lane_ops))
         if mfma == 0:
             problems.append("%s: no MFMA found" % name)
     if not report:
-        problems.append("no k_gp_sweep4 kernel found in %s" % path)
+        problems.append("no %s kernel found in %s" % (prefix, path))
     return report, problems
 
 
 if __name__ == "__main__":
-    report, problems = audit(sys.argv[1])
+    report, problems = audit(sys.argv[1], *(sys.argv[2:3] or ["_Z11k_gp_sweep4"]),
+                             *[int(v) for v in sys.argv[3:5]])
     print("\n".join(report))
     if problems:
         print("AUDIT FAILED:\n" + "\n".join(problems))
