@@ -393,7 +393,9 @@ def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
         achieved = flops * cells_per_launch / (avg_ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                "kernel": "k_bellman_mfma", "kernel_ms": avg_ms, "flops_per_vertex": flops}
+                "kernel": ("k_bellman4" if case["num_points"][-1] % 64 == 0 and not case.get("stack")
+                           and os.environ.get("SL_BELLMAN4", "1") != "0" else "k_bellman_mfma"),
+                "kernel_ms": avg_ms, "flops_per_vertex": flops}
     if is_gp:
         n, p = len(dyn["X"]), d + case["m"]
         heads = d if case.get("stack") else 1
