@@ -117,6 +117,20 @@ def _worker(rank, world, port, results, backend="gloo"):
             failures.append(("rl", "value_iteration", sweep))
         if not res >= 0.0:
             failures.append(("rl", "residual", res))
+    # the 4x4x4 Bellman kernel (last axis = whole wavefronts) on the two shards
+    case = cases.make_case("pendulum", num_points=[12, 64], n_gp=70)
+    rl, orl, vf, ovf = test_gpu_rl._rl_pair(sl, case, [12, 64])
+    rl.policy = sl.Triangulation(vf.discretization, np.zeros((vf.discretization.nindex, 1)))
+    orl.policy = oracle.Triangulation(ovf.discretization, np.zeros((ovf.discretization.nindex, 1)))
+    q = rl.discrete_policy_optimization(actions, return_values=True).cpu().numpy()
+    oq, _ = orl.discrete_policy_optimization(actions)
+    x = orl.state_space
+    ok = np.ones(len(x), dtype=bool)
+    for action in actions:
+        nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))
+        ok &= ~test_gpu_rl.ambiguous_points(ovf, nxt[0] if isinstance(nxt, tuple) else nxt)
+    if q.shape != oq.shape or not np.allclose(q[ok], oq[ok], rtol=1e-9, atol=1e-12):
+        failures.append(("rl", "4x4x4 action values"))
     results[rank] = failures
     dist.barrier()
     dist.destroy_process_group()
