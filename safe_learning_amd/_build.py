@@ -46,6 +46,22 @@ def _audit_fixed_accumulators(objdir, verbose):
             raise RuntimeError("%s failed its code audit:\n" % src + "\n".join(problems))
 
 
+def _audit_in_place(objdir, verbose):
+    """k_bellman4: accumulators are register values updated by opaque inline-asm MFMAs - see
+    tools/audit_gp4.py::audit_in_place."""
+    import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import audit_gp4
+    listings = glob.glob(os.path.join(objdir, "sl_bellman4-hip-amdgcn*gfx950*.s"))
+    if not listings:
+        raise RuntimeError("device assembly of sl_bellman4.hip not found in %s" % objdir)
+    report, problems = audit_gp4.audit_in_place(listings[0])
+    if verbose:
+        print("\n".join(report))
+    if problems:
+        raise RuntimeError("sl_bellman4.hip failed its code audit:\n" + "\n".join(problems))
+
+
 def build(verbose=False, force=False):
     csrc = os.path.join(HERE, "csrc")
     srcs = [os.path.join(csrc, s) for s in SOURCES if os.path.exists(os.path.join(csrc, s))]
@@ -71,6 +87,8 @@ def build(verbose=False, force=False):
             # fixed accumulator registers in inline asm: the compiler must not spill into the
             # accumulator file; keep the device assembly for the audit below
             extra = ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps=obj"]
+        if os.path.basename(src) == "sl_bellman4.hip":
+            extra = ["-save-temps=obj"]                  # assembly for _audit_in_place
         cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -84,6 +102,7 @@ def build(verbose=False, force=False):
     if failed:
         raise RuntimeError("hipcc failed")
     _audit_fixed_accumulators(objdir, verbose)
+    _audit_in_place(objdir, verbose)
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [obj for obj, _ in jobs] + ["-ldl"]
     res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
