@@ -15,6 +15,4 @@ for rep in 1 2; do
   run 1 2 "k_bellman4, no epilogue"
   run 1 1 "k_bellman4, no GEMM"
   run 1 18 "k_bellman4, GEMM only (no generation, no epilogue)"
-  run 1 64 "k_bellman4, one working wavefront per SIMD"
-  run 1 82 "k_bellman4, one wavefront per SIMD, GEMM only"
 done
