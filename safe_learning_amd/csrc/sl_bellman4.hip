@@ -26,6 +26,12 @@
 //    (measured at 64^4 x 9 actions x 1024 points: 37.4 ms with two, 48.4 ms with one; the GEMM
 //    alone 22.5 ms = 97 % of the instruction's rate; a start-up phase offset between the two
 //    changes nothing, prefetching a chunk's table entries across the MFMAs spills);
+//  * a last row block with at most 4 rows (36 = 2 x 16 + 4 rows for 9 actions x 4 outputs) would
+//    waste three of the four blocks of every instruction.  Its rows are given to ALL four blocks
+//    instead, each block taking a different slab of four training points (block b: slab 4 g + b of
+//    the group g of four slabs): one instruction then covers 4 rows x 16 cells x 16 points, a
+//    quarter of the instructions.  The four blocks' partial sums - over the slab classes, for
+//    cell group (b + rot) & 3 - are added across lanes once per tile ("quarter block", Q);
 //  * epilogue as in k_bellman_mfma: the means go through LDS to one lane per (cell, action group):
 //    prior mean, reward, value-table lookup, first arg-max.
 #include "sl_common.h"
@@ -69,6 +75,61 @@ __device__ __forceinline__ void group(Acc<NRB>& acc, const sl_d2& av, const BFra
         : "v"(av.x), "v"(av.y), "v"(b.v[0].x), "v"(b.v[0].y), "v"(b.v[1].x), "v"(b.v[1].y),
           "v"(b.v[2].x), "v"(b.v[2].y), "v"(b.v[3].x), "v"(b.v[3].y));
 }
+// Quarter block: accq(cb, rot).  One instruction per (group of four slabs, cell block, rotation):
+// A = the block's own slab of the <= 4 rows, B = that slab's k_x for cell group (b + rot) & 3.
+struct AccQ { double v[CB][4]; };
+template <int ROT>
+__device__ __forceinline__ void group_q(AccQ& q, double aq, const double (&bq)[CB]) {
+    asm volatile(
+        "v_mfma_f64_4x4x4_4b_f64 %0, %4, %5, %0\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %1, %4, %6, %1\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %2, %4, %7, %2\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %3, %4, %8, %3"
+        : "+v"(q.v[0][ROT]), "+v"(q.v[1][ROT]), "+v"(q.v[2][ROT]), "+v"(q.v[3][ROT])
+        : "v"(aq), "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]));
+}
+// the four slabs of group sgl (0 / 1) of the chunk: lane (k, b, col) reads point 4 (4 sgl + b) + k
+// of cell 16 cb + 4 ((b + rot) & 3) + col; qoff[rot] = its offset inside a (pair, cell block) tile
+__device__ __forceinline__ void quarter(AccQ& q, double aq, const double* kxb, int sgl,
+                                        const int (&qoff)[4]) {
+    double b0[CB], b1[CB];
+    const double* base = kxb + 2 * sgl * KXS2;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) b0[cb] = base[cb * 128 + qoff[0]];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) b1[cb] = base[cb * 128 + qoff[1]];
+    group_q<0>(q, aq, b0);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) b0[cb] = base[cb * 128 + qoff[2]];
+    group_q<1>(q, aq, b1);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) b1[cb] = base[cb * 128 + qoff[3]];
+    group_q<2>(q, aq, b0);
+    group_q<3>(q, aq, b1);
+}
+__device__ __forceinline__ void retire_q(AccQ& q) {
+    asm volatile("s_nop 15\n\ts_nop 7"
+                 : "+v"(q.v[0][0]), "+v"(q.v[0][1]), "+v"(q.v[0][2]), "+v"(q.v[0][3]),
+                   "+v"(q.v[1][0]), "+v"(q.v[1][1]), "+v"(q.v[1][2]), "+v"(q.v[1][3]),
+                   "+v"(q.v[2][0]), "+v"(q.v[2][1]), "+v"(q.v[2][2]), "+v"(q.v[2][3]),
+                   "+v"(q.v[3][0]), "+v"(q.v[3][1]), "+v"(q.v[3][2]), "+v"(q.v[3][3]));
+}
+// Partial sums -> means of the quarter block's rows: the value of (row rowi, cell 16 cb + 4 g + col)
+// is the sum over rot of accq(cb, rot) in lane (rowi, b = (g - rot) & 3, col); lane (rowi, g, col)
+// collects it and stores it behind the NRB full row blocks of half H.
+template <int NRB, int H>
+__device__ __forceinline__ void stage_quarter(const AccQ& q, double* mean_l, int lane) {
+    const int g = (lane >> 2) & 3;
+#pragma unroll
+    for (int cbh = 0; cbh < 2; ++cbh) {
+        double sum = q.v[2 * H + cbh][0];
+#pragma unroll
+        for (int rot = 1; rot < 4; ++rot)
+            sum += __shfl(q.v[2 * H + cbh][rot], (lane & ~12) | (((g - rot) & 3) << 2), 64);
+        mean_l[(16 * cbh + 4 * g + (lane & 3)) * ROWLEN + 16 * NRB + (lane >> 4)] = sum;
+    }
+}
+
 // the last MFMAs have retired before any other instruction reads an accumulator
 template <int NRB, int RI = 0>
 __device__ __forceinline__ void retire(Acc<NRB>& acc) {
@@ -142,9 +203,11 @@ __device__ __forceinline__ void stage_half(const Acc<NRB>& acc, double* mean_l, 
 }
 
 struct Pack {
+    int64_t btq;                // quarter block: [n_pad / 16][64 lanes], lane (i, k): row 16 NRB + (i & 3),
+                                // point 16 g + 4 (i >> 2) + k
     int64_t bt;                 // Bt fragments [NRB][nslab2][64 lanes][2]
     int64_t tab[SL_D];          // T_k [N_k][n_pad], every axis
-    int32_t nslab2, n_pad, nrb, reserved;
+    int32_t nslab2, n_pad, nrb, quarter;
 };
 
 }  // namespace bm4
@@ -178,6 +241,24 @@ __global__ __launch_bounds__(256) void k_bellman4_pack(const SlDevModel M, const
         }
         bt[t] = v;
     }
+    if (pk.quarter) {
+        double* btq = pack + pk.btq;
+        for (int64_t t = tid; t < (int64_t)(n_pad / 16) * 64; t += nthreads) {
+            const int l = (int)(t & 63), g = (int)(t >> 6);
+            const int col = 16 * pk.nrb + (l & 3), j = 16 * g + 4 * ((l >> 2) & 3) + (l >> 4);
+            const int a = col / dout, dd = col - a * dout;
+            double v = 0.0;
+            if (a < n_actions && j < hd.n) {
+                double z = 0.0;
+                for (int c = 0; c < m; ++c) {
+                    const double dlt = hd.xs[(d + c) * src_pad + j] - actions[a * m + c] * hd.inv_ls[d + c];
+                    z = fma(dlt, dlt, z);
+                }
+                v = hd.variance * sl_exp_nonpos(-0.5 * z) * hd.alpha[j * dout + dd];
+            }
+            btq[t] = v;
+        }
+    }
     int64_t stride = 1;                    // flat-index stride of axis k (last axis fastest)
     for (int k = d - 1; k >= 0; --k) {
         const int nk = (int)M.m.grid.num_points[k];
@@ -197,7 +278,7 @@ __global__ __launch_bounds__(256) void k_bellman4_pack(const SlDevModel M, const
     }
 }
 
-template <int DT, int NRB>
+template <int DT, int NRB, bool Q>
 __global__ __launch_bounds__(64 * bm4::W) void k_bellman4(
     const SlDevModel M, const SlGpDev gp, SlAux aux, bm4::Pack pk, int64_t lo, int64_t hi,
     int n_actions, const double* __restrict__ actions, const double* __restrict__ pack,
@@ -235,7 +316,12 @@ __global__ __launch_bounds__(64 * bm4::W) void k_bellman4(
     const int wswz = 4 * ((jj & 3) >> 1);
     double* w_lo = kxb + (jj >> 3) * KXS2 + (2 * half) * 128 + 32 * (jj & 3) + ((jj >> 2) & 1) + 2 * wswz;
     double* w_hi = w_lo - 8 * wswz;                    // slots that wrap around for wswz = 4
-    const int n_last = (int)M.m.grid.num_points[d - 1];
+    // quarter block: lane (k, b, col) reads slab 4 sgl + b = pair 2 sgl + (b >> 1), slab b & 1
+    int qoff[4];
+#pragma unroll
+    for (int rot = 0; rot < 4; ++rot)
+        qoff[rot] = (blk >> 1) * KXS2 + 32 * lk + 2 * ((4 * ((blk + rot) & 3) + low + 4 * (lk >> 1)) & 15) + (blk & 1);
+    const double* btq = pack + pk.btq;
 
     double lmax = 0.0, lsum = 0.0;
     const int64_t wtiles = (hi - lo) / C;
@@ -257,7 +343,17 @@ __global__ __launch_bounds__(64 * bm4::W) void k_bellman4(
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                 for (int rot = 0; rot < 4; ++rot) acc.v[r][cb][rot] = 0.0;
+        AccQ accq;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int rot = 0; rot < 4; ++rot) accq.v[cb][rot] = 0.0;
         for (int ch = (flags & 1) ? nchunks : 0; ch < nchunks; ++ch) {
+            double aq0 = 0.0, aq1 = 0.0;
+            if (Q) {
+                aq0 = btq[(2 * ch) * 64 + lane];
+                aq1 = btq[(2 * ch + 1) * 64 + lane];
+            }
             AFrag<NRB> a0, a1, a2, a3;
             load_a<NRB>(a0, rsrc, nslab2, 4 * ch, lane);
             load_a<NRB>(a1, rsrc, nslab2, 4 * ch + 1, lane);
@@ -294,14 +390,18 @@ __global__ __launch_bounds__(64 * bm4::W) void k_bellman4(
             load_b(be, kxb, boff[0]);
             slab_pair<NRB>(acc, a0, be, bo, kxb, kxb + KXS2, boff);
             slab_pair<NRB>(acc, a1, be, bo, kxb + KXS2, kxb + 2 * KXS2, boff);
+            if (Q) quarter(accq, aq0, kxb, 0, qoff);
             slab_pair<NRB>(acc, a2, be, bo, kxb + 2 * KXS2, kxb + 3 * KXS2, boff);
             slab_pair<NRB>(acc, a3, be, bo, kxb + 3 * KXS2, kxb + 3 * KXS2, boff);
+            if (Q) quarter(accq, aq1, kxb, 1, qoff);
         }
         retire<NRB>(acc);
+        if (Q) retire_q(accq);
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             wave_sync();
             if (h2 == 0) stage_half<NRB, 0>(acc, kxb, lane); else stage_half<NRB, 1>(acc, kxb, lane);
+            if (Q) { if (h2 == 0) stage_quarter<NRB, 0>(accq, kxb, lane); else stage_quarter<NRB, 1>(accq, kxb, lane); }
             wave_sync();
             const int64_t sbase = wbase + SUB * h2;
             // ---- (cell, action) pairs: prior mean, reward, value lookup ------------------------
@@ -393,10 +493,18 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
     if (n_last % C != 0 || lo % C != 0 || hi % C != 0 || hi <= lo) return SL_OK;
     Pack pk;
     memset(&pk, 0, sizeof(pk));
-    pk.nrb = (rows + 15) / 16;
+    // full row blocks, and a quarter block for a remainder of at most 4 rows
+    pk.quarter = (rows > 16 && rows % 16 >= 1 && rows % 16 <= 4) ? 1 : 0;
+    pk.nrb = pk.quarter ? rows / 16 : (rows + 15) / 16;
+    {
+        const char* qenv = getenv("SL_BELLMAN4_QUARTER");
+        if (qenv && qenv[0] == '0' && pk.quarter) { pk.quarter = 0; pk.nrb = (rows + 15) / 16; }
+    }
     pk.n_pad = n_pad;
     pk.nslab2 = n_pad / 8;
     int64_t cursor = 0;
+    pk.btq = cursor;
+    cursor += (int64_t)(n_pad / 16) * 64;
     pk.bt = cursor;
     cursor += (int64_t)pk.nrb * pk.nslab2 * 128;
     for (int k = 0; k < d; ++k) {
@@ -423,9 +531,9 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
     SlAux aux{ctx->d_tri, ctx->d_net};
     const char* fenv = getenv("SL_BM_FLAGS");
     const int flags = fenv ? atoi(fenv) : 0;
-#define SL_B4_LAUNCH(D_, N_)                                                                      \
+#define SL_B4_LAUNCH(D_, N_, Q_)                                                                  \
     do {                                                                                          \
-        auto kern = k_bellman4<D_, N_>;                                                           \
+        auto kern = k_bellman4<D_, N_, Q_>;                                                         \
         SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                               (int)lds));                                         \
@@ -433,11 +541,13 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
                            ctx->h_gp, aux, pk, lo, hi, n_actions, ctx->d_actions, pack, d_v_new,  \
                            d_argmax, d_q, d_stats, flags);                                        \
     } while (0)
-#define SL_B4_ROWS(D_)                                  \
-    do {                                                \
-        if (pk.nrb == 1) SL_B4_LAUNCH(D_, 1);           \
-        else if (pk.nrb == 2) SL_B4_LAUNCH(D_, 2);      \
-        else SL_B4_LAUNCH(D_, 3);                       \
+#define SL_B4_ROWS(D_)                                                    \
+    do {                                                                  \
+        if (pk.nrb == 1 && pk.quarter) SL_B4_LAUNCH(D_, 1, true);         \
+        else if (pk.nrb == 1) SL_B4_LAUNCH(D_, 1, false);                 \
+        else if (pk.nrb == 2 && pk.quarter) SL_B4_LAUNCH(D_, 2, true);    \
+        else if (pk.nrb == 2) SL_B4_LAUNCH(D_, 2, false);                 \
+        else SL_B4_LAUNCH(D_, 3, false);                                  \
     } while (0)
     if (variant == 4) SL_B4_ROWS(4); else SL_B4_ROWS(2);
 #undef SL_B4_ROWS
