@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * bm4::W) void k_bellman4(
     double* __restrict__ v_new, int32_t* __restrict__ argmax, double* __restrict__ q_out,
     double* __restrict__ stats, int flags) {
     // flags (SL_BM_FLAGS, diagnostics): 1 no GEMM, 2 no (cell, action) epilogue, 16 no generation,
-    // 64 one working wavefront per SIMD
+    // 64 one working wavefront per SIMD, 128 no value-table lookup
     using namespace bm4;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red_max[W], red_sum[W];
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64 * bm4::W) void k_bellman4(
                         }
                     }
                     const double r = sl_quadratic(M.m.reward, p, x);
-                    double v = sl_tri_value_fast<DT>(vt, nxt);
+                    double v = (flags & 128) ? nxt[0] : sl_tri_value_fast<DT>(vt, nxt);
                     if (M.m.value.negate) v = v * -1.0;
                     const double tq = M.m.gamma * v;
                     const double q = r + tq;

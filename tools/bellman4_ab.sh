@@ -1,7 +1,7 @@
 #!/bin/bash
 # C5 Bellman max sweep: k_bellman4 (4x4x4) against k_bellman_mfma (16x16x4), interleaved, plus
 # the attribution flags of k_bellman4 (SL_BM_FLAGS: 1 no GEMM, 2 no epilogue, 16 no generation,
-# 64 one working wavefront per SIMD).
+# 64 one working wavefront per SIMD, 128 no value-table lookup).
 mkdir -p gpurun_out
 OUT=gpurun_out/r02_bellman4_ab.txt
 : > $OUT
@@ -15,5 +15,6 @@ for rep in 1 2; do
   run 0 0 "k_bellman_mfma"
   run 1 2 "k_bellman4, no epilogue"
   run 1 1 "k_bellman4, no GEMM"
+  run 1 129 "k_bellman4, no GEMM, no value-table lookup"
   run 1 18 "k_bellman4, GEMM only (no generation, no epilogue)"
 done
