@@ -283,7 +283,9 @@ __global__ __launch_bounds__(64 * bm4::W) void k_bellman4(
     const SlDevModel M, const SlGpDev gp, SlAux aux, bm4::Pack pk, int64_t lo, int64_t hi,
     int n_actions, const double* __restrict__ actions, const double* __restrict__ pack,
     double* __restrict__ v_new, int32_t* __restrict__ argmax, double* __restrict__ q_out,
-    double* __restrict__ stats, int flags) {
+    double* __restrict__ stats, int flags, double* __restrict__ means_out, int64_t means_stride) {
+    // means_out != 0: the kernel stops after the GEMM and writes the posterior means of its cells,
+    // means_out[row * means_stride + (cell - lo)]; k_bellman_lookup finishes the sweep.
     // flags (SL_BM_FLAGS, diagnostics): 1 no GEMM, 2 no (cell, action) epilogue, 16 no generation,
     // 64 one working wavefront per SIMD, 128 no value-table lookup
     using namespace bm4;
@@ -404,6 +406,14 @@ __global__ __launch_bounds__(64 * bm4::W) void k_bellman4(
             if (Q) { if (h2 == 0) stage_quarter<NRB, 0>(accq, kxb, lane); else stage_quarter<NRB, 1>(accq, kxb, lane); }
             wave_sync();
             const int64_t sbase = wbase + SUB * h2;
+            if (means_out) {
+                // lane = (cell of the half, half of the rows): 256-byte runs of cells per row
+                const int rows = A * dout;
+                double* dst = means_out + (sbase - lo) + (lane & (SUB - 1));
+                for (int row = lane >> 5; row < rows; row += 2)
+                    dst[(int64_t)row * means_stride] = kxb[(lane & (SUB - 1)) * ROWLEN + row];
+                continue;
+            }
             // ---- (cell, action) pairs: prior mean, reward, value lookup ------------------------
             // lane = (cell of the step, group of actions): the cell's state is computed once,
             // each group walks its share of the actions in ascending order
@@ -470,6 +480,75 @@ __global__ __launch_bounds__(64 * bm4::W) void k_bellman4(
     }
 }
 
+// Second half of the split sweep: one thread per cell walks the actions - prior mean, reward,
+// value-table lookup, first arg-max - from the means k_bellman4 left in means[row][cell].  The
+// lookup is a long chain of dependent FP64 and LDS operations per (cell, action); inside
+// k_bellman4 two wavefronts per SIMD (all the register file) cannot hide it (10.3 of 31.8 ms), a
+// kernel of its own runs it at four to five wavefronts per SIMD.
+#ifndef SL_B4_LOOKUP_BLOCKS
+#define SL_B4_LOOKUP_BLOCKS 3
+#endif
+template <int DT>
+__global__ __launch_bounds__(256, SL_B4_LOOKUP_BLOCKS) void k_bellman_lookup(
+    const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t out_lo,
+    int n_actions, const double* __restrict__ actions, const double* __restrict__ means,
+    int64_t means_stride, double* __restrict__ v_new, int32_t* __restrict__ argmax,
+    double* __restrict__ q_out, double* __restrict__ stats) {
+    __shared__ double red_max[4];
+    __shared__ SlTri vt_lds;
+    __shared__ double act_l[16 * SL_M];
+    const SlDims nd = sl_dims<DT, 1>(M);
+    const int d = nd.d, p = nd.p, A = n_actions;
+    if ((int)threadIdx.x < A * nd.m) act_l[threadIdx.x] = actions[threadIdx.x];
+    sl_stage_tri(&vt_lds, &aux.tri[0]);
+    const SlTri& vt = vt_lds;
+    const SlGpHeadDev& hd = gp.head[0];
+    const int dout = hd.dout;
+    double lmax = 0.0;
+    for (int64_t idx = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < hi;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        double x[SL_P], u[SL_M], prior[SL_D], nxt[SL_D];
+        sl_index_to_state(M.m.grid, M.gf, d, idx, x);
+        const double* mcol = means + (idx - lo);
+        double best_q = 0.0;
+        int best_a = -1;
+        for (int a = 0; a < A; ++a) {
+#pragma unroll
+            for (int c = 0; c < SL_M; ++c) if (c < nd.m) u[c] = act_l[a * nd.m + c];
+            sl_append_action(nd, u, x);
+            sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) {
+                if (k < d) {
+                    const int dd = k - hd.col0;
+                    const double mu = (dd >= 0 && dd < dout) ? mcol[(int64_t)(a * dout + dd) * means_stride] : 0.0;
+                    nxt[k] = mu + prior[k];
+                }
+            }
+            const double r = sl_quadratic(M.m.reward, p, x);
+            double v = sl_tri_value_fast<DT>(vt, nxt);
+            if (M.m.value.negate) v = v * -1.0;
+            const double tq = M.m.gamma * v;
+            const double q = r + tq;
+            if (q_out) q_out[(idx - out_lo) * A + a] = q;
+            if (best_a < 0 || q > best_q) { best_q = q; best_a = a; }
+        }
+        v_new[idx - out_lo] = best_q;
+        if (argmax) argmax[idx - out_lo] = best_a;
+        double v_old = vt.table[idx * vt.ncols];
+        if (M.m.value.negate) v_old = v_old * -1.0;
+        lmax = fmax(lmax, fabs(best_q - v_old));
+    }
+    for (int o = 32; o >= 1; o >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, o, 64));
+    if ((threadIdx.x & 63) == 0) red_max[threadIdx.x >> 6] = lmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) lmax = fmax(lmax, red_max[w]);
+        atomicMax(reinterpret_cast<unsigned long long*>(&stats[0]),
+                  (unsigned long long)__double_as_longlong(lmax));
+    }
+}
+
 // Sets *done = 1 when this kernel took the sweep: one shared-input GP head covering the state,
 // 2 or 4 state dimensions, one action dimension, at most 48 (action, output) rows, the last grid
 // axis a multiple of 64 cells and a 64-aligned index range.
@@ -512,6 +591,13 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
         cursor += M.m.grid.num_points[k] * (int64_t)n_pad;
     }
     if ((int64_t)pk.nrb * pk.nslab2 * 1024 > 0x7fffffffll) return SL_OK;
+    // split sweep (default): the GEMM kernel leaves the means of a round of cells in the scratch
+    // buffer and k_bellman_lookup finishes them; SL_BELLMAN4_SPLIT=0 keeps the fused epilogue
+    const char* senv = getenv("SL_BELLMAN4_SPLIT");
+    const bool split = !(senv && senv[0] == '0');
+    const int64_t round_cells = split ? ((hi - lo) < (4ll << 20) ? (hi - lo) : (4ll << 20)) : 0;
+    const int64_t means_off = cursor;
+    cursor += (int64_t)rows * round_cells;
     const size_t need = sizeof(double) * (size_t)cursor;
     if (need > ctx->scratch_bytes) {
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -525,21 +611,21 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
                        pk, n_actions, ctx->d_actions, pack);
     SL_HIP_CHECK(ctx, hipGetLastError());
     const size_t lds = sizeof(double) * (size_t)W * KXBUF;
-    const int64_t wtiles = (hi - lo) / C;
-    const int64_t wg = (wtiles + W - 1) / W;
-    const int blocks = (int)(wg < ctx->num_cu ? wg : ctx->num_cu);
     SlAux aux{ctx->d_tri, ctx->d_net};
     const char* fenv = getenv("SL_BM_FLAGS");
     const int flags = fenv ? atoi(fenv) : 0;
 #define SL_B4_LAUNCH(D_, N_, Q_)                                                                  \
     do {                                                                                          \
-        auto kern = k_bellman4<D_, N_, Q_>;                                                         \
+        auto kern = k_bellman4<D_, N_, Q_>;                                                       \
         SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,         \
                                               (int)lds));                                         \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds, ctx->stream, ctx->h_model,      \
-                           ctx->h_gp, aux, pk, lo, hi, n_actions, ctx->d_actions, pack, d_v_new,  \
-                           d_argmax, d_q, d_stats, flags);                                        \
+                           ctx->h_gp, aux, pk, rlo, rhi, n_actions, ctx->d_actions, pack,         \
+                           d_v_new ? d_v_new + (rlo - lo) : d_v_new,                              \
+                           d_argmax ? d_argmax + (rlo - lo) : d_argmax,                           \
+                           d_q ? d_q + (rlo - lo) * n_actions : d_q, d_stats, flags, means,       \
+                           round_cells);                                                          \
     } while (0)
 #define SL_B4_ROWS(D_)                                                    \
     do {                                                                  \
@@ -549,7 +635,29 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
         else if (pk.nrb == 2) SL_B4_LAUNCH(D_, 2, false);                 \
         else SL_B4_LAUNCH(D_, 3, false);                                  \
     } while (0)
-    if (variant == 4) SL_B4_ROWS(4); else SL_B4_ROWS(2);
+    double* means = split ? pack + means_off : nullptr;
+    const int64_t step_cells = split ? round_cells : (hi - lo);
+    for (int64_t rlo = lo; rlo < hi; rlo += step_cells) {
+        const int64_t rhi = rlo + step_cells < hi ? rlo + step_cells : hi;
+        const int64_t wtiles = (rhi - rlo) / C;
+        const int64_t wg = (wtiles + W - 1) / W;
+        const int blocks = (int)(wg < ctx->num_cu ? wg : ctx->num_cu);
+        if (variant == 4) SL_B4_ROWS(4); else SL_B4_ROWS(2);
+        SL_HIP_CHECK(ctx, hipGetLastError());
+        if (split) {
+            const int64_t nblk = (rhi - rlo + 255) / 256;
+            const int lblocks = (int)(nblk < 16 * (int64_t)ctx->num_cu ? nblk : 16 * (int64_t)ctx->num_cu);
+            if (variant == 4)
+                hipLaunchKernelGGL(k_bellman_lookup<4>, dim3(lblocks), dim3(256), 0, ctx->stream,
+                                   ctx->h_model, ctx->h_gp, aux, rlo, rhi, lo, n_actions, ctx->d_actions,
+                                   means, round_cells, d_v_new, d_argmax, d_q, d_stats);
+            else
+                hipLaunchKernelGGL(k_bellman_lookup<2>, dim3(lblocks), dim3(256), 0, ctx->stream,
+                                   ctx->h_model, ctx->h_gp, aux, rlo, rhi, lo, n_actions, ctx->d_actions,
+                                   means, round_cells, d_v_new, d_argmax, d_q, d_stats);
+            SL_HIP_CHECK(ctx, hipGetLastError());
+        }
+    }
 #undef SL_B4_ROWS
 #undef SL_B4_LAUNCH
     SL_HIP_CHECK(ctx, hipGetLastError());

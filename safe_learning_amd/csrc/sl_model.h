@@ -338,15 +338,21 @@ SL_HD int64_t sl_rectangle_1d(const SlTri& t, int k, double x) {
     const double g = (x - offset) * t.inv_unit[k];
     int i;
     if (!(g > 0.0)) i = 0; else if (g >= (double)(n - 1)) i = n - 1; else i = (int)g;
+    // The guess is at most one point off (|g| < 2^31: its error is far below 1, and the points
+    // themselves are i * unit + offset rounded), so ONE step up and ONE step down replace the two
+    // search loops - as selects, without divergent control flow (the loops cost ~280 instructions
+    // per dimension and lookup in exec-mask bookkeeping).
 #define SL_PT(I) ((double)(I) * unit + offset)
-    while (i + 1 < n && SL_PT(i + 1) <= x) ++i;
-    while (i > 0 && SL_PT(i) > x) --i;
-    int cnt = (SL_PT(i) <= x) ? (i + 1) : 0;
+    const bool up = (i + 1 < n) && (SL_PT(i + 1) <= x);
+    i = up ? i + 1 : i;
+    const bool down = (i > 0) && (SL_PT(i) > x);
+    i = down ? i - 1 : i;
+    int cnt = (SL_PT(i) <= x) ? (i + 1) : 0;      // bins[cnt-1] <= x < bins[cnt]
 #undef SL_PT
-    if (x != x) cnt = n;
+    if (x != x) cnt = n;                           // NaN sorts last in digitize
     int r = cnt - 1;
-    if (r < 0) r = 0;
-    if (r > n - 2) r = n - 2;
+    r = r < 0 ? 0 : r;
+    r = r > n - 2 ? n - 2 : r;
     return r;
 }
 
@@ -690,10 +696,14 @@ SL_HD double sl_fmod_exact(double a, double b) {
 }
 // the quotient guessed with a reciprocal (inv_b ~ 1 / b) and corrected until 0 <= r < b
 SL_HD double sl_fmod_exact(double a, double b, double inv_b) {
+    // |q| < 2^31 here: the reciprocal's guess is at most one off on either side
     double q = floor(a * inv_b);
     double r = fma(-q, b, a);
-    while (r < 0.0) { q -= 1.0; r = fma(-q, b, a); }
-    while (r >= b) { q += 1.0; r = fma(-q, b, a); }
+    const double qm = q - 1.0, rm = fma(-qm, b, a);
+    q = (r < 0.0) ? qm : q;
+    r = (r < 0.0) ? rm : r;
+    const double qp = q + 1.0, rp = fma(-qp, b, a);
+    r = (r >= b) ? rp : r;
     return r;
 }
 

@@ -85,6 +85,17 @@ int hs_tri_eval(const sl_grid_desc* grid, int nsimplex, const int32_t* simplices
         for (int c = 0; c < SL_TRI_CODES; ++c) out[c] = (double)t.ncand[c];
         return 0;
     }
+    if (col == -4) {             // rectangle index per point (digitize semantics, functions.py:1116-1124)
+        for (int64_t i = 0; i < npts; ++i) {
+            double corner = 0.0, mul = 1.0;
+            for (int k = d - 1; k >= 0; --k) {
+                corner += mul * (double)sl_rectangle_1d(t, k, pts[i * d + k]);
+                mul *= (double)(grid->num_points[k] - 1);
+            }
+            out[i] = corner;
+        }
+        return 0;
+    }
     if (col == -1) {             // the Bellman sweeps' lookup (column 0, compile-time dimension)
         for (int64_t i = 0; i < npts; ++i) {
             const double* x = pts + i * d;
@@ -100,6 +111,7 @@ int hs_tri_eval(const sl_grid_desc* grid, int nsimplex, const int32_t* simplices
 }
 
 double hs_fmod_exact(double a, double b) { return sl_fmod_exact(a, b); }
+double hs_fmod_exact_inv(double a, double b) { return sl_fmod_exact(a, b, 1.0 / b); }
 double hs_exp_nonpos(double x) { return sl_exp_nonpos(x); }
 void hs_sincos(double x, double* s, double* c) { sl_sincos(x, s, c); }
 

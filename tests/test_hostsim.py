@@ -208,10 +208,39 @@ def test_fmod_exact(hostsim):
     a = np.concatenate([rng.uniform(0, 50, 2000), [0.3, 0.375, 1.0, 62 * (2 / 63), 1.0]])
     # exact multiples and their neighbours, where the rounded quotient is off by one
     k = rng.integers(0, 200, len(b))
+    hostsim.hs_fmod_exact_inv.restype = C.c_double
+    hostsim.hs_fmod_exact_inv.argtypes = [C.c_double, C.c_double]
     for aa in (a, k * b, np.nextafter(k * b, np.inf), np.nextafter(k * b, 0)):
         aa = np.abs(aa)
         got = np.array([hostsim.hs_fmod_exact(float(x), float(y)) for x, y in zip(aa, b)])
         assert_array_equal(got, np.fmod(aa, b))
+        # the lookups' variant: quotient guessed with the reciprocal, corrected by selects
+        got = np.array([hostsim.hs_fmod_exact_inv(float(x), float(y)) for x, y in zip(aa, b)])
+        assert_array_equal(got, np.fmod(aa, b))
+
+
+def test_rectangle_index_matches_digitize(hostsim):
+    """The branch-free rectangle search (one corrected guess) against the oracle's np.digitize
+    on grid points, their floating-point neighbours, points outside the grid and NaN."""
+    rng = np.random.default_rng(9)
+    for limits, num in (([[-1, 1]] * 2, [64, 7]), ([[0.3, 2.9], [-5, -1], [0, 1e-3]], [33, 128, 5]),
+                        ([[-1, 1]] * 4, [64, 64, 64, 64])):
+        grid = F.GridWorld(limits, num)
+        ogrid = oracle.GridWorld(limits, num)
+        tri = F.Triangulation(grid, np.zeros((grid.nindex, 1)))
+        d = grid.ndim
+        cols = []
+        for k in range(d):
+            p = grid.discrete_points[k]
+            cols.append(np.concatenate([p, np.nextafter(p, np.inf), np.nextafter(p, -np.inf),
+                                        [p[0] - 1.0, p[-1] + 1.0, 1e300, -1e300, np.nan],
+                                        rng.uniform(p[0] - 0.1, p[-1] + 0.1, 300)]))
+        m = min(len(c) for c in cols)
+        pts = np.stack([rng.permutation(c)[:m] for c in cols], axis=1)
+        got = _tri_eval(hostsim, tri, pts, col=-4)
+        want = ogrid.state_to_rectangle(pts)
+        assert_array_equal(got, want)
+
 
 
 def test_triangulation_golden_cases(hostsim, golden):
