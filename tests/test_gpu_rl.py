@@ -313,8 +313,11 @@ def test_bellman_sweep_4x4x4_kernel(sl, name, kw, nv, na, monkeypatch):
     case = cases.make_case(name, num_points=nv, **kw)
     actions = np.linspace(-1, 1, na)[:, None]
     results = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("SL_BELLMAN4", flag)
+    # "1": GEMM kernel + k_bellman_lookup (shipped); "fused": the same GEMM with its own epilogue;
+    # "0": the 16x16x4 kernel
+    for flag in ("1", "fused", "0"):
+        monkeypatch.setenv("SL_BELLMAN4", "0" if flag == "0" else "1")
+        monkeypatch.setenv("SL_BELLMAN4_SPLIT", "0" if flag == "fused" else "1")
         rl, orl, vf, ovf = _rl_pair(sl, case, nv)
         q = rl.discrete_policy_optimization(actions, return_values=True)
         results[flag] = (q.cpu().numpy(), rl.policy.parameters[:, 0].copy())
@@ -330,6 +333,8 @@ def test_bellman_sweep_4x4x4_kernel(sl, name, kw, nv, na, monkeypatch):
     q16, best16 = results["0"]
     assert_allclose(q4[ok], oq[ok], rtol=1e-9, atol=1e-12)
     assert_allclose(q4, q16, rtol=1e-11, atol=1e-13)
+    assert_array_equal(results["fused"][0], q4)          # same GEMM, same per-pair arithmetic
+    assert_array_equal(results["fused"][1], best4)
     top2 = np.sort(oq, axis=1)[:, -2:]
     tie = np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1])
     assert not np.any((best4 != actions[obest, 0]) & ok & ~tie)
