@@ -48,6 +48,32 @@ def test_bench_line_small_and_two_ranks():
     assert two["config"]["c_max"] == cfg["c_max"]
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch line for N > 1 (one process per rank started by
+    torch.distributed.run, RANK / LOCAL_RANK / WORLD_SIZE in the environment); on this one-GPU box
+    both ranks share cuda:0 and rendezvous over gloo."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--num-points", "24", "--n-gp", "300", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout                   # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["config"]["collectives"]["world_size"] == 2
+    assert out["config"]["safe_cells"] > out["config"]["initial_cells"]
+
+
 @pytest.mark.parametrize("config,flags", [
     ("C1", []),
     ("C2", ["--num-points", "64", "--n-gp", "128"]),
