@@ -52,6 +52,13 @@ struct SlTri {
     // region_code = one bit per coordinate pair (i < j): z_i < z_j.  ncand[code] == 0: no table.
     uint8_t ncand[SL_TRI_CODES];
     uint8_t cand[SL_TRI_CODES][SL_TRI_MAXCAND];
+    // Second level (4-D only): inside a coordinate-order region the six signs of z_i + z_j - 1 cut
+    // the candidates down to at most four.  fine[perm_index[code] * 64 + sum_code] = up to four
+    // simplex indices, 0xFF = none / no entry (then the region's full list above is used).  Found
+    // by sampling - complete up to slivers, and a miss only costs the full walk, never the result.
+    int32_t has_fine, reserved2;
+    uint8_t perm_index[SL_TRI_CODES];
+    uint8_t fine[24 * 64][4];
     const double* table;                             // [nindex][ncols] (device)
 };
 
@@ -590,6 +597,14 @@ SL_HD int sl_tri_region_code(int d, const double* z) {
     return code;
 }
 
+// bit per pair (i < j), same order as sl_tri_region_code: 1 iff z_i + z_j < 1
+SL_HD int sl_tri_sum_code(int d, const double* z) {
+    int code = 0, bit = 0;
+    for (int i = 0; i < d; ++i)
+        for (int j = i + 1; j < d; ++j, ++bit) code |= (z[i] + z[j] < 1.0) ? (1 << bit) : 0;
+    return code;
+}
+
 inline void sl_tri_regions_compute(SlTri& t);
 // (a few milliseconds of host time in 4-D: the last result is kept and reused while the unit-cell
 // simplices stay the same, e.g. across the uploads of a value-iteration loop)
@@ -601,6 +616,9 @@ inline void sl_tri_regions(SlTri& t) {
         memcmp(memo.simplices, t.simplices, sizeof(t.simplices)) == 0) {
         memcpy(t.ncand, memo.ncand, sizeof(t.ncand));
         memcpy(t.cand, memo.cand, sizeof(t.cand));
+        t.has_fine = memo.has_fine;
+        memcpy(t.perm_index, memo.perm_index, sizeof(t.perm_index));
+        memcpy(t.fine, memo.fine, sizeof(t.fine));
         return;
     }
     sl_tri_regions_compute(t);
@@ -609,6 +627,9 @@ inline void sl_tri_regions(SlTri& t) {
     memcpy(memo.simplices, t.simplices, sizeof(t.simplices));
     memcpy(memo.ncand, t.ncand, sizeof(t.ncand));
     memcpy(memo.cand, t.cand, sizeof(t.cand));
+    memo.has_fine = t.has_fine;
+    memcpy(memo.perm_index, t.perm_index, sizeof(t.perm_index));
+    memcpy(memo.fine, t.fine, sizeof(t.fine));
     have = true;
 }
 
@@ -616,6 +637,7 @@ inline void sl_tri_regions_compute(SlTri& t) {
     using namespace sl_tri_detail;
     const int d = t.grid.d;
     for (int c = 0; c < SL_TRI_CODES; ++c) t.ncand[c] = 0;
+    t.has_fine = 0;
     if (d < 2 || d > 4 || t.nsimplex < 3) return;           // nothing to prune
     double sg[SL_MAX_SIMPLICES][5][4], sh[SL_MAX_SIMPLICES][5];
     for (int s = 0; s < t.nsimplex; ++s) {
@@ -660,6 +682,59 @@ inline void sl_tri_regions_compute(SlTri& t) {
         }
     }
     for (int c = 0; c < SL_TRI_CODES; ++c) t.ncand[c] = ncand[c];
+    // ---- second level by sampling (4-D) ------------------------------------------------------
+    if (d != 4) return;
+    int nperm = 0;
+    for (int c = 0; c < SL_TRI_CODES; ++c) t.perm_index[c] = (ncand[c] > 0) ? (uint8_t)nperm++ : 0xFF;
+    if (nperm != 24) return;
+    memset(t.fine, 0xFF, sizeof(t.fine));
+    // hits[region][simplex]: how many of the sampled points of the region lie in the simplex; the
+    // four most frequent simplices of a region become its candidates (in ascending index order:
+    // the first-index tie rule), rarer slivers are left to the full walk
+    static const int NSAMPLES = 2000000;
+    static thread_local uint32_t hits[24 * 64][SL_MAX_SIMPLICES];
+    memset(hits, 0, sizeof(hits));
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    for (int n = 0; n < NSAMPLES; ++n) {
+        double z[4];
+        for (int k = 0; k < 4; ++k) {
+            rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+            z[k] = ((double)(rng >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+        }
+        int best = -1;
+        double best_min = 1e-9;                       // strictly interior points only
+        for (int s = 0; s < t.nsimplex; ++s) {
+            double wmin = 1e300;
+            for (int i = 0; i <= 4 && wmin > best_min; ++i) {
+                double w = sh[s][i];
+                for (int k = 0; k < 4; ++k) w += sg[s][i][k] * z[k];
+                wmin = w < wmin ? w : wmin;
+            }
+            if (wmin > best_min) { best_min = wmin; best = s; break; }   // interiors are disjoint
+        }
+        if (best < 0) continue;
+        ++hits[t.perm_index[sl_tri_region_code(4, z)] * 64 + sl_tri_sum_code(4, z)][best];
+    }
+    for (int idx = 0; idx < 24 * 64; ++idx) {
+        int chosen[4] = {-1, -1, -1, -1};
+        for (int q = 0; q < 4; ++q) {
+            int arg = -1;
+            uint32_t top = 0;
+            for (int sidx = 0; sidx < t.nsimplex; ++sidx) {
+                bool taken = false;
+                for (int p = 0; p < q; ++p) taken = taken || chosen[p] == sidx;
+                if (!taken && hits[idx][sidx] > top) { top = hits[idx][sidx]; arg = sidx; }
+            }
+            chosen[q] = arg;
+        }
+        for (int a = 0; a < 4; ++a)                          // ascending, -1 (none) last
+            for (int b2 = a + 1; b2 < 4; ++b2)
+                if (chosen[b2] >= 0 && (chosen[a] < 0 || chosen[b2] < chosen[a])) {
+                    const int tmp = chosen[a]; chosen[a] = chosen[b2]; chosen[b2] = tmp;
+                }
+        for (int q = 0; q < 4; ++q) t.fine[idx][q] = chosen[q] < 0 ? 0xFF : (uint8_t)chosen[q];
+    }
+    t.has_fine = 1;
 }
 
 inline void sl_tri_finish(SlTri& t, const double* h_points) {
@@ -767,13 +842,30 @@ SL_HD void sl_tri_locate_fast(const SlTri& t, const double* x, SlTriLoc<(DT > 0 
 #pragma unroll
         for (int k = 0; k < D; ++k) z[k] = unitc[k] * t.inv_unit[k];
         const int code = sl_tri_region_code(D, z);
-        const int nc = t.ncand[code];
-        // two candidates per round: their hyperplane rows are read together instead of in two
-        // dependent round trips (an odd last candidate is tried twice, which changes nothing)
-        for (int i = 0; i < nc; i += 2) {
-            const int s0 = t.cand[code][i], s1 = t.cand[code][i + 1 < nc ? i + 1 : i];
-            SL_TRI_TRY(s0);
-            SL_TRI_TRY(s1);
+        // second level (4-D): at most four candidates; two per round - their hyperplane rows are
+        // read together instead of in two dependent round trips (an odd last candidate is tried
+        // twice, which changes nothing)
+        uint32_t fw = 0xFFFFFFFFu;
+        if (D == 4 && t.has_fine)
+            fw = *reinterpret_cast<const uint32_t*>(t.fine[t.perm_index[code] * 64 + sl_tri_sum_code(D, z)]);
+        int nc = 1;
+        if ((fw & 0xFFu) != 0xFFu) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int s0 = (int)((fw >> (16 * r)) & 0xFFu);
+                if (s0 == 0xFF) break;
+                int s1 = (int)((fw >> (16 * r + 8)) & 0xFFu);
+                s1 = (s1 == 0xFF) ? s0 : s1;
+                SL_TRI_TRY(s0);
+                SL_TRI_TRY(s1);
+            }
+        } else {
+            nc = t.ncand[code];
+            for (int i = 0; i < nc; i += 2) {
+                const int s0 = t.cand[code][i], s1 = t.cand[code][i + 1 < nc ? i + 1 : i];
+                SL_TRI_TRY(s0);
+                SL_TRI_TRY(s1);
+            }
         }
         full = !(nc > 0 && best_min > 0.0);
     }

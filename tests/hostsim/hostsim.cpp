@@ -80,9 +80,47 @@ int hs_tri_eval(const sl_grid_desc* grid, int nsimplex, const int32_t* simplices
     t.table = table;
     sl_tri_finish(t, discrete_points);
     if (getenv("SL_HOSTSIM_LOAD_POINTS")) t.affine_points = 0;
-    if (getenv("SL_HOSTSIM_NO_REGIONS")) std::memset(t.ncand, 0, sizeof(t.ncand));
+    if (getenv("SL_HOSTSIM_NO_REGIONS")) { std::memset(t.ncand, 0, sizeof(t.ncand)); t.has_fine = 0; }
     if (col == -2) {             // the candidate table of the point location shortcut
         for (int c = 0; c < SL_TRI_CODES; ++c) out[c] = (double)t.ncand[c];
+        return 0;
+    }
+    if (col == -3) {             // 1.0 where the candidate phase of the point location resolves the point
+        for (int64_t i = 0; i < npts; ++i) {
+            const double* x = pts + i * d;
+            double z[4], zn[4], best_min = -1e300;
+            for (int k = 0; k < d; ++k) {
+                double c = x[k] - t.grid.offset[k];
+                const double eps2 = 2.0 * 2.220446049250313e-16;
+                const double lo = 0.0 + eps2, hi = (t.grid.upper[k] - t.grid.offset[k]) - eps2;
+                c = (c < lo) ? lo : c;
+                c = (c > hi) ? hi : c;
+                z[k] = sl_fmod_exact(c, t.grid.unit_maxes[k], t.inv_unit[k]);
+                zn[k] = z[k] * t.inv_unit[k];
+            }
+            const int code = sl_tri_region_code(d, zn);
+            int list[SL_TRI_MAXCAND], n = 0;
+            bool fine = false;
+            if (d == 4 && t.has_fine) {
+                const uint8_t* f = t.fine[t.perm_index[code] * 64 + sl_tri_sum_code(d, zn)];
+                for (int q = 0; q < 4 && f[q] != 0xFF; ++q) list[n++] = f[q];
+                fine = n > 0;
+            }
+            if (!fine) for (int q = 0; q < t.ncand[code]; ++q) list[n++] = t.cand[code][q];
+            for (int q = 0; q < n; ++q) {
+                const int s = list[q];
+                double w0 = 1.0, wmin = 1e300;
+                for (int j = 0; j < d; ++j) {
+                    double w = -t.hyper_c[s][j];
+                    for (int k = 0; k < d; ++k) w = fma(z[k], t.hyper[s][k][j], w);
+                    w0 -= w;
+                    wmin = fmin(wmin, w);
+                }
+                wmin = fmin(wmin, w0);
+                if (wmin > best_min) best_min = wmin;
+            }
+            out[i] = (best_min > 0.0 ? 1.0 : 0.0) + (fine ? 2.0 : 0.0) + 4.0 * n;
+        }
         return 0;
     }
     if (col == -4) {             // rectangle index per point (digitize semantics, functions.py:1116-1124)

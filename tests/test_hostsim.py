@@ -188,6 +188,14 @@ def test_point_location_shortcut(hostsim, monkeypatch):
     pts = np.vstack([rng.uniform(-0.2, 1.2, (4000, 4)) * span + grid.offset, grid.all_points,
                      0.5 * (grid.all_points[:-1] + grid.all_points[1:])])
     fast = _tri_eval(hostsim, tri, pts, col=-1)
+    # second level (signs of z_i + z_j - 1): at most four candidates, and the candidate phase
+    # settles every point that is not on a face of the unit cell in two or more coordinates
+    probe = _tri_eval(hostsim, tri, pts, col=-3).astype(int)
+    resolved, fine, tried = (probe & 1) == 1, (probe & 2) == 2, probe >> 2
+    assert fine.all() and tried.max() <= 4 and tried.mean() < 3.5
+    generic = pts[:4000]
+    inside = (np.abs(generic - grid.offset) < span).all(axis=1) & (generic > grid.offset).all(axis=1)
+    assert resolved[:4000][inside].all()
     monkeypatch.setenv("SL_HOSTSIM_NO_REGIONS", "1")
     assert_array_equal(fast, _tri_eval(hostsim, tri, pts, col=-1))
     monkeypatch.setenv("SL_HOSTSIM_LOAD_POINTS", "1")
