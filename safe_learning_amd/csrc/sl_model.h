@@ -609,10 +609,18 @@ inline void sl_tri_regions_compute(SlTri& t);
 // (a few milliseconds of host time in 4-D: the last result is kept and reused while the unit-cell
 // simplices stay the same, e.g. across the uploads of a value-iteration loop)
 inline void sl_tri_regions(SlTri& t) {
-    static thread_local SlTri memo;
-    static thread_local bool have = false;
+    // one remembered result per dimension: programs that alternate between, say, a 4-D value
+    // table and a 2-D one do not pay the 4-D sampling again
+    static thread_local SlTri memos[SL_D + 1];
+    static thread_local bool have[SL_D + 1] = {false};
     const int d = t.grid.d;
-    if (have && memo.grid.d == d && memo.nsimplex == t.nsimplex &&
+    if (d < 2 || d > 4) {                            // nothing to prune
+        for (int c = 0; c < SL_TRI_CODES; ++c) t.ncand[c] = 0;
+        t.has_fine = 0;
+        return;
+    }
+    SlTri& memo = memos[d];
+    if (have[d] && memo.nsimplex == t.nsimplex &&
         memcmp(memo.simplices, t.simplices, sizeof(t.simplices)) == 0) {
         memcpy(t.ncand, memo.ncand, sizeof(t.ncand));
         memcpy(t.cand, memo.cand, sizeof(t.cand));
@@ -622,7 +630,6 @@ inline void sl_tri_regions(SlTri& t) {
         return;
     }
     sl_tri_regions_compute(t);
-    memo.grid.d = d;
     memo.nsimplex = t.nsimplex;
     memcpy(memo.simplices, t.simplices, sizeof(t.simplices));
     memcpy(memo.ncand, t.ncand, sizeof(t.ncand));
@@ -630,7 +637,7 @@ inline void sl_tri_regions(SlTri& t) {
     memo.has_fine = t.has_fine;
     memcpy(memo.perm_index, t.perm_index, sizeof(t.perm_index));
     memcpy(memo.fine, t.fine, sizeof(t.fine));
-    have = true;
+    have[d] = true;
 }
 
 inline void sl_tri_regions_compute(SlTri& t) {
