@@ -6,9 +6,9 @@
 // FP64 GEMM  mean[(a, dd)][cell] = sum_j Bt[(a, dd)][j] S[j][cell],  Bt = sigma^2 E_j(u_a) alpha'[j][dd].
 // What differs is the instruction: v_mfma_f64_16x16x4_f64 issues every ~100 cycles on gfx950
 // (47 TFLOP/s, where k_bellman_mfma's GEMM loop sits), the four-block 4x4x4 one every 16.3
-// (76 TFLOP/s), and its 4-column granularity fits the 9 actions x 4 outputs = 36 columns of the
-// cart-pole sweep into 3 row blocks of 16 where the 16x16x4 kernel pads to 48 of 48 as well but
-// pays 100 cycles per 16 columns.  Structure (the discipline of sl_gp4.hip):
+// (76 TFLOP/s), and its 4-row granularity lets the 9 actions x 4 outputs = 36 rows of the cart-pole
+// sweep cost 2.25 row blocks of 16 (see "quarter block") where the 16x16x4 kernel pays for 48
+// columns.  Structure (fragment layouts of sl_gp4.hip):
 //
 //  * rows of the GEMM = (action, output) pairs: Bt is packed once per sweep in MFMA A-fragment
 //    order [row block][slab pair][lane][2] (k_bellman4_pack) and fetched with buffer loads;
@@ -23,17 +23,20 @@
 //    ordinary values in vector registers (MFMAs in inline asm with read-write operands: the
 //    builtin would insist on the accumulator file); two wavefronts per SIMD (256 registers
 //    each), so one runs its GEMM while the other generates a chunk or walks the value table
-//    (measured at 64^4 x 9 actions x 1024 points: 37.4 ms with two, 48.4 ms with one; the GEMM
-//    alone 22.5 ms = 97 % of the instruction's rate; a start-up phase offset between the two
-//    changes nothing, prefetching a chunk's table entries across the MFMAs spills);
+//    (measured at 64^4 x 9 actions x 1024 points with three full row blocks and the fused
+//    epilogue: 37.4 ms with two, 48.4 ms with one; the GEMM alone 22.5 ms = 97 % of the
+//    instruction's rate; a start-up phase offset between the two changes nothing, prefetching
+//    a chunk's table entries across the MFMAs spills);
 //  * a last row block with at most 4 rows (36 = 2 x 16 + 4 rows for 9 actions x 4 outputs) would
 //    waste three of the four blocks of every instruction.  Its rows are given to ALL four blocks
 //    instead, each block taking a different slab of four training points (block b: slab 4 g + b of
 //    the group g of four slabs): one instruction then covers 4 rows x 16 cells x 16 points, a
 //    quarter of the instructions.  The four blocks' partial sums - over the slab classes, for
 //    cell group (b + rot) & 3 - are added across lanes once per tile ("quarter block", Q);
-//  * epilogue as in k_bellman_mfma: the means go through LDS to one lane per (cell, action group):
-//    prior mean, reward, value-table lookup, first arg-max.
+//  * the means go through LDS either to global memory, means[row][cell], for k_bellman_lookup
+//    (one thread per cell, three wavefronts per SIMD: prior mean, reward, value-table lookup,
+//    first arg-max) - the default, 27.8 ms per sweep - or to the fused epilogue of
+//    k_bellman_mfma, one lane per (cell, action group), 28.8 ms (SL_BELLMAN4_SPLIT=0).
 #include "sl_common.h"
 
 typedef double sl_d2 __attribute__((ext_vector_type(2)));
