@@ -207,6 +207,26 @@ def test_point_location_shortcut(hostsim, monkeypatch):
     assert (n3 > 0).sum() == 6 and n3.max() == 1
 
 
+def test_region_tables_are_remembered_per_dimension(hostsim):
+    """sl_tri_regions keeps one result per dimension: a 2-D table in between must neither disturb
+    nor be disturbed by the 4-D tables (same values before and after, sampled level included)."""
+    rng = np.random.default_rng(11)
+    g4 = F.GridWorld([[-1, 1]] * 4, [4, 5, 3, 4])
+    t4 = F.Triangulation(g4, rng.normal(size=(g4.nindex, 1)), project=True)
+    g2 = F.GridWorld([[-1, 1], [0, 3]], [9, 6])
+    t2 = F.Triangulation(g2, rng.normal(size=(g2.nindex, 1)), project=True)
+    p4 = rng.uniform(-1.1, 1.1, (3000, 4))
+    p2 = rng.uniform(-1.1, 3.1, (3000, 2))
+    first4 = _tri_eval(hostsim, t4, p4, col=-1)
+    first2 = _tri_eval(hostsim, t2, p2, col=-1)
+    assert_array_equal(_tri_eval(hostsim, t4, p4, col=-1), first4)
+    assert_array_equal(_tri_eval(hostsim, t2, p2, col=-1), first2)
+    assert_array_equal(_tri_eval(hostsim, t4, np.zeros((64, 4)), col=-2),
+                       _tri_eval(hostsim, t4, np.zeros((64, 4)), col=-2))
+    ot4 = oracle.Triangulation(oracle.GridWorld([[-1, 1]] * 4, [4, 5, 3, 4]), t4.parameters, project=True)
+    assert_allclose(first4[:, None], ot4(p4), rtol=1e-10, atol=1e-12)
+
+
 def test_fmod_exact(hostsim):
     """sl_fmod_exact (one fma with the integer quotient) returns numpy's `%` bit for bit."""
     hostsim.hs_fmod_exact.restype = C.c_double
