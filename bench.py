@@ -250,14 +250,18 @@ def run_rank(args, rank, world, local_rank, backend):
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local_rank % max(ndev, 1))
     dist = None
-    if world > 1:
+    # SL_FORCE_COLLECTIVES=1: the exact collective sequence of the N > 1 path at world size 1
+    # (RCCL on a one-GPU box, tests/test_gpu_bench.py)
+    grouped = world > 1 or os.environ.get("SL_FORCE_COLLECTIVES") == "1"
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()) if world == 1 else "29511")
+        backend = backend or "nccl"
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -275,24 +279,28 @@ def run_rank(args, rank, world, local_rank, backend):
         step = lambda: obj.value_iteration(actions)          # noqa: E731
         cells_per_launch = obj._hi - obj._lo
 
+    from safe_learning_amd import distributed as dist_utils
     for _ in range(args.warmup):
         step()
     barrier()
     obj.sweep_events = []                         # HIP events around the dominant kernel
+    dist_utils.start_timing()                     # device events around every collective
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    own_elapsed = time.perf_counter() - t0        # this rank's host clock before the barrier
     barrier()
     elapsed = time.perf_counter() - t0
+    collective_ms = dist_utils.stop_timing() / max(args.steps, 1)
     kernel_ms = [a.elapsed_time(b) for a, b in obj.sweep_events]
     obj.sweep_events = None
     avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-    per_rank = [elapsed, avg_ms]
-    if world > 1:
+    per_rank = [elapsed, avg_ms, collective_ms, 1e3 * own_elapsed / max(args.steps, 1)]
+    if grouped:
         t = torch.tensor(per_rank, dtype=torch.float64, device="cuda")
-        gathered = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)
-        per_rank_all = [[float(v) for v in g] for g in gathered]
+        gathered = torch.empty(world * t.numel(), dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(gathered, t)
+        per_rank_all = gathered.reshape(world, -1).cpu().tolist()
         elapsed = max(r[0] for r in per_rank_all)
         observed_world = dist.get_world_size()
     else:
@@ -313,7 +321,7 @@ def run_rank(args, rank, world, local_rank, backend):
         # cells that pass the decrease check (popcount of the mask words of all ranks)
         neg = obj._d_neg[:(cells_per_launch + 63) // 64]
         cnt = torch.tensor([int(_popcount(neg))], dtype=torch.int64, device="cuda")
-        if world > 1:
+        if grouped:
             dist.all_reduce(cnt)
         extra["negative_cells"] = int(cnt[0])
         # end to end: one more update including the bool[N] mask on the host (lyapunov.py:598-606)
@@ -360,9 +368,16 @@ def run_rank(args, rank, world, local_rank, backend):
             "data": "synthetic",
             "config": dict({"workload": label, "name": args.config,
                             "grid_sharding": "contiguous 64-aligned index ranges over %d GPU(s)" % world,
-                            "collectives": {"backend": backend if world > 1 else None,
+                            "collectives": {"backend": backend if grouped else None,
                                             "world_size": observed_world,
                                             "ranks_share_a_device": bool(world > max(ndev, 1))},
+                            # per step; collective_ms = device time inside the collectives of a
+                            # step (two 64-byte record gathers + the mask-word gather for
+                            # update_safe_set; table gather + residual for a Bellman sweep),
+                            # including the wait for the slowest rank to arrive; max over ranks
+                            "collective_ms": max(r[2] for r in per_rank_all),
+                            "per_rank_collective_ms": [r[2] for r in per_rank_all],
+                            "per_rank_ms_per_step": [r[3] for r in per_rank_all],
                             "per_rank_kernel_ms": [r[1] for r in per_rank_all]}, **extra),
         }
         if end_to_end_ms is not None:
@@ -371,7 +386,7 @@ def run_rank(args, rank, world, local_rank, backend):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, case)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

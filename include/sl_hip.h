@@ -29,6 +29,9 @@
 extern "C" {
 #endif
 
+/* libslhip.so is built with -fvisibility=hidden: only the entry points declared here are exported. */
+#define SL_API __attribute__((visibility("default")))
+
 #define SL_OK               0
 #define SL_ERR_INVALID     (-1)   /* bad argument / model not set            */
 #define SL_ERR_HIP         (-2)   /* a HIP runtime call failed               */
@@ -136,14 +139,19 @@ typedef struct sl_sweep_result {
 } sl_sweep_result;
 
 /* ---- context ------------------------------------------------------------------------- */
-int  sl_version(void);
-int  sl_ctx_create(int device, void* hip_stream, sl_ctx** out);
-int  sl_ctx_destroy(sl_ctx* ctx);
-const char* sl_last_error(const sl_ctx* ctx);      /* ctx may be NULL: last global error */
-int  sl_ctx_synchronize(sl_ctx* ctx);
+SL_API int  sl_version(void);
+SL_API int  sl_ctx_create(int device, void* hip_stream, sl_ctx** out);
+SL_API int  sl_ctx_destroy(sl_ctx* ctx);
+SL_API const char* sl_last_error(const sl_ctx* ctx);      /* ctx may be NULL: last global error */
+SL_API int  sl_ctx_synchronize(sl_ctx* ctx);
+/* Name (with its template arguments) of the kernel(s) the last sl_lyap_sweep / sl_bellman_sweep of
+ * this context launched for the per-cell work, e.g. "k_gp_sweep4<d=4, m=1, xs_global=0>" or
+ * "k_gp_sweep<...> + k_nn_check_mfma<...>" for a two-pass sweep; "" before the first sweep.  The
+ * string lives in the context and is overwritten by the next sweep. */
+SL_API const char* sl_last_kernel(const sl_ctx* ctx);
 
 /* ---- model upload (copies; replaces the TF graph build of lyapunov.py:431-443) --------- */
-int  sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model);
+SL_API int  sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model);
 
 /* GP head `head` of the dynamics (FunctionStack: one head per output column,
  * functions.py:278-291; a shared-kernel multi-output GPRCached is one head with dout = D).
@@ -152,7 +160,7 @@ int  sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model);
  *                     so that a = Linv k_x equals tf.matrix_triangular_solve (functions.py:441)
  *   h_alpha  [n][dout] L^-1 (Y - m(X))                    (GPRCached.alpha,  functions.py:405-409)
  * RBF (gpflow 0.4.0): k = variance * exp(-0.5 sum_q ((x_q - x'_q) / lengthscales_q)^2). */
-int  sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
+SL_API int  sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
                     const double* h_X, const double* h_Linv, const double* h_alpha,
                     double variance, const double* h_lengthscales);
 /* One more training point for an uploaded head (GaussianProcess.add_data_point,
@@ -162,29 +170,29 @@ int  sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
  *   h_alpha_new [dout] = the new last row of alpha = L^-1 (Y - m(X)).
  * alpha' = Linv^T alpha gets the rank-one term linv_row * alpha_new.  Returns SL_ERR_UNSUPPORTED
  * when the padded capacity of the head is exhausted (then call sl_gp_set_head again). */
-int  sl_gp_append_point(sl_ctx* ctx, int head, const double* h_x, const double* h_linv_row,
+SL_API int  sl_gp_append_point(sl_ctx* ctx, int head, const double* h_x, const double* h_linv_row,
                         const double* h_alpha_new);
-int  sl_gp_configure(sl_ctx* ctx, int nheads, double beta);
+SL_API int  sl_gp_configure(sl_ctx* ctx, int nheads, double beta);
 
 /* Auxiliary grid #slot with a per-vertex table (Triangulation: functions.py:1002-1032,
  * 1064-1101): slot 0 = value function, slot 1 = policy.  h_simplices [nsimplex][d+1] are the
  * unit-cell vertices as {0,1}^d corner codes (bit k = dimension k), h_hyperplanes
  * [nsimplex][d][d] = inv(vertices[1:] - vertices[0]); d_table [nindex][ncols] stays caller-owned. */
-int  sl_tri_set(sl_ctx* ctx, int slot, const sl_grid_desc* h_grid, int nsimplex,
+SL_API int  sl_tri_set(sl_ctx* ctx, int slot, const sl_grid_desc* h_grid, int nsimplex,
                 const int32_t* h_simplices, const double* h_hyperplanes,
                 const double* h_discrete_points, int project, int ncols, const double* d_table);
-int  sl_tri_set_table(sl_ctx* ctx, int slot, const double* d_table);
+SL_API int  sl_tri_set_table(sl_ctx* ctx, int slot, const double* d_table);
 
 /* LyapunovNetwork (examples/utilities.py:85-104): h_kernels = per-layer kernel matrices
  * [out_i][in_i] concatenated; activation codes 0 = linear, 1 = tanh, 2 = relu. */
-int  sl_network_set(sl_ctx* ctx, int nlayers, const int32_t* h_dims /* nlayers+1 */,
+SL_API int  sl_network_set(sl_ctx* ctx, int nlayers, const int32_t* h_dims /* nlayers+1 */,
                     const int32_t* h_activations, const double* h_kernels);
 
 /* ---- Lyapunov passes ------------------------------------------------------------------- */
 /* values[i-lo] = V(all_points[i]), i in [lo,hi): the points of functions.py:622-638 (np.linspace:
  * the last point of each dimension is exactly the upper limit).  Replaces
  * Lyapunov.update_values (lyapunov.py:305-322). */
-int  sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values);
+SL_API int  sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values);
 
 /* Decrease check of every cell i in [lo,hi) (lo % 64 == 0): policy -> dynamics ->
  * V(f(x)) - V(x) + L_v.err < -|L_v|_1 (1 + L_f) tau  (lyapunov.py:436-441, 265-288, 324-376).
@@ -195,14 +203,14 @@ int  sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values);
  *   d_neg_bits    out the `negative` mask
  *   d_result      out ->fail = lexmin over failing cells (other fields untouched)
  *   d_dbg         out (may be NULL) per cell [decrease, threshold, mean[d], err[d]] */
-int  sl_lyap_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
+SL_API int  sl_lyap_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
                    const double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
                    double* d_dbg);
 
 /* safe_i = init_i | (key_i < key_star) | (prev_i & key_i >= key_keep), the parallel form of
  * lyapunov.py:513-606.  d_prev_bits may be NULL.  Fills last_safe, max_key,
  * count_below, count_safe of d_result. */
-int  sl_lyap_finalize(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values,
+SL_API int  sl_lyap_finalize(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values,
                       const uint64_t* d_init_bits, const uint64_t* d_prev_bits,
                       sl_key key_star, sl_key key_keep, uint64_t* d_safe_bits,
                       sl_sweep_result* d_result);
@@ -211,12 +219,12 @@ int  sl_lyap_finalize(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_value
  * `byte` (7 = most significant) of the vbits (which = 0) or of the index (which = 1, only cells
  * with vbits == prefix) among keys whose higher bytes equal `prefix`'s.  d_hist[256] is ADDED to
  * (zero it first).  Gives the k-th order statistic that lyapunov.py:590-595 reads through argsort. */
-int  sl_select_pass(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values, int which,
+SL_API int  sl_select_pass(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values, int which,
                     int byte, uint64_t prefix, uint64_t vbits_equal, uint64_t* d_hist);
 
 /* Bit mask <-> byte mask helpers for the bool[N] safe_set of the reference (lyapunov.py:187). */
-int  sl_bits_to_bytes(sl_ctx* ctx, int64_t n, const uint64_t* d_bits, uint8_t* d_bytes);
-int  sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uint64_t* d_bits);
+SL_API int  sl_bits_to_bytes(sl_ctx* ctx, int64_t n, const uint64_t* d_bits, uint8_t* d_bytes);
+SL_API int  sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uint64_t* d_bits);
 
 /* ---- dynamic programming (reinforcement_learning.py:65-140, 213-279) --------------------- */
 /* One Jacobi sweep over vertices [lo,hi) of the value grid (auxiliary grid #0):
@@ -228,7 +236,7 @@ int  sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uint64_t* 
  *   sum_i (v_new_i - V(x_i))^2} with V(x_i) interpolated as in reinforcement_learning.py:130-133;
  *   the sum (the Bellman error of the current policy, :116-133) is produced for n_actions == 0
  *   only and is 0 otherwise. */
-int  sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const double* h_actions,
+SL_API int  sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const double* h_actions,
                       double* d_v_new, int32_t* d_argmax, double* d_q, double* d_stats);
 
 /* ---- evaluation at arbitrary points (Function.__call__, lyapunov.py:265-288, 324-376) ------ */
@@ -239,7 +247,7 @@ enum sl_eval_what {
     SL_EVAL_DECREASE = 4,   /*   [v_decrease_bound, threshold, mean f[d], error[d]] (both selectors) */
     SL_EVAL_LV = 5          /* L_v(x)                  out [n][lv_cols]            */
 };
-int  sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_points /* [n][d] */,
+SL_API int  sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_points /* [n][d] */,
                     double* d_out);
 
 /* ---- multi-GPU collectives directly on RCCL ----------------------------- *
@@ -255,25 +263,25 @@ int  sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_points /* 
  *     (reinforcement_learning.py:135-140); sl_allreduce_max_f64: its residual;
  *   sl_allreduce_sum_u64: the radix-select histograms of sl_select_pass.                        */
 #define SL_COMM_ID_BYTES 128
-int  sl_comm_unique_id(unsigned char* id_out /* [SL_COMM_ID_BYTES] */);
-int  sl_comm_init(sl_ctx* ctx, const unsigned char* id /* [SL_COMM_ID_BYTES] */, int rank, int world);
-int  sl_comm_destroy(sl_ctx* ctx);
-int  sl_allreduce_result(sl_ctx* ctx, sl_sweep_result* d_result);
-int  sl_allgather(sl_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank);
-int  sl_allreduce_sum_u64(sl_ctx* ctx, uint64_t* d_values, int64_t count);
-int  sl_allreduce_max_f64(sl_ctx* ctx, double* d_values, int64_t count);
+SL_API int  sl_comm_unique_id(unsigned char* id_out /* [SL_COMM_ID_BYTES] */);
+SL_API int  sl_comm_init(sl_ctx* ctx, const unsigned char* id /* [SL_COMM_ID_BYTES] */, int rank, int world);
+SL_API int  sl_comm_destroy(sl_ctx* ctx);
+SL_API int  sl_allreduce_result(sl_ctx* ctx, sl_sweep_result* d_result);
+SL_API int  sl_allgather(sl_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank);
+SL_API int  sl_allreduce_sum_u64(sl_ctx* ctx, uint64_t* d_values, int64_t count);
+SL_API int  sl_allreduce_max_f64(sl_ctx* ctx, double* d_values, int64_t count);
 
 /* ---- diagnostics -------------------------------------------------------------------------- */
 /* D = A(16x4) * B(4x16) through v_mfma_f64_16x16x4_f64 with this library's fragment maps. */
-int  sl_debug_mfma(sl_ctx* ctx, const double* h_a, const double* h_b, double* h_d);
+SL_API int  sl_debug_mfma(sl_ctx* ctx, const double* h_a, const double* h_b, double* h_d);
 /* v_mfma_f64_4x4x4_4b_f64 on per-lane operands (nwaves x 64 values each); mode 0: plain, 1..4:
    cbsz = 2, abid = mode - 1 (not a block broadcast for FP64).  Pins the fragment layout in the
    tests. */
-int  sl_debug_mfma4(sl_ctx* ctx, int nwaves, const double* h_a, const double* h_b,
+SL_API int  sl_debug_mfma4(sl_ctx* ctx, int nwaves, const double* h_a, const double* h_b,
                     const double* h_c, int mode, double* h_d);
 /* Sustained FP64 rate probes: which = 0 MFMA, 1 VALU FMA, 2 both interleaved.
  * h_out[3] = {TFLOP/s, sustained shader clock in MHz, shader cycles per MFMA slot per SIMD}. */
-int  sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_out);
+SL_API int  sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_out);
 
 #ifdef __cplusplus
 }

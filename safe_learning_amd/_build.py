@@ -71,6 +71,7 @@ def build(verbose=False, force=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+             "-fvisibility=hidden",           # exports = the SL_API declarations of include/sl_hip.h
              "-I" + os.path.join(ROOT, "include"), "-I" + csrc]
     flags += os.environ.get("SL_EXTRA_FLAGS", "").split()         # experiments: -DSL_GP_CFG... etc.
     if verbose:
@@ -101,8 +102,29 @@ def build(verbose=False, force=False):
         failed = failed or proc.returncode != 0
     if failed:
         raise RuntimeError("hipcc failed")
-    _audit_fixed_accumulators(objdir, verbose)
-    _audit_in_place(objdir, verbose)
+    # The 4x4x4 kernels rely on properties of the generated code that only the audits can prove
+    # (inline asm owns accumulator registers).  A toolchain that schedules or names things
+    # differently must not make the package unbuildable: the kernel in question is compiled out
+    # (-DSL_NO_GP4 / -DSL_NO_BELLMAN4: the 16x16x4 kernels take over) and the build warns.
+    import warnings
+    for audit, src, macro in ((_audit_fixed_accumulators, "sl_gp4.hip", "SL_NO_GP4"),
+                              (_audit_in_place, "sl_bellman4.hip", "SL_NO_BELLMAN4")):
+        if os.environ.get("SL_FORCE_AUDIT_FAILURE") == macro:       # exercised by the tests
+            problem = "forced by SL_FORCE_AUDIT_FAILURE"
+        else:
+            try:
+                audit(objdir, verbose)
+                continue
+            except RuntimeError as exc:
+                problem = str(exc)
+        warnings.warn("%s failed its code audit; building without it (-D%s): %s"
+                      % (src, macro, problem), RuntimeWarning)
+        obj = os.path.join(objdir, src + ".o")
+        res = subprocess.run([hipcc] + flags + ["-D" + macro, "-c", os.path.join(csrc, src), "-o", obj],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0:
+            sys.stderr.write(res.stdout)
+            raise RuntimeError("hipcc failed on the fallback build of %s" % src)
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [obj for obj, _ in jobs] + ["-ldl"]
     res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:

@@ -85,6 +85,7 @@ R_FAIL_V, R_FAIL_I, R_LAST_V, R_LAST_I, R_MAX_V, R_MAX_I, R_BELOW, R_SAFE = rang
 
 EXPORTS = [
     "sl_version", "sl_ctx_create", "sl_ctx_destroy", "sl_last_error", "sl_ctx_synchronize",
+    "sl_last_kernel",
     "sl_model_set", "sl_gp_set_head", "sl_gp_append_point", "sl_gp_configure", "sl_tri_set", "sl_tri_set_table",
     "sl_network_set", "sl_values", "sl_lyap_sweep", "sl_lyap_finalize", "sl_select_pass",
     "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_eval_points",
@@ -154,9 +155,11 @@ def load_library():
     lib.sl_debug_mfma4.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int,
                                    c_double_p]
     for name in EXPORTS:
-        if name not in ("sl_last_error",):
+        if name not in ("sl_last_error", "sl_last_kernel"):
             getattr(lib, name).restype = C.c_int
     lib.sl_last_error.restype = C.c_char_p
+    lib.sl_last_kernel.restype = C.c_char_p
+    lib.sl_last_kernel.argtypes = [C.c_void_p]
     _lib = lib
     return lib
 

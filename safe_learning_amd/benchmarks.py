@@ -11,6 +11,7 @@ are BASELINE.json's.
 import numpy as np
 from scipy import signal
 
+from .functions import _cartpole_linearize, _pendulum_linearize
 from .utilities import dlqr
 
 GRAVITY = 9.81
@@ -28,29 +29,6 @@ GP_VARIANTS = {
     'informed': dict(signal_std=0.03, noise_std=0.0005, lengthscale=1.5),
     'tight': dict(signal_std=0.001, noise_std=0.0002, lengthscale=1.0),
 }
-
-
-def _pendulum_linearize(mass, length, friction, dt, norm):
-    inertia = mass * length ** 2
-    A = np.array([[0, 1], [GRAVITY / length, -friction / inertia]])
-    B = np.array([[0], [1 / inertia]])
-    Tx, Tu = np.diag(norm[0]), np.diag(norm[1])
-    A = np.linalg.multi_dot((np.linalg.inv(Tx), A, Tx))
-    B = np.linalg.multi_dot((np.linalg.inv(Tx), B, Tu))
-    sysd = signal.StateSpace(A, B, np.eye(2), np.zeros((2, 1))).to_discrete(dt)
-    return sysd.A, sysd.B
-
-
-def _cartpole_linearize(m, M, L, b, dt, norm):
-    g = GRAVITY
-    A = np.array([[0, 0, 1, 0], [0, 0, 0, 1], [0, g * m / M, 0, -b / (M * L)],
-                  [0, g * (m + M) / (L * M), 0, -b * (m + M) / (m * M * L ** 2)]])
-    B = np.array([0, 0, 1 / M, 1 / (M * L)]).reshape(-1, 1)
-    Tx, Tu = np.diag(norm[0]), np.diag(norm[1])
-    A = np.linalg.multi_dot((np.linalg.inv(Tx), A, Tx))
-    B = np.linalg.multi_dot((np.linalg.inv(Tx), B, Tu))
-    Ad, Bd, _, _, _ = signal.cont2discrete((A, B, 0, 0), dt, method='zoh')
-    return Ad, Bd
 
 
 def _true_dynamics_numpy(case, X):

@@ -813,6 +813,7 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
         if (variant == 4) SL_BP_LAUNCH(4); else SL_BP_LAUNCH(2);
 #undef SL_BP_LAUNCH
         SL_HIP_CHECK(ctx, hipGetLastError());
+        sl_note_kernel(ctx, false, "k_bellman_policy_mfma<d=%d>", variant == 4 ? 4 : 2);
         *done = 1;
         return SL_OK;
     }
@@ -842,6 +843,8 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
 #undef SL_BM_DIMS
 #undef SL_BM_LAUNCH
     SL_HIP_CHECK(ctx, hipGetLastError());
+    sl_note_kernel(ctx, false, "k_bellman_mfma<d=%d, column blocks=%d, heads=%d>", variant == 4 ? 4 : 2,
+                   nheads > 1 ? 1 : ncb_t, nheads);
     *done = 1;
     return SL_OK;
 }
@@ -877,6 +880,7 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
         return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: GP dynamics without heads");
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SL_HIP_CHECK(ctx, hipMemsetAsync(d_stats, 0, 2 * sizeof(double), ctx->stream));
+    ctx->last_kernel[0] = 0;
     if (hi == lo) return SL_OK;
     size_t lds = 0;
     int amax = 0;
@@ -922,6 +926,7 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
         else if (variant == 1) SL_BELLMAN(AM_, 1, 1);           \
         else SL_BELLMAN(AM_, 0, 0);                             \
     } while (0)
+    sl_note_kernel(ctx, false, "k_bellman<actions<=%d, d=%d>", amax, variant);
     if (amax == 3) SL_BELLMAN_DIMS(3);
     else if (amax == 9) SL_BELLMAN_DIMS(9);
     else if (amax == SL_MAX_ACTIONS) SL_BELLMAN_DIMS(SL_MAX_ACTIONS);

@@ -39,6 +39,15 @@
 //    k_bellman_mfma, one lane per (cell, action group), 28.8 ms (SL_BELLMAN4_SPLIT=0).
 #include "sl_common.h"
 
+#ifdef SL_NO_BELLMAN4
+// Compiled out: the build's in-place audit of the MFMA loop failed on this toolchain
+// (safe_learning_amd/_build.py); the sweeps stay on k_bellman_mfma (sl_bellman.hip).
+int sl_bellman4_launch(sl_ctx*, int64_t, int64_t, int, double*, int32_t*, double*, double*, int* done) {
+    *done = 0;
+    return SL_OK;
+}
+#else
+
 typedef double sl_d2 __attribute__((ext_vector_type(2)));
 typedef unsigned sl_u4 __attribute__((ext_vector_type(4)));
 
@@ -664,6 +673,10 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
 #undef SL_B4_ROWS
 #undef SL_B4_LAUNCH
     SL_HIP_CHECK(ctx, hipGetLastError());
+    sl_note_kernel(ctx, false, split ? "k_bellman4<d=%d, row blocks=%d, quarter=%d> + k_bellman_lookup<%d>"
+                                     : "k_bellman4<d=%d, row blocks=%d, quarter=%d> (fused lookup)",
+                   variant == 4 ? 4 : 2, pk.nrb, (int)pk.quarter, variant == 4 ? 4 : 2);
     *done = 1;
     return SL_OK;
 }
+#endif  // SL_NO_BELLMAN4

@@ -17,6 +17,8 @@
 struct SlGpHeadHost {
     bool set = false;
     int n = 0, n_pad = 0, p = 0, dout = 0, col0 = 0, cfg = 0;
+    double lengthscales[SL_MAX_INPUT_DIM] = {};   // as uploaded: appended points are scaled by the
+                                                  // same division as the packed ones (bit-identical)
     double* d_xs = nullptr;
     double* d_mpack = nullptr;
     double* d_alpha = nullptr;
@@ -53,11 +55,14 @@ struct sl_ctx {
     void* comm = nullptr;              // RCCL communicator (sl_comm.hip), optional
     void* d_comm_records = nullptr;    // [world] gathered sl_sweep_result records
     int comm_rank = 0, comm_world = 1;
+    char last_kernel[160] = "";        // dominant kernel(s) of the last sweep call (sl_last_kernel)
 };
 
 extern thread_local std::string g_sl_last_error;
 
 int sl_fail(sl_ctx* ctx, int code, const char* fmt, ...);
+// name of the kernel a sweep entry point launched (append = true: "a + b" for two-pass sweeps)
+void sl_note_kernel(sl_ctx* ctx, bool append, const char* fmt, ...);
 
 // launchers defined in the other translation units
 int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,

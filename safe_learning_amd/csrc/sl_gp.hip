@@ -434,6 +434,7 @@ extern "C" int sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int
     dv.n = n; dv.n_pad = n_pad; dv.p = p; dv.dout = dout; dv.col0 = col0; dv.nslab2 = nslab2;
     dv.variance = variance;
     for (int q = 0; q < p; ++q) dv.inv_ls[q] = 1.0 / h_lengthscales[q];
+    for (int q = 0; q < p; ++q) ctx->gp_heads[head].lengthscales[q] = h_lengthscales[q];
     dv.xs = hh.d_xs; dv.mpack = hh.d_mpack; dv.alpha = hh.d_alpha;
     return SL_OK;
 }
@@ -481,7 +482,7 @@ extern "C" int sl_gp_append_point(sl_ctx* ctx, int head, const double* h_x, cons
     }
     std::vector<double> stage((size_t)(n + 1 + hh.p + hh.dout));
     for (int c = 0; c <= n; ++c) stage[c] = h_linv_row[c];
-    for (int q = 0; q < hh.p; ++q) stage[n + 1 + q] = h_x[q] * dv.inv_ls[q];
+    for (int q = 0; q < hh.p; ++q) stage[n + 1 + q] = h_x[q] / hh.lengthscales[q];   // as sl_gp_set_head
     for (int dd = 0; dd < hh.dout; ++dd) stage[n + 1 + hh.p + dd] = h_alpha_new[dd];
     double* d_stage = reinterpret_cast<double*>(ctx->d_scratch);
     SL_HIP_CHECK(ctx, hipMemcpy(d_stage, stage.data(), need, hipMemcpyHostToDevice));
@@ -571,6 +572,8 @@ static int launch_cfg(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t 
                        ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits, ctx->d_partials, d_dbg,
                        xs_doubles, alpha_doubles, d_points, nb);
     SL_HIP_CHECK(ctx, hipGetLastError());
+    sl_note_kernel(ctx, false, "k_gp_sweep<W=%d, R=%d, CB=%d, general=%d, d=%d, m=%d, xs_global=%d>", W, R,
+                   CB, (int)GENERAL, DT, MT, (int)XSG);
     return SL_OK;
 }
 

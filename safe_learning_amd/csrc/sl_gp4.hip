@@ -32,6 +32,17 @@
 // Measured in tools/gp_lab.hip (1 Mi cells, 1024 points): 16x16x4 structure 49.5 TFLOP/s, this
 // one 60.5; profiles/r02_summary.md has the ablation.
 #include "sl_common.h"
+#include "sl_gp4_clobbers.h"
+
+#ifdef SL_NO_GP4
+// Compiled out: the build's audit of the fixed-accumulator code failed on this toolchain
+// (safe_learning_amd/_build.py); every GP sweep then runs k_gp_sweep (sl_gp.hip).
+bool sl_gp4_supports(const SlDevModel&) { return false; }
+int sl_gp4_sweep_launch(sl_ctx* ctx, const SlDevModel&, int64_t, int64_t, const uint64_t*, const double*,
+                        uint64_t*, int*, double*, const double*) {
+    return sl_fail(ctx, SL_ERR_UNSUPPORTED, "k_gp_sweep4 is compiled out of this build");
+}
+#else
 
 typedef double sl_d2 __attribute__((ext_vector_type(2)));
 typedef unsigned sl_u4 __attribute__((ext_vector_type(4)));
@@ -110,31 +121,109 @@ __device__ __forceinline__ void acc_squares(double (&ssr)[CB][4]) {
 
 // eight MFMAs of one (row block, rotation): both slabs of the pair for the four cell blocks.  The
 // operands come straight from loads (the compiler's s_waitcnt precedes the statement); an
-// accumulate chain on one register needs no wait states.
-template <int RI, int ROT>
+// accumulate chain on one register needs no wait states.  PART selects a contiguous piece of that
+// sequence (0: all eight, 1/2: first / second four, 3..6: the pairs) so that operand loads can be
+// issued BETWEEN the MFMAs of a group.
+template <int RI, int ROT, int PART = 0>
 __device__ __forceinline__ void group(const sl_d2& av, const BFrag& b) {
     constexpr int N0 = 2 * ((RI * CB + 0) * 4 + ROT), N1 = 2 * ((RI * CB + 1) * 4 + ROT);
     constexpr int N2 = 2 * ((RI * CB + 2) * 4 + ROT), N3 = 2 * ((RI * CB + 3) * 4 + ROT);
-    asm volatile(
-        "v_mfma_f64_4x4x4_4b_f64 a[%c10:%c11], %0, %2, a[%c10:%c11]\n\t"
-        "v_mfma_f64_4x4x4_4b_f64 a[%c12:%c13], %0, %4, a[%c12:%c13]\n\t"
-        "v_mfma_f64_4x4x4_4b_f64 a[%c14:%c15], %0, %6, a[%c14:%c15]\n\t"
-        "v_mfma_f64_4x4x4_4b_f64 a[%c16:%c17], %0, %8, a[%c16:%c17]\n\t"
-        "v_mfma_f64_4x4x4_4b_f64 a[%c10:%c11], %1, %3, a[%c10:%c11]\n\t"
-        "v_mfma_f64_4x4x4_4b_f64 a[%c12:%c13], %1, %5, a[%c12:%c13]\n\t"
-        "v_mfma_f64_4x4x4_4b_f64 a[%c14:%c15], %1, %7, a[%c14:%c15]\n\t"
-        "v_mfma_f64_4x4x4_4b_f64 a[%c16:%c17], %1, %9, a[%c16:%c17]"
-        :
-        : "v"(av.x), "v"(av.y), "v"(b.v[0].x), "v"(b.v[0].y), "v"(b.v[1].x), "v"(b.v[1].y),
-          "v"(b.v[2].x), "v"(b.v[2].y), "v"(b.v[3].x), "v"(b.v[3].y), "i"(N0), "i"(N0 + 1),
-          "i"(N1), "i"(N1 + 1), "i"(N2), "i"(N2 + 1), "i"(N3), "i"(N3 + 1)
-        : SL_ALL_AGPRS);
+#define SL_GP4_X01 "v_mfma_f64_4x4x4_4b_f64 a[%c10:%c11], %0, %2, a[%c10:%c11]\n\t" \
+                   "v_mfma_f64_4x4x4_4b_f64 a[%c12:%c13], %0, %4, a[%c12:%c13]"
+#define SL_GP4_X23 "v_mfma_f64_4x4x4_4b_f64 a[%c14:%c15], %0, %6, a[%c14:%c15]\n\t" \
+                   "v_mfma_f64_4x4x4_4b_f64 a[%c16:%c17], %0, %8, a[%c16:%c17]"
+#define SL_GP4_Y01 "v_mfma_f64_4x4x4_4b_f64 a[%c10:%c11], %1, %3, a[%c10:%c11]\n\t" \
+                   "v_mfma_f64_4x4x4_4b_f64 a[%c12:%c13], %1, %5, a[%c12:%c13]"
+#define SL_GP4_Y23 "v_mfma_f64_4x4x4_4b_f64 a[%c14:%c15], %1, %7, a[%c14:%c15]\n\t" \
+                   "v_mfma_f64_4x4x4_4b_f64 a[%c16:%c17], %1, %9, a[%c16:%c17]"
+// The clobber list names the accumulators the piece writes (a[32 RI + 16 h ...], sl_gp4_clobbers.h).
+// Listing the whole file on every statement made the compiler separate adjacent statements with
+// an s_nop (write-after-write on the clobbered registers) - one bubble per group.  That the
+// compiler keeps no value of its own in ANY accumulator register is established by the kernel's
+// opening statement, -amdgpu-spill-vgpr-to-agpr=0 and the build-time audit of the generated code.
+#define SL_GP4_ASM_CL(TEXT, ...)                                                                   \
+    asm volatile(TEXT                                                                              \
+                 :                                                                                 \
+                 : "v"(av.x), "v"(av.y), "v"(b.v[0].x), "v"(b.v[0].y), "v"(b.v[1].x), "v"(b.v[1].y), \
+                   "v"(b.v[2].x), "v"(b.v[2].y), "v"(b.v[3].x), "v"(b.v[3].y), "i"(N0), "i"(N0 + 1), \
+                   "i"(N1), "i"(N1 + 1), "i"(N2), "i"(N2 + 1), "i"(N3), "i"(N3 + 1)                 \
+                 : __VA_ARGS__)
+#ifdef SL_GP4_CLOBBER_ALL
+#define SL_GP4_ASM_R(TEXT, R_, H_) SL_GP4_ASM_CL(TEXT, SL_ALL_AGPRS)
+#else
+#define SL_GP4_ASM_R(TEXT, R_, H_) SL_GP4_ASM_CL(TEXT, SL_GP4_CL_##R_##H_)
+#endif
+#define SL_GP4_ASM_H(TEXT, H_)                                     \
+    do {                                                           \
+        if constexpr (RI == 0) SL_GP4_ASM_R(TEXT, 0, H_);          \
+        else if constexpr (RI == 1) SL_GP4_ASM_R(TEXT, 1, H_);     \
+        else if constexpr (RI == 2) SL_GP4_ASM_R(TEXT, 2, H_);     \
+        else if constexpr (RI == 3) SL_GP4_ASM_R(TEXT, 3, H_);     \
+        else if constexpr (RI == 4) SL_GP4_ASM_R(TEXT, 4, H_);     \
+        else if constexpr (RI == 5) SL_GP4_ASM_R(TEXT, 5, H_);     \
+        else if constexpr (RI == 6) SL_GP4_ASM_R(TEXT, 6, H_);     \
+        else SL_GP4_ASM_R(TEXT, 7, H_);                            \
+    } while (0)
+    // H_: empty = both cell-block pairs, _0 / _1 = cell blocks 0-1 / 2-3
+    if constexpr (PART == 0) SL_GP4_ASM_H(SL_GP4_X01 "\n\t" SL_GP4_X23 "\n\t" SL_GP4_Y01 "\n\t" SL_GP4_Y23, );
+    else if constexpr (PART == 1) SL_GP4_ASM_H(SL_GP4_X01 "\n\t" SL_GP4_X23, );
+    else if constexpr (PART == 2) SL_GP4_ASM_H(SL_GP4_Y01 "\n\t" SL_GP4_Y23, );
+    else if constexpr (PART == 3) SL_GP4_ASM_H(SL_GP4_X01, _0);
+    else if constexpr (PART == 4) SL_GP4_ASM_H(SL_GP4_X23, _1);
+    else if constexpr (PART == 5) SL_GP4_ASM_H(SL_GP4_Y01, _0);
+    else SL_GP4_ASM_H(SL_GP4_Y23, _1);
+#undef SL_GP4_ASM_H
+#undef SL_GP4_ASM_R
+#undef SL_GP4_ASM_CL
+#undef SL_GP4_X01
+#undef SL_GP4_X23
+#undef SL_GP4_Y01
+#undef SL_GP4_Y23
 }
-template <int R0, int ROT, int RI = R0>
-__device__ __forceinline__ void mfmas(const AFrag& a, const BFrag& b) {
+// One rotation of a slab pair against the row blocks r >= R0, operand loads INSIDE the MFMA
+// stream: with one wavefront per SIMD every instruction issued between two groups is a bubble of
+// the matrix pipe (four ds_read_b128 in a row: 20-30 cycles per 130-cycle group), issued between
+// the MFMAs of a group it disappears in the 16-cycle shadow of the previous MFMA.  The first
+// group of the rotation carries the four k_x fragment reads of the NEXT rotation (two after each of
+// its first two MFMA pairs: at least four MFMAs old when the next rotation starts, also when the
+// rotation is a single group); group r carries the buffer load of A fragment r of the slab pair
+// two ahead in the rotation (r - R0) & 3, so every fragment is requested once per slab pair.
+// sched_barrier pins the placement (the scheduler would otherwise gather the loads in front of
+// the group); it always follows a load - directly behind an asm statement it costs an s_nop.
+template <int R0, int ROT, bool LOADA, int RI = R0>
+__device__ __forceinline__ void rotation(const AFrag& a, const BFrag& b, BFrag& bn, const double* kxn,
+                                         AFrag& an, __amdgpu_buffer_rsrc_t rsrc,
+                                         const int (&rowoff)[R], int s2n, int lane) {
     if constexpr (RI < R) {
-        group<RI, ROT>(a.v[RI], b);
-        mfmas<R0, ROT, RI + 1>(a, b);
+        constexpr bool LA = LOADA && ((RI - R0) & 3) == ROT;
+        if constexpr (RI == R0) {
+            group<RI, ROT, 3>(a.v[RI], b);
+            bn.v[0] = *reinterpret_cast<const sl_d2*>(kxn);
+            bn.v[1] = *reinterpret_cast<const sl_d2*>(kxn + 128);
+            __builtin_amdgcn_sched_barrier(0);
+            group<RI, ROT, 4>(a.v[RI], b);
+            bn.v[2] = *reinterpret_cast<const sl_d2*>(kxn + 256);
+            bn.v[3] = *reinterpret_cast<const sl_d2*>(kxn + 384);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LA) {
+                group<RI, ROT, 5>(a.v[RI], b);
+                an.v[RI] = __builtin_bit_cast(
+                    sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[RI] + s2n * 1024, 0));
+                __builtin_amdgcn_sched_barrier(0);
+                group<RI, ROT, 6>(a.v[RI], b);
+            } else {
+                group<RI, ROT, 2>(a.v[RI], b);
+            }
+        } else if constexpr (LA) {
+            group<RI, ROT, 1>(a.v[RI], b);
+            an.v[RI] = __builtin_bit_cast(
+                sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[RI] + s2n * 1024, 0));
+            __builtin_amdgcn_sched_barrier(0);
+            group<RI, ROT, 2>(a.v[RI], b);
+        } else {
+            group<RI, ROT>(a.v[RI], b);
+        }
+        rotation<R0, ROT, LOADA, RI + 1>(a, b, bn, kxn, an, rsrc, rowoff, s2n, lane);
     }
 }
 __device__ __forceinline__ void load_b(BFrag& b, const double* kxs, int off) {
@@ -151,22 +240,20 @@ __device__ __forceinline__ void load_a(AFrag& a, __amdgpu_buffer_rsrc_t rsrc, co
         a.v[r] = __builtin_bit_cast(
             sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[r] + s2abs * 1024, 0));
 }
-// one slab pair: the four rotations, the k_x fragment of the next rotation (or of the next slab
-// pair's first rotation) requested before the MFMAs of the current one
-template <int R0>
-__device__ __forceinline__ void slab_pair(const AFrag& a, BFrag& be, BFrag& bo,
-                                          const double* kxs, const double* kxs_next,
-                                          const int (&boff)[4]) {
-    load_b(bo, kxs, boff[1]);
-    mfmas<R0, 0>(a, be);
-    load_b(be, kxs, boff[2]);
-    mfmas<R0, 1>(a, bo);
-    load_b(bo, kxs, boff[3]);
-    mfmas<R0, 2>(a, be);
-    load_b(be, kxs_next, boff[0]);
-    mfmas<R0, 3>(a, bo);
+// one slab pair: the four rotations; `be` holds the fragments of rotation 0 on entry and those of
+// the next slab pair's rotation 0 on exit; the A fragments of slab pair s2n go to `an` (LOADA)
+template <int R0, bool LOADA>
+__device__ __forceinline__ void slab_pair(const AFrag& a, BFrag& be, BFrag& bo, const double* kxs,
+                                          const double* kxs_next, const int (&boff)[4], AFrag& an,
+                                          __amdgpu_buffer_rsrc_t rsrc, const int (&rowoff)[R], int s2n,
+                                          int lane) {
+    rotation<R0, 0, LOADA>(a, be, bo, kxs + boff[1], an, rsrc, rowoff, s2n, lane);
+    rotation<R0, 1, LOADA>(a, bo, be, kxs + boff[2], an, rsrc, rowoff, s2n, lane);
+    rotation<R0, 2, LOADA>(a, be, bo, kxs + boff[3], an, rsrc, rowoff, s2n, lane);
+    rotation<R0, 3, LOADA>(a, bo, be, kxs_next + boff[0], an, rsrc, rowoff, s2n, lane);
 }
-// one chunk of 64 training points against the row blocks r >= R0
+// one chunk of 64 training points against the row blocks r >= R0: A fragments two slab pairs
+// ahead in three register sets
 template <int R0>
 __device__ __forceinline__ void chunk(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
                                       const int (&rowoff)[R], int ch, int lane, const int (&boff)[4]) {
@@ -177,15 +264,12 @@ __device__ __forceinline__ void chunk(__amdgpu_buffer_rsrc_t rsrc, const double*
     load_b(be, kxb, boff[0]);
     for (int s2 = 0; s2 < 6; s2 += 3) {
         const double* k0 = kxb + s2 * KXS2;
-        load_a<R0>(a2, rsrc, rowoff, 8 * ch + s2 + 2, lane);
-        slab_pair<R0>(a0, be, bo, k0, k0 + KXS2, boff);
-        load_a<R0>(a0, rsrc, rowoff, 8 * ch + s2 + 3, lane);
-        slab_pair<R0>(a1, be, bo, k0 + KXS2, k0 + 2 * KXS2, boff);
-        load_a<R0>(a1, rsrc, rowoff, 8 * ch + s2 + 4, lane);
-        slab_pair<R0>(a2, be, bo, k0 + 2 * KXS2, k0 + 3 * KXS2, boff);
+        slab_pair<R0, true>(a0, be, bo, k0, k0 + KXS2, boff, a2, rsrc, rowoff, 8 * ch + s2 + 2, lane);
+        slab_pair<R0, true>(a1, be, bo, k0 + KXS2, k0 + 2 * KXS2, boff, a0, rsrc, rowoff, 8 * ch + s2 + 3, lane);
+        slab_pair<R0, true>(a2, be, bo, k0 + 2 * KXS2, k0 + 3 * KXS2, boff, a1, rsrc, rowoff, 8 * ch + s2 + 4, lane);
     }
-    slab_pair<R0>(a0, be, bo, kxb + 6 * KXS2, kxb + 7 * KXS2, boff);
-    slab_pair<R0>(a1, be, bo, kxb + 7 * KXS2, kxb + 7 * KXS2, boff);
+    slab_pair<R0, false>(a0, be, bo, kxb + 6 * KXS2, kxb + 7 * KXS2, boff, a2, rsrc, rowoff, 0, lane);
+    slab_pair<R0, false>(a1, be, bo, kxb + 7 * KXS2, kxb + 7 * KXS2, boff, a2, rsrc, rowoff, 0, lane);
 }
 // q = chunk index relative to the panel's diagonal band.  Row block r of a wavefront has its
 // diagonal in chunk r of the band: blocks r >= q are active (the diagonal block's fragments are
@@ -203,6 +287,35 @@ __device__ __forceinline__ void chunk_any(__amdgpu_buffer_rsrc_t rsrc, const dou
         case 7: chunk<7>(rsrc, kxb, rowoff, ch, lane, boff); break;
         default: chunk<0>(rsrc, kxb, rowoff, ch, lane, boff); break;
     }
+}
+
+// exp of two arguments (sl_exp_nonpos twice), the two dependent FMA chains written alternately: a
+// single wavefront per SIMD has nobody else to fill the latency of a 13-deep chain
+__device__ __forceinline__ void exp_pair(double x1, double x2, double& e1, double& e2) {
+    x1 = x1 < -800.0 ? -800.0 : x1;
+    x2 = x2 < -800.0 ? -800.0 : x2;
+    const double k1 = rint(x1 * 1.4426950408889634), k2 = rint(x2 * 1.4426950408889634);
+    double r1 = fma(k1, -6.93147180369123816490e-01, x1), r2 = fma(k2, -6.93147180369123816490e-01, x2);
+    r1 = fma(k1, -1.90821492927058770002e-10, r1);
+    r2 = fma(k2, -1.90821492927058770002e-10, r2);
+    double q1 = 1.6059043836821613e-10, q2 = 1.6059043836821613e-10;
+#define SL_EXP_STEP(C) q1 = fma(q1, r1, C); q2 = fma(q2, r2, C)
+    SL_EXP_STEP(2.08767569878681e-09);
+    SL_EXP_STEP(2.505210838544172e-08);
+    SL_EXP_STEP(2.755731922398589e-07);
+    SL_EXP_STEP(2.7557319223985893e-06);
+    SL_EXP_STEP(2.48015873015873e-05);
+    SL_EXP_STEP(1.984126984126984e-04);
+    SL_EXP_STEP(1.3888888888888889e-03);
+    SL_EXP_STEP(8.333333333333333e-03);
+    SL_EXP_STEP(4.1666666666666664e-02);
+    SL_EXP_STEP(1.6666666666666666e-01);
+    SL_EXP_STEP(0.5);
+    SL_EXP_STEP(1.0);
+    SL_EXP_STEP(1.0);
+#undef SL_EXP_STEP
+    e1 = ldexp(q1, (int)k1);
+    e2 = ldexp(q2, (int)k2);
 }
 
 // a wave-uniform double held in scalar registers
@@ -264,7 +377,6 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             const SlGpHeadDev& hd = gp.head[h];
             const int n_pad = hd.n_pad, dout = hd.dout;
             const double variance = hd.variance;
-            const double* __restrict__ alphap = alpha_doubles > 0 ? alpha_l : hd.alpha;
             const double* __restrict__ xs_glob = hd.xs;
             __amdgpu_buffer_rsrc_t rsrc =
                 __builtin_amdgcn_make_buffer_rsrc((void*)hd.mpack, 0, 0x7fffffff, 0x27000);
@@ -295,8 +407,21 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             // row starts a new one): bit c of `runs` = cell c starts a run.  More than four runs
             // (curved policies, explicit points): one exponential per (point, cell) instead.
             unsigned runs = 1u;
+            bool wide = false;
             {
                 bool bend = false;
+                if (lcol >= 1) {                    // |step|^2 of the scaled input between neighbours
+                    double st2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < SL_P; ++q) {
+                        if (q < p) {
+                            const double st = cin[(16 * wave + lcol) * SL_P + q] -
+                                              cin[(16 * wave + lcol - 1) * SL_P + q];
+                            st2 = fma(st, st, st2);
+                        }
+                    }
+                    wide = !(st2 <= 1.0);           // also NaN
+                }
                 if (lcol >= 2) {
 #pragma unroll
                     for (int q = 0; q < SL_P; ++q) {
@@ -317,7 +442,13 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                 }
             }
             runs = (unsigned)__builtin_amdgcn_readfirstlane((int)runs);
-            const bool direct = __builtin_popcount(runs) > 4;
+            // The recurrence forms e_0 = s^2 exp(-z/2) and rho_0 = exp(b - a^2/2) separately: with
+            // steps longer than a lengthscale (a^2 > 1) e_0 can underflow for a training point
+            // that a later cell of the run comes close to, so such tiles take one exponential
+            // per (point, cell) like curved inputs do.  With a^2 <= 1 a point whose e_0 underflows
+            // stays > 20 lengthscales away from all 16 cells (true value < 1e-100), and the
+            // exponent of rho is capped (b > 700 implies e_0 = 0 exactly: 0 * finite, not 0 * inf).
+            const bool direct = __builtin_popcount(runs) > 4 || (__ballot(wide) & 0xffffull) != 0ull;
             // constants of the first run (the only one for most tiles) in scalar registers
             double x0[SL_P], dlt[SL_P], a2 = 0.0;
 #pragma unroll
@@ -351,8 +482,9 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                             bj = fma(dq, dlt[q], bj);
                         }
                     }
-                    double e = variance * sl_exp_nonpos(-0.5 * z);
-                    double rho = sl_exp_nonpos(bj - 0.5 * a2);
+                    double e, rho;
+                    exp_pair(-0.5 * z, fmin(bj - 0.5 * a2, 700.0), e, rho);
+                    e = variance * e;
                     // slot (c + wswz) & 15 with wswz 0 or 4: two bases, immediate offsets
                     double* w_lo = kxw + 2 * wswz;               // cells 0..11
                     double* w_hi = w_lo - 8 * wswz;              // cells 12..15 wrap for wswz = 4
@@ -382,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                             }
                         }
                         double e = variance * sl_exp_nonpos(-0.5 * z);
-                        double rho = sl_exp_nonpos(bj - 0.5 * a2r);
+                        double rho = sl_exp_nonpos(fmin(bj - 0.5 * a2r, 700.0));
                         const double qr = sl_exp_nonpos(-a2r);
                         for (int c = c0; c < c1; ++c) {
                             kxw[2 * ((c + wswz) & 15)] = e;
@@ -410,27 +542,43 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             // rotation-0 k_x fragment of cell block `wave`.  Lane (k, blk, low) ends up with the
             // mean of output dd = k at cell 4 blk + low.  (As FP64-VALU work in the (k, cell)
             // lane mapping this cost 8 % of the sweep.)
-            auto mean_pass = [&](int ch, int buf) {
+            auto mean_pass = [&](int ch, int buf, const double* __restrict__ alpha_src) {
                 const double* kxr = kx_l + buf * KXBUF + wave * 128 + own;
                 // rows dd >= dout of A are zero: every lane loads a valid column, then selects
                 const bool row = low < dout;
-                const double* ap = alphap + (64 * ch + lk) * dout + (row ? low : 0);
+                const double* ap = alpha_src + (64 * ch + lk) * dout + (row ? low : 0);
+                // all operands first (8 fragment reads, 16 alpha' entries: one round trip instead
+                // of eight dependent ones), then the sixteen MFMAs back to back
+                sl_d2 kx[8];
+                double a0[8], a1[8];
 #pragma unroll
                 for (int s2 = 0; s2 < 8; ++s2) {
-                    const sl_d2 kx = *reinterpret_cast<const sl_d2*>(kxr + s2 * KXS2);
+                    kx[s2] = *reinterpret_cast<const sl_d2*>(kxr + s2 * KXS2);
                     const double t0 = ap[(8 * s2) * dout], t1 = ap[(8 * s2 + 4) * dout];
-                    const double a0 = row ? t0 : 0.0, a1 = row ? t1 : 0.0;
-                    // Accumulators in vector registers (the builtin would route them through
-                    // a0:a1).  A dependent FP64 MFMA must not issue right behind its producer
-                    // (no interlock: measured, the second product was lost): four accumulators
-                    // in rotation keep three MFMAs and the loads between a write and its reuse.
-                    // The A operands may come fresh from a VALU select: wait states first.
-                    asm volatile("s_nop 3\n\t"
-                                 "v_mfma_f64_4x4x4_4b_f64 %0, %2, %3, %0\n\t"
-                                 "v_mfma_f64_4x4x4_4b_f64 %1, %4, %5, %1"
-                                 : "+v"(macc[2 * (s2 & 1)]), "+v"(macc[2 * (s2 & 1) + 1])
-                                 : "v"(a0), "v"(kx.x), "v"(a1), "v"(kx.y));
+                    a0[s2] = row ? t0 : 0.0;
+                    a1[s2] = row ? t1 : 0.0;
                 }
+                // Accumulators in vector registers (the builtin would route them through a0:a1).
+                // A dependent FP64 MFMA must not issue right behind its producer (no interlock:
+                // measured, the second product was lost): four accumulators in rotation keep
+                // three MFMAs between a write and its reuse.  The A operands come from VALU
+                // selects: wait states first.
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    asm volatile("s_nop 3\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %0, %4, %5, %0\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %1, %6, %7, %1\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %2, %8, %9, %2\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %3, %10, %11, %3\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %0, %12, %13, %0\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %1, %14, %15, %1\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %2, %16, %17, %2\n\t"
+                                 "v_mfma_f64_4x4x4_4b_f64 %3, %18, %19, %3"
+                                 : "+v"(macc[0]), "+v"(macc[1]), "+v"(macc[2]), "+v"(macc[3])
+                                 : "v"(a0[4 * h]), "v"(kx[4 * h].x), "v"(a1[4 * h]), "v"(kx[4 * h].y),
+                                   "v"(a0[4 * h + 1]), "v"(kx[4 * h + 1].x), "v"(a1[4 * h + 1]), "v"(kx[4 * h + 1].y),
+                                   "v"(a0[4 * h + 2]), "v"(kx[4 * h + 2].x), "v"(a1[4 * h + 2]), "v"(kx[4 * h + 2].y),
+                                   "v"(a0[4 * h + 3]), "v"(kx[4 * h + 3].x), "v"(a1[4 * h + 3]), "v"(kx[4 * h + 3].y));
                 // retired before any other reader (a register copy, the final sum)
                 asm volatile("s_nop 15\n\ts_nop 7" : "+v"(macc[0]), "+v"(macc[1]), "+v"(macc[2]), "+v"(macc[3]));
             };
@@ -450,7 +598,12 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                 __syncthreads();
                 for (int ch = 0; ch < nchunks; ++ch) {
                     const int buf = ch & 1;
-                    if (ch >= first_new_chunk && !(skip & 2)) mean_pass(ch, buf);
+                    if (ch >= first_new_chunk && !(skip & 2)) {
+                        // two call sites: the LDS copy of alpha' is read with ds_read (a common
+                        // pointer would make every access a flat load that waits on both counters)
+                        if (alpha_doubles > 0) mean_pass(ch, buf, alpha_l);
+                        else mean_pass(ch, buf, hd.alpha);
+                    }
                     const int q = __builtin_amdgcn_readfirstlane(ch - 8 * pan);
                     if (!(skip & 8)) chunk_any(rsrc, kx_l + buf * KXBUF, rowoff, q, ch, lane, boff);
                     if (ch + 1 < nchunks && !(skip & 1)) generate(ch + 1, buf ^ 1);
@@ -597,6 +750,7 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
                        ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,
                        ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, d_points, skip);
     SL_HIP_CHECK(ctx, hipGetLastError());
+    sl_note_kernel(ctx, false, "k_gp_sweep4<d=%d, m=%d, xs_global=%d>", DT, MT, (int)XSG);
     return SL_OK;
 }
 
@@ -612,9 +766,11 @@ int sl_gp4_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
                : launch4<D_, M_, false>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,    \
                                         nblocks, d_dbg, d_points)
     switch (variant) {
+#ifndef SL_GP4_ONLY_D4                 // (development: compile the 4-D instantiation only)
         case 1: SL_GP4(1, 1);
         case 2: SL_GP4(2, 1);
         case 3: SL_GP4(3, 1);
+#endif
         case 4: SL_GP4(4, 1);
         default: break;
     }
@@ -627,3 +783,4 @@ int sl_gp4_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
 bool sl_gp4_supports(const SlDevModel& model) {
     return !sl_model_is_general(model) && sl_dim_variant_of(model) >= 1;
 }
+#endif  // SL_NO_GP4

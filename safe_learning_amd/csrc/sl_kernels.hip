@@ -14,6 +14,22 @@
 
 thread_local std::string g_sl_last_error;
 
+void sl_note_kernel(sl_ctx* ctx, bool append, const char* fmt, ...) {
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (append && ctx->last_kernel[0]) {
+        const size_t used = strlen(ctx->last_kernel);
+        snprintf(ctx->last_kernel + used, sizeof(ctx->last_kernel) - used, " + %s", buf);
+    } else {
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "%s", buf);
+    }
+}
+
+extern "C" const char* sl_last_kernel(const sl_ctx* ctx) { return ctx ? ctx->last_kernel : ""; }
+
 int sl_fail(sl_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -591,6 +607,7 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
     if (!d_neg_bits || !d_result) return sl_fail(ctx, SL_ERR_INVALID, "sl_lyap_sweep: NULL output");
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     int blocks = 1;
+    ctx->last_kernel[0] = 0;
     if (hi == lo) {
         blocks = 0;
     } else if (ctx->h_model.m.value.kind == SL_V_NETWORK) {
@@ -653,6 +670,8 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
         else SL_LAUNCH_DET(G, D_, M_, 0);                                                      \
     } while (0)
         SL_DISPATCH_DIMS(sl_dim_variant(ctx->h_model), sl_model_is_general(ctx->h_model), SL_CALL);
+        sl_note_kernel(ctx, false, "k_det_sweep<general=%d, d=%d, dynamics=%d, pow2=%d>",
+                       (int)sl_model_is_general(ctx->h_model), sl_dim_variant(ctx->h_model), dyn, (int)pow2);
 #undef SL_CALL
 #undef SL_LAUNCH_DET
         SL_HIP_CHECK(ctx, hipGetLastError());

@@ -606,8 +606,10 @@ SL_HD int sl_tri_sum_code(int d, const double* z) {
 }
 
 inline void sl_tri_regions_compute(SlTri& t);
-// (a few milliseconds of host time in 4-D: the last result is kept and reused while the unit-cell
-// simplices stay the same, e.g. across the uploads of a value-iteration loop)
+// (host time: the exact first-level table is milliseconds; the sampled second level of a 4-D table
+// walks 2e6 points x up to 24 simplices, 0.5-1 s on the first 4-D sl_tri_set of a thread.  The
+// result is kept per dimension and reused while the unit-cell simplices stay the same, e.g. across
+// the uploads of a value-iteration loop)
 inline void sl_tri_regions(SlTri& t) {
     // one remembered result per dimension: programs that alternate between, say, a 4-D value
     // table and a 2-D one do not pay the 4-D sampling again
@@ -874,7 +876,10 @@ SL_HD void sl_tri_locate_fast(const SlTri& t, const double* x, SlTriLoc<(DT > 0 
                 SL_TRI_TRY(s1);
             }
         }
-        full = !(nc > 0 && best_min > 0.0);
+        // the margin keeps points within rounding of a shared face on the full walk: there a
+        // simplex outside the candidate list may have a (tiny) larger computed minimum, and the
+        // shortcut must never change which simplex the arg-max rule picks
+        full = !(nc > 0 && best_min > 1e-12);
     }
     if (full) {
         best = 0;

@@ -281,5 +281,7 @@ int sl_nn_check_launch(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_in
     else if (variant == 4) SL_NN_DISPATCH(SL_NN_CHECK_D4, SL_NN_CHECK_ARGS);
     else SL_NN_DISPATCH(SL_NN_CHECK_D0, SL_NN_CHECK_ARGS);
     SL_HIP_CHECK(ctx, hipGetLastError());
+    sl_note_kernel(ctx, d_records != nullptr, "k_nn_check_mfma<layers=%d, d=%d>", ctx->h_net.nlayers,
+                   variant);
     return SL_OK;
 }

@@ -48,6 +48,59 @@ def shard_range(n, rank=None, world=None, align=64):
     return bounds[rank], bounds[rank + 1]
 
 
+# ---- collective timing (bench.py: ``config.collective_ms``) ---------------------------------
+_timing = None          # None, or a list of (start, stop) events / float seconds per collective
+
+
+def start_timing():
+    """Record the duration of every collective issued through this module from now on."""
+    global _timing
+    _timing = []
+
+
+def stop_timing():
+    """-> milliseconds spent inside collectives since ``start_timing`` (device events on the
+    stream the collective was issued on for GPU tensors - the span includes waiting for the
+    slowest rank to arrive -, host clock for CPU tensors).  Synchronises the device."""
+    global _timing
+    spans, _timing = _timing or [], None
+    total = 0.0
+    for span in spans:
+        if isinstance(span, tuple):
+            span[1].synchronize()
+            total += span[0].elapsed_time(span[1])
+        else:
+            total += 1e3 * span
+    return total
+
+
+class _timed(object):
+    """Context manager around one collective on ``tensor``'s device."""
+
+    def __init__(self, tensor):
+        self.cuda = _timing is not None and getattr(tensor, 'is_cuda', False)
+        self.host = _timing is not None and not self.cuda
+
+    def __enter__(self):
+        if self.cuda:
+            import torch
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.stop = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        elif self.host:
+            import time
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if self.cuda:
+            self.stop.record()
+            _timing.append((self.start, self.stop))
+        elif self.host:
+            import time
+            _timing.append(time.perf_counter() - self.t0)
+        return False
+
+
 def gather_words(tensor):
     """Every rank's copy of a small packed int64 record as ONE host array ``[world, len]``.
 
@@ -63,7 +116,8 @@ def gather_words(tensor):
     world = dist.get_world_size()
     flat = tensor.detach().reshape(-1).contiguous()
     out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
-    dist.all_gather_into_tensor(out, flat)
+    with _timed(flat):
+        dist.all_gather_into_tensor(out, flat)
     return out.cpu().numpy().reshape(world, -1)
 
 
@@ -76,26 +130,59 @@ def allreduce_sum_(tensor):
     """In-place SUM all-reduce of an integer / float tensor."""
     if is_distributed():
         import torch.distributed as dist
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+        with _timed(tensor):
+            dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor
 
 
 def allreduce_max_(tensor):
     if is_distributed():
         import torch.distributed as dist
-        dist.all_reduce(tensor, op=dist.ReduceOp.MAX)
+        with _timed(tensor):
+            dist.all_reduce(tensor, op=dist.ReduceOp.MAX)
     return tensor
 
 
-def allgather_concat(tensor, sizes):
-    """Concatenate per-rank 1-D tensors of (possibly different) lengths ``sizes``."""
+def allgather_equal(buffer, total=None, out=None):
+    """ONE ``all_gather_into_tensor`` of equally sized per-rank buffers into a pre-sized tensor
+    (``out`` is reused when given); returns the first ``total`` elements.
+
+    Contiguous shards (``shard_bounds``) are all ``per`` elements long except the last non-empty
+    one, so gathering the shards padded to ``per`` and cutting the result at ``total`` IS the
+    concatenation: no per-rank list, no ``torch.cat``, no extra copy of the gathered data."""
+    import torch
+    flat = buffer.reshape(-1)
+    if not is_distributed():
+        return flat if total is None else flat[:total]
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    if out is None or out.numel() != world * flat.numel() or out.dtype != flat.dtype \
+            or out.device != flat.device:
+        out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
+    with _timed(flat):
+        dist.all_gather_into_tensor(out, flat.contiguous())
+    return out if total is None else out[:total]
+
+
+def allgather_concat(tensor, sizes, out=None):
+    """Concatenate per-rank 1-D tensors of lengths ``sizes`` (the same list on every rank).
+
+    Sizes of contiguous shards (``longest`` on the leading ranks, one shorter shard, then empty
+    ones) take one ``all_gather_into_tensor`` and a slice; any other pattern is compacted after
+    the same single collective."""
     if not is_distributed():
         return tensor
     import torch
-    import torch.distributed as dist
     longest = max(sizes)
-    padded = torch.zeros(longest, dtype=tensor.dtype, device=tensor.device)
-    padded[:tensor.numel()] = tensor
-    out = [torch.empty_like(padded) for _ in sizes]
-    dist.all_gather(out, padded)
-    return torch.cat([o[:s] for o, s in zip(out, sizes)])
+    if longest == 0:
+        return tensor
+    if tensor.numel() == longest:
+        padded = tensor.reshape(-1)
+    else:
+        padded = torch.zeros(longest, dtype=tensor.dtype, device=tensor.device)
+        padded[:tensor.numel()] = tensor.reshape(-1)
+    full = allgather_equal(padded, out=out)
+    short = [r for r, s in enumerate(sizes) if s < longest]
+    if all(s == 0 for r, s in enumerate(sizes) if short and r > short[0]):
+        return full[:sum(sizes)]
+    return torch.cat([full[r * longest:r * longest + s] for r, s in enumerate(sizes)])

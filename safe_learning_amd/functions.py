@@ -19,6 +19,7 @@ from itertools import product as _cartesian
 
 import numpy as np
 import scipy.linalg
+import scipy.signal
 from scipy import spatial
 
 import itertools
@@ -560,6 +561,33 @@ def _normalization(normalization):
     return norm, [v ** -1 for v in norm]
 
 
+def _pendulum_linearize(mass, length, friction, dt, norm, gravity=9.81):
+    """Discretised linearisation of the pendulum about the upright position
+    (``examples/utilities.py:207-240``)."""
+    inertia = mass * length ** 2
+    A = np.array([[0, 1], [gravity / length, -friction / inertia]])
+    B = np.array([[0], [1 / inertia]])
+    Tx, Tu = np.diag(norm[0]), np.diag(norm[1])
+    A = np.linalg.multi_dot((np.linalg.inv(Tx), A, Tx))
+    B = np.linalg.multi_dot((np.linalg.inv(Tx), B, Tu))
+    sysd = scipy.signal.StateSpace(A, B, np.eye(2), np.zeros((2, 1))).to_discrete(dt)
+    return sysd.A, sysd.B
+
+
+def _cartpole_linearize(m, M, L, b, dt, norm, gravity=9.81):
+    """Zero-order-hold discretisation of the linearised cart-pole
+    (``examples/utilities.py:352-385``)."""
+    g = gravity
+    A = np.array([[0, 0, 1, 0], [0, 0, 0, 1], [0, g * m / M, 0, -b / (M * L)],
+                  [0, g * (m + M) / (L * M), 0, -b * (m + M) / (m * M * L ** 2)]])
+    B = np.array([0, 0, 1 / M, 1 / (M * L)]).reshape(-1, 1)
+    Tx, Tu = np.diag(norm[0]), np.diag(norm[1])
+    A = np.linalg.multi_dot((np.linalg.inv(Tx), A, Tx))
+    B = np.linalg.multi_dot((np.linalg.inv(Tx), B, Tu))
+    Ad, Bd, _, _, _ = scipy.signal.cont2discrete((A, B, 0, 0), dt, method='zoh')
+    return Ad, Bd
+
+
 class InvertedPendulum(DeterministicFunction):
     """Pendulum with 10 explicit-Euler sub-steps (``examples/utilities.py:144-289``)."""
 
@@ -579,9 +607,9 @@ class InvertedPendulum(DeterministicFunction):
         """``(A, B)`` of the discretised linearisation about the upright rest position, in
         normalised coordinates when a normalisation is set (same result as
         ``examples/utilities.py:207-240``)."""
-        from .benchmarks import _pendulum_linearize
         norm = self.normalization if self.normalization is not None else [np.ones(2), np.ones(1)]
-        return _pendulum_linearize(self.mass, self.length, self.friction, self.dt, norm)
+        return _pendulum_linearize(self.mass, self.length, self.friction, self.dt, norm,
+                                   gravity=self.gravity)
 
     def _write_dynamics(self, desc):
         desc.kind = _hip.DYN_PENDULUM
@@ -610,10 +638,9 @@ class CartPole(DeterministicFunction):
         """``(A, B)`` of the zero-order-hold discretisation of the linearised cart-pole, in
         normalised coordinates when a normalisation is set (same result as
         ``examples/utilities.py:352-385``)."""
-        from .benchmarks import _cartpole_linearize
         norm = self.normalization if self.normalization is not None else [np.ones(4), np.ones(1)]
         return _cartpole_linearize(self.pendulum_mass, self.cart_mass, self.length,
-                                   self.rot_friction, self.dt, norm)
+                                   self.rot_friction, self.dt, norm, gravity=self.gravity)
 
     def _write_dynamics(self, desc):
         m, M, L, b, g = (self.pendulum_mass, self.cart_mass, self.length, self.rot_friction,

@@ -89,19 +89,26 @@ class Lyapunov(object):
         self._builder = ModelBuilder(self._ctx, discretization)
         n = discretization.nindex
         self._rank, self._world = dist_utils.rank_and_world()
+        # collectives run with more than one rank (or SL_FORCE_COLLECTIVES=1: the same call
+        # sequence at world size 1, to exercise RCCL on a one-GPU box)
+        self._collective = dist_utils.is_distributed()
         self._bounds = dist_utils.shard_bounds(n, self._world)
         self._lo, self._hi = self._bounds[self._rank], self._bounds[self._rank + 1]
         dev = self._ctx.torch_device
         count = self._hi - self._lo
         self._nwords = (count + 63) // 64
-        self._d_values = torch.empty(max(count, 1), dtype=torch.float64, device=dev)
-        self._d_init = torch.zeros(max(self._nwords, 1), dtype=torch.int64, device=dev)
-        self._d_neg = torch.zeros(max(self._nwords, 1), dtype=torch.int64, device=dev)
-        self._d_safe = torch.zeros(max(self._nwords, 1), dtype=torch.int64, device=dev)
+        # every rank's buffers have the capacity of a full shard (``per`` cells, a multiple of 64),
+        # so that the gathers are ONE all_gather_into_tensor of equal pieces without a pad copy
+        per = max(self._bounds[1] - self._bounds[0], 1)
+        cap, wcap = (per, -(-per // 64)) if self._collective else (max(count, 1), max(self._nwords, 1))
+        self._d_values = torch.zeros(cap, dtype=torch.float64, device=dev)
+        self._d_init = torch.zeros(wcap, dtype=torch.int64, device=dev)
+        self._d_neg = torch.zeros(wcap, dtype=torch.int64, device=dev)
+        self._d_safe = torch.zeros(wcap, dtype=torch.int64, device=dev)
         self._d_result = torch.zeros(_hip.RESULT_WORDS, dtype=torch.int64, device=dev)
         self._d_hist = torch.zeros(256, dtype=torch.int64, device=dev)
         self._values_host = None
-        self._d_values_full = None      # all shards, gathered by update_values when world > 1
+        self._d_values_full = None      # all shards of V: gathered on demand (gather_values)
         self._d_safe_full = None        # all shards' mask words, gathered by update_safe_set
         self._init_version = None
         self._init_object = None
@@ -192,18 +199,36 @@ class Lyapunov(object):
 
     @property
     def values(self):
-        """V at every grid point, ``float64[nindex]`` (``lyapunov.py:305-322``).  A local read on
-        every rank: ``update_values`` (collective) has already gathered the shards on the device;
-        the copy to the host happens on first access."""
+        """V at every grid point, ``float64[nindex]`` (``lyapunov.py:305-322``).
+
+        With more than one rank every rank keeps only its shard of V on the device (the sweep
+        needs nothing else); the first read after ``update_values`` gathers the shards and is
+        therefore COLLECTIVE: read it on every rank (or call :meth:`gather_values` on every
+        rank first), never on one rank only."""
         if self._values_host is None:
-            full = self._d_values_full
-            if full is None:
-                full = self._d_values[:self._hi - self._lo]
-            self._values_host = full.cpu().numpy()
+            self._values_host = self.gather_values().cpu().numpy()
         return self._values_host
 
-    def _word_sizes(self):
-        return [-(-(self._bounds[r + 1] - self._bounds[r]) // 64) for r in range(self._world)]
+    def gather_values(self):
+        """All shards of V as one device tensor ``float64[nindex]`` (collective when the grid is
+        sharded; cached until the next ``update_values``).  One ``all_gather_into_tensor`` into a
+        pre-sized buffer - 2.1 GB per GPU at 128^4, which is why it is not done eagerly."""
+        if not self._collective:
+            return self._d_values[:self._hi - self._lo]
+        if self._d_values_full is None:
+            self._d_values_full = dist_utils.allgather_equal(self._d_values,
+                                                             self.discretization.nindex)
+        return self._d_values_full
+
+    def _safe_full_buffer(self):
+        """Pre-sized receive buffer of the mask gather (world x words per shard), reused."""
+        import torch
+        need = self._world * self._d_safe.numel()
+        buf = getattr(self, '_d_safe_gather', None)
+        if buf is None or buf.numel() != need:
+            buf = self._d_safe_gather = torch.empty(need, dtype=torch.int64,
+                                                    device=self._ctx.torch_device)
+        return buf
 
     @property
     def safe_set(self):
@@ -326,10 +351,7 @@ class Lyapunov(object):
         self._upload_model()
         self._ctx.values(self._lo, self._hi, self._d_values)
         self._values_host = None
-        if self._world > 1:
-            sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
-            self._d_values_full = dist_utils.allgather_concat(
-                self._d_values[:self._hi - self._lo], sizes)
+        self._d_values_full = None       # shards only; ``values`` / ``gather_values`` gather lazily
 
     def update_safe_set(self, can_shrink=True, max_refinement=1, safety_factor=1.,
                         parallel_iterations=1):
@@ -351,11 +373,11 @@ class Lyapunov(object):
         self.safe_count = stats['safe']       # cells in the safe set (all ranks), no mask copy
         self._safe_host_valid = False
         self._safe_dev_valid = True
-        if self._world > 1:
+        if self._collective:
             # shards start at multiples of 64 cells, so their mask words concatenate (4 MB per
             # rank at 128^4 over 8 GPUs); afterwards ``safe_set`` is a local read on every rank
-            sizes = self._word_sizes()
-            self._d_safe_full = dist_utils.allgather_concat(self._d_safe[:sizes[self._rank]], sizes)
+            self._d_safe_full = dist_utils.allgather_equal(
+                self._d_safe, -(-self.discretization.nindex // 64), out=self._safe_full_buffer())
 
 
     def _threshold_base_device(self):
@@ -422,7 +444,7 @@ class Lyapunov(object):
         d_bytes = torch.empty(max(-(-count // 8) * 8, 8), dtype=torch.uint8, device=dev)
         self._ctx.bits_to_bytes(count, self._d_neg, d_bytes)
         negative = dist_utils.allgather_concat(d_bytes[:count], sizes).to(torch.bool)
-        values = self._d_values_full if self._d_values_full is not None else self._d_values[:count]
+        values = self.gather_values()
         base = self._threshold_base_device()
         init_mask = torch.zeros(n, dtype=torch.bool, device=dev)
         if self._initial_safe_set is not None:
@@ -488,7 +510,7 @@ class Lyapunov(object):
         self._ctx.bytes_to_bits(n, safe.to(torch.uint8).contiguous(), full_bits)
         nwords = (count + 63) // 64
         self._d_safe[:nwords] = full_bits[lo // 64:lo // 64 + nwords]
-        self._d_safe_full = full_bits if self._world > 1 else None
+        self._d_safe_full = full_bits if self._collective else None
         self._safe_host_valid = False
         self._safe_dev_valid = True
 

@@ -57,7 +57,9 @@ class PolicyIteration(object):
         import torch
         ctx, lo, hi = self._ctx, self._lo, self._hi
         dev = ctx.torch_device
-        count = max(hi - lo, 1)
+        # a full shard's capacity on every rank: the gathers are one all_gather_into_tensor of
+        # equal pieces (distributed.allgather_equal), no pad copy
+        count = max(self._bounds[1] - self._bounds[0] if dist_utils.is_distributed() else hi - lo, 1)
         self._upload(policy)
         v_new = torch.empty(count, dtype=torch.float64, device=dev)
         stats = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -75,11 +77,14 @@ class PolicyIteration(object):
         if events is not None:
             stop.record()
             events.append((start, stop))
-        return v_new[:hi - lo], argmax, q, stats
+        return v_new, argmax, q, stats
 
-    def _gather(self, shard):
-        sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
-        return dist_utils.allgather_concat(shard, sizes)
+    def _gather(self, shard, width=1):
+        """All ranks' shards (``width`` entries per vertex) as one device tensor."""
+        n = self.discretization.nindex
+        if not dist_utils.is_distributed():
+            return shard.reshape(-1)[:(self._hi - self._lo) * width]
+        return dist_utils.allgather_equal(shard, n * width)
 
     def future_values(self, states=None, policy=None, actions=None, lyapunov=None,
                       lagrange_multiplier=1.):
@@ -167,7 +172,7 @@ class PolicyIteration(object):
         ranks (4 bytes per vertex), never the ``[N, A]`` table of action values."""
         import torch
         if best is None:
-            best = self._gather(argmax[:self._hi - self._lo]).to(torch.int64)
+            best = self._gather(argmax).to(torch.int64)
         table = torch.from_numpy(action_space).to(best.device)[best]
         if not isinstance(self.policy, Triangulation):
             self.policy = Triangulation(self.discretization)
@@ -200,9 +205,7 @@ class PolicyIteration(object):
         _, argmax, q, _ = self._sweep(self.policy, action_space, want_q=want_q)
         q_all = None
         if want_q:
-            sizes = [(self._bounds[r + 1] - self._bounds[r]) * n_act for r in range(self._world)]
-            flat = q.reshape(-1)[:(self._hi - self._lo) * n_act]
-            q_all = dist_utils.allgather_concat(flat, sizes).reshape(-1, n_act)
+            q_all = self._gather(q, n_act).reshape(-1, n_act)
         best = None
         if constraint is not None:
             # actions whose safety slack is negative at a vertex are ruled out there (:272-275);
