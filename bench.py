@@ -331,6 +331,10 @@ def run_rank(args, rank, world, local_rank, backend):
         mask = obj.safe_set
         end_to_end_ms = 1e3 * (time.perf_counter() - t1)
         assert int(mask.sum()) == extra["safe_cells"]
+        if args.config in ("C2", "C4") and extra["safe_cells"] <= extra["initial_cells"] \
+                and not os.environ.get("SL_GP4_SKIP"):          # (attribution runs skip phases)
+            raise SystemExit("bench.py: degenerate workload - the level set did not grow (%d safe "
+                             "cells, %d initial)" % (extra["safe_cells"], extra["initial_cells"]))
     else:
         end_to_end_ms = None
         # sweeps to convergence at max|dV| <= 1e-6 max|V| (SURVEY 8d metric iii), continuing from
@@ -383,6 +387,7 @@ def run_rank(args, rank, world, local_rank, backend):
         if end_to_end_ms is not None:
             out["end_to_end_ms"] = end_to_end_ms      # incl. bits->bytes and the bool[N] D2H
         out["roofline"] = roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world)
+        out["roofline"]["kernel"] = obj._ctx.last_kernel()    # what the library launched (sl_last_kernel)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, case)
         print(json.dumps(out), flush=True)
@@ -408,8 +413,7 @@ def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
         achieved = flops * cells_per_launch / (avg_ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                "kernel": ("k_bellman4" if case["num_points"][-1] % 64 == 0 and not case.get("stack")
-                           and os.environ.get("SL_BELLMAN4", "1") != "0" else "k_bellman_mfma"),
+                "kernel": None,            # filled in from sl_last_kernel by the caller
                 "kernel_ms": avg_ms, "flops_per_vertex": flops}
     if is_gp:
         n, p = len(dyn["X"]), d + case["m"]
@@ -425,15 +429,9 @@ def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
                     "FETCH_SIZE x2 + WRITE_SIZE of this command, separate passes; not this run)"
         except (OSError, ValueError, KeyError):
             pass
-        # sl_gp4_supports(): the fixed-register 4x4x4 kernel takes closed-form policies with a
-        # quadratic V and more than 256 training points; everything else runs k_gp_sweep
-        plain = case.get("V", {"kind": "quadratic"})["kind"] == "quadratic" and \
-            "policy_table" not in case
-        kernel = "k_gp_sweep4" if (n > 256 and plain and os.environ.get("SL_GP_CFG", "2") == "2") \
-            else "k_gp_sweep"
         return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                "traffic_source": source, "kernel": kernel, "kernel_ms": avg_ms,
+                "traffic_source": source, "kernel": None, "kernel_ms": avg_ms,
                 "flops_per_check": fpc,
                 "note": "compute-bound: 8.25 algorithmic HBM bytes per check (SURVEY 8d)"}
     # analytic dynamics: SURVEY 8d's 10 B per check (V read 8 + init mask + mask write, states
@@ -441,7 +439,7 @@ def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
     bytes_per_check = 10.0
     achieved = bytes_per_check * cells_per_launch / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": "k_det_sweep",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": None,
             "kernel_ms": avg_ms, "bytes_per_check": bytes_per_check,
             "note": "the bit-exactness contract (one rounding per multiply and per add, no FMA; "
                     "~165 FP64 operations per cart-pole cell) puts the FP64-VALU floor above the "
@@ -493,7 +491,7 @@ def main():
         return
     world = max(1, args.gpus)
     if world == 1:
-        run_rank(args, 0, 1, 0, None)
+        run_rank(args, 0, 1, 0, args.backend)
         return
     # self-launch: one process per GPU (never fork a process that may hold a HIP context)
     import torch.multiprocessing as mp

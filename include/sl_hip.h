@@ -282,6 +282,10 @@ SL_API int  sl_debug_mfma4(sl_ctx* ctx, int nwaves, const double* h_a, const dou
 /* Sustained FP64 rate probes: which = 0 MFMA, 1 VALU FMA, 2 both interleaved.
  * h_out[3] = {TFLOP/s, sustained shader clock in MHz, shader cycles per MFMA slot per SIMD}. */
 SL_API int  sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_out);
+/* The scaled training inputs X / lengthscales of an uploaded GP head as the kernels read them,
+ * h_xs [p][n] (row q = input dimension q): lets the tests compare an incrementally extended head
+ * (sl_gp_append_point) with a fresh upload bit for bit. */
+SL_API int  sl_debug_gp_inputs(sl_ctx* ctx, int head, double* h_xs);
 
 #ifdef __cplusplus
 }

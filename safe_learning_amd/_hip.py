@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libslhip.so")
+# SL_LIB_PATH: another build of the same library (kernel A/B runs, tools/build_variant.sh)
+LIB_PATH = os.environ.get("SL_LIB_PATH") or os.path.join(HERE, "libslhip.so")
 
 MAX_STATE_DIM = 6
 MAX_ACTION_DIM = 2
@@ -91,7 +92,7 @@ EXPORTS = [
     "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_eval_points",
     "sl_comm_unique_id", "sl_comm_init", "sl_comm_destroy", "sl_allreduce_result", "sl_allgather",
     "sl_allreduce_sum_u64", "sl_allreduce_max_f64",
-    "sl_debug_mfma", "sl_debug_mfma4", "sl_debug_fp64_rate",
+    "sl_debug_mfma", "sl_debug_mfma4", "sl_debug_fp64_rate", "sl_debug_gp_inputs",
 ]
 
 _lib = None
@@ -152,6 +153,7 @@ def load_library():
     lib.sl_allreduce_max_f64.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.sl_debug_mfma.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
     lib.sl_debug_fp64_rate.argtypes = [C.c_void_p, C.c_int, C.c_int, c_double_p]
+    lib.sl_debug_gp_inputs.argtypes = [C.c_void_p, C.c_int, c_double_p]
     lib.sl_debug_mfma4.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int,
                                    c_double_p]
     for name in EXPORTS:
@@ -237,6 +239,13 @@ class Context(object):
         self.check(rc, "sl_gp_append_point")
         return True
 
+    def gp_inputs(self, head, n, p):
+        """Scaled training inputs of an uploaded head as the kernels read them, ``[p, n]``."""
+        out = np.empty((p, n), dtype=np.float64)
+        self.check(self.lib.sl_debug_gp_inputs(self.handle, head, out.ctypes.data_as(c_double_p)),
+                   "sl_debug_gp_inputs")
+        return out
+
     def gp_configure(self, nheads, beta):
         self.check(self.lib.sl_gp_configure(self.handle, nheads, float(beta)), "sl_gp_configure")
 
@@ -307,6 +316,11 @@ class Context(object):
 
     def synchronize(self):
         self.check(self.lib.sl_ctx_synchronize(self.handle), "sl_ctx_synchronize")
+
+    def last_kernel(self):
+        """Name of the kernel(s) the last sweep of this context launched (``sl_last_kernel``)."""
+        name = self.lib.sl_last_kernel(self.handle)
+        return name.decode() if name else ""
 
     # ---- RCCL collectives of the C ABI (the package itself uses torch.distributed) ---------
     @staticmethod

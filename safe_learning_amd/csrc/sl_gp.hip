@@ -497,6 +497,19 @@ extern "C" int sl_gp_append_point(sl_ctx* ctx, int head, const double* h_x, cons
     return SL_OK;
 }
 
+extern "C" int sl_debug_gp_inputs(sl_ctx* ctx, int head, double* h_xs) {
+    if (!ctx || !h_xs) return sl_fail(ctx, SL_ERR_INVALID, "sl_debug_gp_inputs: NULL argument");
+    if (head < 0 || head >= SL_MAX_GP_HEADS || !ctx->gp_heads[head].set)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_debug_gp_inputs: head %d not set", head);
+    const SlGpHeadHost& hh = ctx->gp_heads[head];
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < hh.p; ++q)
+        SL_HIP_CHECK(ctx, hipMemcpy(h_xs + (size_t)q * hh.n, hh.d_xs + (size_t)q * hh.n_pad,
+                                    sizeof(double) * hh.n, hipMemcpyDeviceToHost));
+    return SL_OK;
+}
+
 extern "C" int sl_gp_configure(sl_ctx* ctx, int nheads, double beta) {
     if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_gp_configure: NULL context");
     if (nheads < 1 || nheads > SL_MAX_GP_HEADS)

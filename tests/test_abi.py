@@ -33,6 +33,18 @@ def test_library_exports_every_declared_symbol():
     assert lib.sl_version() >= 100
 
 
+def test_library_exports_nothing_else():
+    """-fvisibility=hidden + SL_API: the dynamic symbol table defines the C ABI and nothing of the
+    C++ internals (launchers, device stubs, sl_fail)."""
+    import subprocess
+    if not os.path.exists(_hip.LIB_PATH):
+        from safe_learning_amd._build import build
+        build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _hip.LIB_PATH], text=True)
+    defined = sorted(line.split()[-1] for line in out.splitlines() if " T " in line or " t " in line)
+    assert defined == _declared_symbols(), sorted(set(defined) ^ set(_declared_symbols()))
+
+
 def test_struct_layout_matches_header():
     """ctypes mirrors must have the C sizes (compiled check with the host compiler)."""
     import subprocess

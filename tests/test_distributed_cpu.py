@@ -46,6 +46,10 @@ def _scenarios():
     out.append(("first_fails", c, [dict(can_shrink=True)]))
     c = cases.make_case("cartpole", num_points=7, dynamics="analytic", tau_scale=0.0)
     out.append(("cartpole", c, [dict(can_shrink=True), dict(can_shrink=False, extra=50)]))
+    # 150 cells: with 8 ranks the shards are [0,64) [64,128) [128,150) and five EMPTY tail shards
+    # that start at the unaligned index 150 - the shape of a 128^4-like split with spare ranks
+    c = cases.make_case("1d", num_points=150)
+    out.append(("tail", c, [dict(can_shrink=True), dict(can_shrink=False, extra=20, tau=2.0)]))
     return out
 
 
@@ -80,9 +84,16 @@ def _worker(rank, world, port, results):
             negative = olyap.negative(olyap.discretization.index_to_state(np.arange(n)))
             engine = NumpyShardEngine(lo, hi, olyap.values, negative, init, prev)
             c_max = prefix_rule(engine, n, 100, step["can_shrink"], device)
-            sizes = [b - a for a, b in zip(du.shard_bounds(n, world)[:-1], du.shard_bounds(n, world)[1:])]
+            bounds = du.shard_bounds(n, world)
+            sizes = [b - a for a, b in zip(bounds[:-1], bounds[1:])]
             full = du.allgather_concat(torch.from_numpy(engine.safe.astype(np.uint8)), sizes)
             safe = full.numpy().astype(bool)
+            # the production form: every rank's buffer has the capacity of a full shard, ONE
+            # all_gather_into_tensor into a pre-sized buffer, cut at n (Lyapunov._d_safe & co.)
+            padded = torch.zeros(max(bounds[1] - bounds[0], 1), dtype=torch.uint8)
+            padded[:hi - lo] = torch.from_numpy(engine.safe.astype(np.uint8))
+            if not torch.equal(du.allgather_equal(padded, n), full):
+                failures.append((name, "allgather_equal"))
             olyap.update_safe_set(can_shrink=step["can_shrink"])
             same_c = (c_max == olyap.c_max) or (np.isnan(c_max) and np.isnan(olyap.c_max))
             if not np.array_equal(safe, olyap.safe_set) or not same_c:
@@ -93,7 +104,7 @@ def _worker(rank, world, port, results):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_prefix_rule_gloo(world):
     port = _free_port()
     manager = mp.Manager()
@@ -134,3 +145,39 @@ def test_single_process_matches_oracle_semantics():
             assert c_max == olyap.c_max, name
     finally:
         oracle.config.gp_batch_size = old
+
+
+def _gather_worker(rank, world, port, results):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from safe_learning_amd import distributed as du
+    ok = True
+    # contiguous-shard pattern (equal, one shorter, empty) and an arbitrary pattern
+    for sizes in ([5, 5, 3, 0][:world] if world == 4 else [4] * (world - 1) + [1], [2, 0, 7, 1][:world]):
+        sizes = list(sizes) + [0] * (world - len(sizes))
+        mine = torch.arange(sizes[rank], dtype=torch.float64) + 100.0 * rank
+        full = du.allgather_concat(mine, sizes)
+        want = torch.cat([torch.arange(s, dtype=torch.float64) + 100.0 * r for r, s in enumerate(sizes)])
+        ok = ok and torch.equal(full, want)
+    # a reused receive buffer is really reused
+    buf = torch.empty(world * 3, dtype=torch.int64)
+    out = du.allgather_equal(torch.full((3,), rank, dtype=torch.int64), out=buf)
+    ok = ok and out.data_ptr() == buf.data_ptr() and out.tolist() == [r for r in range(world) for _ in range(3)]
+    # collective timing: spans are recorded and summed
+    du.start_timing()
+    du.allreduce_sum_(torch.ones(4))
+    du.gather_words(torch.arange(8, dtype=torch.int64))
+    ms = du.stop_timing()
+    ok = ok and ms > 0.0 and du._timing is None
+    results[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_tensor_gathers_gloo():
+    port = _free_port()
+    results = mp.Manager().dict()
+    mp.spawn(_gather_worker, args=(4, port, results), nprocs=4, join=True)
+    assert all(results[r] for r in range(4)), dict(results)

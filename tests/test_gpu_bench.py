@@ -13,8 +13,8 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(*flags):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+def _run(*flags, **extra_env):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **extra_env)
     for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(key, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), env=env,
@@ -46,6 +46,32 @@ def test_bench_line_small_and_two_ranks():
     assert two["config"]["safe_cells"] == cfg["safe_cells"]
     assert two["config"]["negative_cells"] == cfg["negative_cells"]
     assert two["config"]["c_max"] == cfg["c_max"]
+
+
+def test_bench_rccl_call_sequence_at_world_one():
+    """The exact collective sequence of the N > 1 path on this one-GPU box: SL_FORCE_COLLECTIVES=1
+    makes bench.py create an `nccl` (= RCCL) process group of one rank and the package issue
+    every gather / reduction of the sharded path as an RCCL call on device tensors
+    (two packed-record gathers + the mask-word gather per update, single-tensor gathers).  The
+    result must equal the plain single-rank run and the line must carry the collective timing."""
+    small = ["--num-points", "24", "--n-gp", "300", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    plain = _run(*small)
+    forced = _run("--backend", "nccl", *small, SL_FORCE_COLLECTIVES="1")
+    cfg, ref = forced["config"], plain["config"]
+    assert cfg["collectives"] == {"backend": "nccl", "world_size": 1, "ranks_share_a_device": False}
+    assert ref["collectives"]["backend"] is None and ref["collective_ms"] == 0.0
+    assert cfg["collective_ms"] > 0.0 and len(cfg["per_rank_collective_ms"]) == 1
+    assert len(cfg["per_rank_ms_per_step"]) == 1 and cfg["per_rank_ms_per_step"][0] > 0
+    for key in ("safe_cells", "negative_cells", "c_max", "initial_cells"):
+        assert cfg[key] == ref[key]
+    assert forced["roofline"]["kernel"].startswith("k_gp_sweep4<")
+    # the Bellman path: table gather + residual reduction over RCCL
+    c5 = ["--config", "C5", "--num-points", "10", "--n-gp", "128", "--steps", "3", "--no-cpu-baseline",
+          "--max-sweeps", "40"]
+    plain5 = _run(*c5)
+    forced5 = _run("--backend", "nccl", *c5, SL_FORCE_COLLECTIVES="1")
+    assert forced5["config"]["relative_residual"] == plain5["config"]["relative_residual"]
+    assert forced5["config"]["collective_ms"] > 0.0
 
 
 def test_bench_under_torch_distributed_run():

@@ -51,8 +51,13 @@ def _worker(rank, world, port, results, backend="gloo"):
         lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
         assert lyap._world == world
         assert world == 1 or name == "tiny" or lyap._hi - lyap._lo < lyap.discretization.nindex
+        # the constructor keeps only the shard of V; the first read of `values` gathers (collective)
+        if lyap._d_values_full is not None:
+            failures.append((name, "V gathered eagerly"))
         if not np.array_equal(lyap.values, olyap.values):
             failures.append((name, "values"))
+        if lyap._d_values_full is None or lyap._d_values_full.numel() != lyap.discretization.nindex:
+            failures.append((name, "gathered V"))
         rng = np.random.default_rng(3)
         for step, shrink in enumerate((True, False, False)):
             if step == 1:

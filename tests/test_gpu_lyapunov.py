@@ -62,12 +62,17 @@ def _check_masks(neg, ref_neg, rec, ref_rec, allowed=2):
     return int(differs.sum()), float(np.min(margin / np.maximum(scale, 1e-300)))
 
 
-def _compare_safe_sets(lyap, olyap, flips):
+def _compare_safe_sets(lyap, olyap, flips, neg=None):
+    """safe_set and c_max against the oracle's sequential prefix rule.  When cells within rounding
+    of the threshold flipped (``flips`` > 0) the oracle's rule is applied to the ENGINE's decrease
+    mask instead of its own - the comparison is made modulo the flipped cells, never skipped."""
     lyap.update_safe_set()
+    if flips and neg is not None:
+        grid = olyap.discretization
+        olyap.negative = lambda states: neg[grid.state_to_index(states)]
     olyap.update_safe_set()
-    if flips == 0:
-        assert_array_equal(lyap.safe_set, olyap.safe_set)
-        assert lyap.c_max == olyap.c_max or (np.isnan(lyap.c_max) and np.isnan(olyap.c_max))
+    assert_array_equal(lyap.safe_set, olyap.safe_set)
+    assert lyap.c_max == olyap.c_max or (np.isnan(lyap.c_max) and np.isnan(olyap.c_max))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -176,7 +181,7 @@ def test_euler_dynamics(sl, name, kw):
     assert_array_equal(values, olyap.values)
     assert_allclose(rec, ref_rec, rtol=1e-11, atol=1e-14)
     flips, _ = _check_masks(neg, ref_neg, rec, ref_rec)
-    _compare_safe_sets(lyap, olyap, flips)
+    _compare_safe_sets(lyap, olyap, flips, neg)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -217,7 +222,7 @@ def test_gp_dynamics(sl, name, kw, cfg, min_growth, monkeypatch):
     assert_allclose(var, ref_var, rtol=1e-6, atol=1e-16)                              # variance
     assert_allclose(rec[:, :2], ref_rec[:, :2], rtol=1e-7, atol=1e-12)
     flips, _ = _check_masks(neg, ref_neg, rec, ref_rec)
-    _compare_safe_sets(lyap, olyap, flips)
+    _compare_safe_sets(lyap, olyap, flips, neg)
     _assert_non_degenerate(case, ref_neg, olyap, min_growth)
     if flips == 0:
         # the level set the engine produced really is larger than the initial set
@@ -738,7 +743,7 @@ def test_state_dependent_lipschitz_dynamics(sl, name, kw):
     x = olyap.discretization.index_to_state(np.arange(0, len(rec), 7))
     assert_allclose(lyap.lipschitz_dynamics(x), olf(x), rtol=0, atol=0)
     assert_allclose(lyap.threshold(x), olyap.threshold(x), rtol=1e-13)
-    _compare_safe_sets(lyap, olyap, flips)
+    _compare_safe_sets(lyap, olyap, flips, neg)
 
 
 @pytest.mark.parametrize("noise_std,cond_min,var_rtol", [
@@ -767,3 +772,47 @@ def test_ill_conditioned_gp(sl, noise_std, cond_min, var_rtol):
     var, ref_var = (rec[:, 2 + d:] / 2.0) ** 2, (ref_rec[:, 2 + d:] / 2.0) ** 2
     assert np.all(ref_var > 0) and ref_var.min() < 1e-6 * dyn["variance"]     # heavy cancellation
     assert_allclose(var, ref_var, rtol=var_rtol, atol=0)
+
+
+def test_short_lengthscale_takes_the_direct_path(sl):
+    """A lengthscale 25x below the cell spacing (scaled step 25, a^2 = 625): the Gaussian
+    recurrence of k_gp_sweep4 would form 0 * inf for training points the run passes close to; the
+    kernel must switch to one exponential per (point, cell) there.  Posterior and mask against the
+    oracle, nothing NaN."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case("cartpole", num_points=12, n_gp=300, tau_scale=0.0,
+                           signal_std=0.03, noise_std=0.0005, lengthscale=2.0 / 11 / 25)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    values, neg, rec = _engine_records(lyap)
+    assert "k_gp_sweep4" in lyap._ctx.last_kernel()
+    ref_rec, ref_neg = _oracle_all(olyap)
+    assert np.isfinite(rec).all()
+    d = case["d"]
+    assert_allclose(rec[:, 2:2 + d], ref_rec[:, 2:2 + d], rtol=RTOL_GP, atol=1e-12)
+    assert_allclose(rec[:, 2 + d:], ref_rec[:, 2 + d:], rtol=1e-7, atol=1e-12)
+    _check_masks(neg, ref_neg, rec, ref_rec)
+    # a lengthscale between the two regimes (scaled step 0.8 < 1: recurrence; 1.6 > 1: direct)
+    for ratio in (0.8, 1.6):
+        case = cases.make_case("cartpole", num_points=12, n_gp=300, tau_scale=0.0,
+                               signal_std=0.03, noise_std=0.0005, lengthscale=2.0 / 11 / ratio)
+        lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+        values, neg, rec = _engine_records(lyap)
+        ref_rec, ref_neg = _oracle_all(olyap)
+        assert_allclose(rec[:, 2:2 + d], ref_rec[:, 2:2 + d], rtol=RTOL_GP, atol=1e-12)
+        assert_allclose(rec[:, 2 + d:], ref_rec[:, 2 + d:], rtol=1e-7, atol=1e-12)
+
+
+def test_last_kernel_names_what_ran(sl, monkeypatch):
+    """sl_last_kernel: the library itself reports which kernel a sweep launched."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    monkeypatch.delenv("SL_GP_CFG", raising=False)
+    lyap = build_lyapunov(cases.make_case("pendulum", num_points=50, dynamics="linear", tau_scale=0.02))
+    assert lyap._ctx.last_kernel() == ""
+    lyap.update_safe_set()
+    assert lyap._ctx.last_kernel().startswith("k_det_sweep<")
+    lyap = build_lyapunov(cases.make_case("cartpole", num_points=8, n_gp=300, tau_scale=0.0))
+    lyap.update_safe_set()
+    assert lyap._ctx.last_kernel().startswith("k_gp_sweep4<d=4")
+    lyap = build_lyapunov(cases.make_case("pendulum", num_points=32, n_gp=100, tau_scale=0.0))
+    lyap.update_safe_set()
+    assert lyap._ctx.last_kernel().startswith("k_gp_sweep<")
