@@ -7,17 +7,22 @@ tree.  ``-ffp-contract=off`` is part of the numerical contract: the per-cell ari
 round exactly like the float64 oracle (one rounding per multiply and per add).
 """
 
+import glob
 import os
 import subprocess
 import sys
+import warnings
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = ["sl_kernels.hip", "sl_gp.hip", "sl_gp4.hip", "sl_bellman.hip", "sl_bellman4.hip", "sl_nn.hip",
-           "sl_comm.hip"]
-# kernels that own accumulator registers through inline asm: (source, kernel symbol prefix,
-# least number of MFMA loops the audit must recognise, accumulator registers the asm owns)
-FIXED_ACCUMULATOR_SOURCES = [("sl_gp4.hip", "_Z11k_gp_sweep4", 8, 256)]
+# translation units: (object stem, source, extra flags).  sl_gp4.hip is compiled once per state
+# dimension (its unrolled MFMA streams make one instantiation a minute of compile time; the four
+# jobs run side by side).
+GP4_FLAGS = ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps=obj"]
+UNITS = [("sl_kernels", "sl_kernels.hip", []), ("sl_gp", "sl_gp.hip", []),
+         ("sl_bellman", "sl_bellman.hip", []), ("sl_bellman4", "sl_bellman4.hip", ["-save-temps=obj"]),
+         ("sl_nn", "sl_nn.hip", []), ("sl_comm", "sl_comm.hip", [])]
+UNITS += [("sl_gp4_d%d" % dim, "sl_gp4.hip", GP4_FLAGS + ["-DSL_GP4_DIM=%d" % dim]) for dim in (1, 2, 3, 4)]
 LIB = os.path.join(HERE, "libslhip.so")
 
 
@@ -28,34 +33,33 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _audit_fixed_accumulators(objdir, verbose):
-    """k_gp_sweep4 and k_bellman4 own accumulator registers through inline asm: prove on the
-    generated code that the compiler never uses one and keeps the MFMA loops free of spill traffic."""
-    import glob
+def _listing(objdir, stem):
+    found = glob.glob(os.path.join(objdir, stem, "*-hip-amdgcn*gfx950*.s"))
+    if not found:
+        raise RuntimeError("device assembly of %s not found in %s" % (stem, objdir))
+    return found[0]
+
+
+def _audit_gp4(objdir, verbose):
+    """k_gp_sweep4 owns the accumulator registers through inline asm: prove on the generated code
+    that the compiler never uses one and keeps the MFMA streams free of spill traffic
+    (tools/audit_gp4.py::audit), for every dimension's translation unit."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_gp4
-    for src, prefix, min_loops, owned in FIXED_ACCUMULATOR_SOURCES:
-        stem = src[:-len(".hip")]
-        listings = [f for f in glob.glob(os.path.join(objdir, stem + "-hip-amdgcn*gfx950*.s"))]
-        if not listings:
-            raise RuntimeError("device assembly of %s not found in %s" % (src, objdir))
-        report, problems = audit_gp4.audit(listings[0], prefix, min_loops, owned)
+    for dim in (1, 2, 3, 4):
+        report, problems = audit_gp4.audit(_listing(objdir, "sl_gp4_d%d" % dim), "_Z11k_gp_sweep4", 8, 256)
         if verbose:
             print("\n".join(report))
         if problems:
-            raise RuntimeError("%s failed its code audit:\n" % src + "\n".join(problems))
+            raise RuntimeError("sl_gp4.hip (d = %d) failed its code audit:\n" % dim + "\n".join(problems))
 
 
-def _audit_in_place(objdir, verbose):
+def _audit_bellman4(objdir, verbose):
     """k_bellman4: accumulators are register values updated by opaque inline-asm MFMAs - see
     tools/audit_gp4.py::audit_in_place."""
-    import glob
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_gp4
-    listings = glob.glob(os.path.join(objdir, "sl_bellman4-hip-amdgcn*gfx950*.s"))
-    if not listings:
-        raise RuntimeError("device assembly of sl_bellman4.hip not found in %s" % objdir)
-    report, problems = audit_gp4.audit_in_place(listings[0])
+    report, problems = audit_gp4.audit_in_place(_listing(objdir, "sl_bellman4"))
     if verbose:
         print("\n".join(report))
     if problems:
@@ -64,8 +68,7 @@ def _audit_in_place(objdir, verbose):
 
 def build(verbose=False, force=False):
     csrc = os.path.join(HERE, "csrc")
-    srcs = [os.path.join(csrc, s) for s in SOURCES if os.path.exists(os.path.join(csrc, s))]
-    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip"))]
     deps.append(os.path.join(ROOT, "include", "sl_hip.h"))
     if not force and not _newer(LIB, deps):
         return LIB
@@ -76,39 +79,37 @@ def build(verbose=False, force=False):
     flags += os.environ.get("SL_EXTRA_FLAGS", "").split()         # experiments: -DSL_GP_CFG... etc.
     if verbose:
         flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
-    # one hipcc per translation unit, all at once (the kernels are heavily templated: ~2-4 min of
-    # compile time in total), then one link
+    # one hipcc per translation unit, all at once, then one link.  Each unit has its own directory
+    # (-save-temps=obj names the listing after the SOURCE file).
     objdir = os.path.join(HERE, "build")
-    os.makedirs(objdir, exist_ok=True)
+
+    def compile_cmd(stem, src, extra):
+        os.makedirs(os.path.join(objdir, stem), exist_ok=True)
+        return [hipcc] + flags + extra + ["-c", os.path.join(csrc, src), "-o",
+                                          os.path.join(objdir, stem, stem + ".o")]
+
     jobs = []
-    for src in srcs:
-        obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        extra = []
-        if os.path.basename(src) in [f[0] for f in FIXED_ACCUMULATOR_SOURCES]:
-            # fixed accumulator registers in inline asm: the compiler must not spill into the
-            # accumulator file; keep the device assembly for the audit below
-            extra = ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps=obj"]
-        if os.path.basename(src) == "sl_bellman4.hip":
-            extra = ["-save-temps=obj"]                  # assembly for _audit_in_place
-        cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
+    for stem, src, extra in UNITS:
+        cmd = compile_cmd(stem, src, extra)
         if verbose:
             print(" ".join(cmd))
-        jobs.append((obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        jobs.append((stem, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
-    for obj, proc in jobs:
+    for stem, proc in jobs:
         out, _ = proc.communicate()
         if verbose or proc.returncode != 0:
             sys.stderr.write(out)
         failed = failed or proc.returncode != 0
     if failed:
         raise RuntimeError("hipcc failed")
+    objects = {stem: os.path.join(objdir, stem, stem + ".o") for stem, _, _ in UNITS}
     # The 4x4x4 kernels rely on properties of the generated code that only the audits can prove
     # (inline asm owns accumulator registers).  A toolchain that schedules or names things
     # differently must not make the package unbuildable: the kernel in question is compiled out
     # (-DSL_NO_GP4 / -DSL_NO_BELLMAN4: the 16x16x4 kernels take over) and the build warns.
-    import warnings
-    for audit, src, macro in ((_audit_fixed_accumulators, "sl_gp4.hip", "SL_NO_GP4"),
-                              (_audit_in_place, "sl_bellman4.hip", "SL_NO_BELLMAN4")):
+    for audit, src, macro, stems in ((_audit_gp4, "sl_gp4.hip", "SL_NO_GP4",
+                                      ["sl_gp4_d%d" % dim for dim in (1, 2, 3, 4)]),
+                                     (_audit_bellman4, "sl_bellman4.hip", "SL_NO_BELLMAN4", ["sl_bellman4"])):
         if os.environ.get("SL_FORCE_AUDIT_FAILURE") == macro:       # exercised by the tests
             problem = "forced by SL_FORCE_AUDIT_FAILURE"
         else:
@@ -119,13 +120,16 @@ def build(verbose=False, force=False):
                 problem = str(exc)
         warnings.warn("%s failed its code audit; building without it (-D%s): %s"
                       % (src, macro, problem), RuntimeWarning)
-        obj = os.path.join(objdir, src + ".o")
-        res = subprocess.run([hipcc] + flags + ["-D" + macro, "-c", os.path.join(csrc, src), "-o", obj],
-                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        for stem in stems:
+            objects.pop(stem)
+        stem = macro.lower()
+        res = subprocess.run(compile_cmd(stem, src, ["-D" + macro]), stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, text=True)
         if res.returncode != 0:
             sys.stderr.write(res.stdout)
             raise RuntimeError("hipcc failed on the fallback build of %s" % src)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [obj for obj, _ in jobs] + ["-ldl"]
+        objects[stem] = os.path.join(objdir, stem, stem + ".o")
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + sorted(objects.values()) + ["-ldl"]
     res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         sys.stderr.write(res.stdout)

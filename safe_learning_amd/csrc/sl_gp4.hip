@@ -61,6 +61,7 @@ constexpr int RB = R * W;                  // row blocks per panel
 // cell for the rotated fragment reads to be conflict free; the shift between the row pairs and
 // the slab-pair skew leave the generation writes (lane = training point, 8 B, one cell per
 // instruction) with 2-way conflicts only.
+constexpr int RUNC = 2 * SL_P + 2;         // per wavefront: x0[SL_P], step[SL_P], a^2, Q (see Fill)
 constexpr int KXS2 = CB * 128 + 4;
 constexpr int KXBUF = 8 * KXS2;
 static_assert(R * CB * 4 * 2 == 256, "the accumulators fill the 256 accumulator registers");
@@ -180,37 +181,174 @@ __device__ __forceinline__ void group(const sl_d2& av, const BFrag& b) {
 #undef SL_GP4_Y01
 #undef SL_GP4_Y23
 }
+// ---- work of the other phases, issued INSIDE the MFMA stream ---------------------------------------
+// One wavefront per SIMD means that everything a wavefront does between two chunks - the posterior
+// mean of the chunk (16 MFMAs behind a round trip of operand loads), the generation of the next
+// k_x chunk (two 20-deep FMA chains, a 16-deep chain of multiplies, LDS writes and their wait),
+// the barrier - leaves the matrix pipe idle: 0.8 us per chunk for ~90 FP64 instructions.  Cut into
+// pieces of two or three instructions and issued between the MFMAs of the chunk in flight, the
+// same work costs its issue slots only: every dependent instruction finds its operand ready (32+
+// cycles between slots).  A piece runs in slot I = ((slab pair * 4 + rotation) * 4 + k) of the
+// chunk, k = position inside the first MFMA group of the rotation (see rotation<>).
+struct NoFill {
+    static constexpr bool has(int) { return false; }
+    template <int I> __device__ __forceinline__ void step() {}
+};
+template <bool MEAN, bool GEN, int P>
+struct Fill {
+    // posterior mean of the chunk in flight: mean[dd][cell] += sum_j alpha'[j][dd] k_x[j][cell] as
+    // 16 MFMAs (A = alpha'^T, rows dd = lane & 3, zero rows beyond dout come from the padded LDS
+    // copy; B = the rotation-0 k_x fragment of this wavefront's own cell block)
+    const double* kxr;          // LDS: this lane's (k, cell) item of the chunk in flight
+    const double* ap;           // LDS: alpha' [point][4], this lane's column of the chunk
+    double* macc;               // [4] accumulators in rotation
+    sl_d2 kx[4];
+    double a0[4], a1[4];
+    // k_x of the NEXT chunk, lane = training point, the wavefront's 16 cells one affine run:
+    // e_{c+1} = e_c rho_c, rho_{c+1} = rho_c Q
+    const double* xs;           // LDS: scaled training inputs, this lane's point, stride n_pad
+    int n_pad;
+    const double* run;          // LDS: x0[SL_P], dlt[SL_P], a2, Q of the run (broadcast reads)
+    double variance;
+    double* w_lo;               // LDS write bases of the next chunk's buffer (cells 0-11 / 12-15)
+    double* w_hi;
+    double xv[P], x0[P], dl[P], a2, qs, z, bj, x1, x2, k1, k2, r1, r2, q1, q2, e, rho;
+
+    static constexpr int G0 = 14;                       // first generation slot
+    static constexpr bool has(int i) {
+        return (MEAN && (i < 4 || i == 5 || (i >= 6 && i < 10) || i == 11)) ||
+               (GEN && i >= G0 && i < G0 + 8 + P + 13 + 16);
+    }
+    template <int H> __device__ __forceinline__ void mean_loads(int j) {
+        kx[j] = *reinterpret_cast<const sl_d2*>(kxr + (4 * H + j) * KXS2);
+        a0[j] = ap[(8 * (4 * H + j)) * 4];
+        a1[j] = ap[(8 * (4 * H + j) + 4) * 4];
+    }
+    __device__ __forceinline__ void mean_mfmas() {
+        // Accumulators in vector registers; a dependent FP64 MFMA must not issue right behind its
+        // producer (no interlock: the second product was lost): four accumulators in rotation
+        // keep three MFMAs between a write and its reuse.  The trailing wait states retire the
+        // results before any other reader (a register copy by the compiler).
+        // (s_nop 1: two wait states between a VALU write - a register copy of an accumulator
+        // by the compiler - and an MFMA that reads the register)
+        asm volatile("s_nop 1\n\t"
+                     "v_mfma_f64_4x4x4_4b_f64 %0, %4, %5, %0\n\t"
+                     "v_mfma_f64_4x4x4_4b_f64 %1, %6, %7, %1\n\t"
+                     "v_mfma_f64_4x4x4_4b_f64 %2, %8, %9, %2\n\t"
+                     "v_mfma_f64_4x4x4_4b_f64 %3, %10, %11, %3\n\t"
+                     "v_mfma_f64_4x4x4_4b_f64 %0, %12, %13, %0\n\t"
+                     "v_mfma_f64_4x4x4_4b_f64 %1, %14, %15, %1\n\t"
+                     "v_mfma_f64_4x4x4_4b_f64 %2, %16, %17, %2\n\t"
+                     "v_mfma_f64_4x4x4_4b_f64 %3, %18, %19, %3\n\t"
+                     "s_nop 7"
+                     : "+v"(macc[0]), "+v"(macc[1]), "+v"(macc[2]), "+v"(macc[3])
+                     : "v"(a0[0]), "v"(kx[0].x), "v"(a1[0]), "v"(kx[0].y), "v"(a0[1]), "v"(kx[1].x),
+                       "v"(a1[1]), "v"(kx[1].y), "v"(a0[2]), "v"(kx[2].x), "v"(a1[2]), "v"(kx[2].y),
+                       "v"(a0[3]), "v"(kx[3].x), "v"(a1[3]), "v"(kx[3].y));
+    }
+    template <int I> __device__ __forceinline__ void step() {
+        if constexpr (MEAN) {
+            if constexpr (I < 4) mean_loads<0>(I);
+            else if constexpr (I == 5) mean_mfmas();
+            else if constexpr (I >= 6 && I < 10) mean_loads<1>(I - 6);
+            else if constexpr (I == 11) mean_mfmas();
+        }
+        if constexpr (GEN && I >= G0) {
+            constexpr int K = I - G0;
+            if constexpr (K == 0) {
+#pragma unroll
+                for (int q = 0; q < P; ++q) xv[q] = xs[q * n_pad];
+            } else if constexpr (K == 1) {
+#pragma unroll
+                for (int q = 0; q < P; ++q) x0[q] = run[q];
+            } else if constexpr (K == 2) {
+#pragma unroll
+                for (int q = 0; q < P; ++q) dl[q] = run[SL_P + q];
+                a2 = run[2 * SL_P];
+                qs = run[2 * SL_P + 1];
+                z = 0.0;
+                bj = 0.0;
+            } else if constexpr (K < 3 + P) {                    // one input dimension per slot
+                const double dq = xv[K - 3] - x0[K - 3];
+                z = fma(dq, dq, z);
+                bj = fma(dq, dl[K - 3], bj);
+            } else if constexpr (K == 3 + P) {                   // exp arguments (sl_exp_nonpos twice,
+                x1 = -0.5 * z;                                   // the two chains side by side)
+                x2 = fmin(bj - 0.5 * a2, 700.0);
+            } else if constexpr (K == 4 + P) {
+                x1 = x1 < -800.0 ? -800.0 : x1;
+                x2 = x2 < -800.0 ? -800.0 : x2;
+            } else if constexpr (K == 5 + P) {
+                k1 = rint(x1 * 1.4426950408889634);
+                k2 = rint(x2 * 1.4426950408889634);
+            } else if constexpr (K == 6 + P) {
+                r1 = fma(k1, -6.93147180369123816490e-01, x1);
+                r2 = fma(k2, -6.93147180369123816490e-01, x2);
+            } else if constexpr (K == 7 + P) {
+                r1 = fma(k1, -1.90821492927058770002e-10, r1);
+                r2 = fma(k2, -1.90821492927058770002e-10, r2);
+                q1 = 1.6059043836821613e-10;
+                q2 = 1.6059043836821613e-10;
+            } else if constexpr (K < 8 + P + 13) {               // the 13 Horner steps
+                constexpr double C[13] = {2.08767569878681e-09, 2.505210838544172e-08,
+                                          2.755731922398589e-07, 2.7557319223985893e-06,
+                                          2.48015873015873e-05, 1.984126984126984e-04,
+                                          1.3888888888888889e-03, 8.333333333333333e-03,
+                                          4.1666666666666664e-02, 1.6666666666666666e-01, 0.5, 1.0, 1.0};
+                q1 = fma(q1, r1, C[K - 8 - P]);
+                q2 = fma(q2, r2, C[K - 8 - P]);
+                if constexpr (K == 8 + P + 12) {
+                    e = variance * ldexp(q1, (int)k1);
+                    rho = ldexp(q2, (int)k2);
+                }
+            } else if constexpr (K < 8 + P + 13 + 16) {          // the 16 cells, one per slot
+                constexpr int c = K - (8 + P + 13);
+                (c < 12 ? w_lo : w_hi)[2 * c] = e;
+                e *= rho;
+                rho *= qs;
+            }
+        }
+    }
+};
+
 // One rotation of a slab pair against the row blocks r >= R0, operand loads INSIDE the MFMA
 // stream: with one wavefront per SIMD every instruction issued between two groups is a bubble of
 // the matrix pipe (four ds_read_b128 in a row: 20-30 cycles per 130-cycle group), issued between
 // the MFMAs of a group it disappears in the 16-cycle shadow of the previous MFMA.  The first
 // group of the rotation carries the four k_x fragment reads of the NEXT rotation (two after each of
 // its first two MFMA pairs: at least four MFMAs old when the next rotation starts, also when the
-// rotation is a single group); group r carries the buffer load of A fragment r of the slab pair
-// two ahead in the rotation (r - R0) & 3, so every fragment is requested once per slab pair.
-// sched_barrier pins the placement (the scheduler would otherwise gather the loads in front of
-// the group); it always follows a load - directly behind an asm statement it costs an s_nop.
-template <int R0, int ROT, bool LOADA, int RI = R0>
+// rotation is a single group) and the filler pieces of slots I0 .. I0 + 3; group r carries the
+// buffer load of A fragment r of the slab pair two ahead in the rotation (r - R0) & 3, so every
+// fragment is requested once per slab pair.  sched_barrier pins the placement (the scheduler
+// would otherwise gather the loads in front of the group).
+template <int R0, int ROT, bool LOADA, int S2, class F, int RI = R0>
 __device__ __forceinline__ void rotation(const AFrag& a, const BFrag& b, BFrag& bn, const double* kxn,
                                          AFrag& an, __amdgpu_buffer_rsrc_t rsrc,
-                                         const int (&rowoff)[R], int s2n, int lane) {
+                                         const int (&rowoff)[R], int s2n, int lane, F& f) {
     if constexpr (RI < R) {
         constexpr bool LA = LOADA && ((RI - R0) & 3) == ROT;
         if constexpr (RI == R0) {
+            constexpr int I0 = (S2 * 4 + ROT) * 4;
             group<RI, ROT, 3>(a.v[RI], b);
             bn.v[0] = *reinterpret_cast<const sl_d2*>(kxn);
             bn.v[1] = *reinterpret_cast<const sl_d2*>(kxn + 128);
+            f.template step<I0>();
             __builtin_amdgcn_sched_barrier(0);
             group<RI, ROT, 4>(a.v[RI], b);
             bn.v[2] = *reinterpret_cast<const sl_d2*>(kxn + 256);
             bn.v[3] = *reinterpret_cast<const sl_d2*>(kxn + 384);
+            f.template step<I0 + 1>();
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (LA) {
+            if constexpr (LA || F::has(I0 + 2) || F::has(I0 + 3)) {
                 group<RI, ROT, 5>(a.v[RI], b);
-                an.v[RI] = __builtin_bit_cast(
-                    sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[RI] + s2n * 1024, 0));
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (LA)
+                    an.v[RI] = __builtin_bit_cast(
+                        sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[RI] + s2n * 1024, 0));
+                f.template step<I0 + 2>();
+                if constexpr (LA || F::has(I0 + 2)) __builtin_amdgcn_sched_barrier(0);
                 group<RI, ROT, 6>(a.v[RI], b);
+                f.template step<I0 + 3>();
+                if constexpr (F::has(I0 + 3)) __builtin_amdgcn_sched_barrier(0);
             } else {
                 group<RI, ROT, 2>(a.v[RI], b);
             }
@@ -223,7 +361,7 @@ __device__ __forceinline__ void rotation(const AFrag& a, const BFrag& b, BFrag& 
         } else {
             group<RI, ROT>(a.v[RI], b);
         }
-        rotation<R0, ROT, LOADA, RI + 1>(a, b, bn, kxn, an, rsrc, rowoff, s2n, lane);
+        rotation<R0, ROT, LOADA, S2, F, RI + 1>(a, b, bn, kxn, an, rsrc, rowoff, s2n, lane, f);
     }
 }
 __device__ __forceinline__ void load_b(BFrag& b, const double* kxs, int off) {
@@ -240,52 +378,55 @@ __device__ __forceinline__ void load_a(AFrag& a, __amdgpu_buffer_rsrc_t rsrc, co
         a.v[r] = __builtin_bit_cast(
             sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[r] + s2abs * 1024, 0));
 }
-// one slab pair: the four rotations; `be` holds the fragments of rotation 0 on entry and those of
-// the next slab pair's rotation 0 on exit; the A fragments of slab pair s2n go to `an` (LOADA)
-template <int R0, bool LOADA>
-__device__ __forceinline__ void slab_pair(const AFrag& a, BFrag& be, BFrag& bo, const double* kxs,
-                                          const double* kxs_next, const int (&boff)[4], AFrag& an,
-                                          __amdgpu_buffer_rsrc_t rsrc, const int (&rowoff)[R], int s2n,
-                                          int lane) {
-    rotation<R0, 0, LOADA>(a, be, bo, kxs + boff[1], an, rsrc, rowoff, s2n, lane);
-    rotation<R0, 1, LOADA>(a, bo, be, kxs + boff[2], an, rsrc, rowoff, s2n, lane);
-    rotation<R0, 2, LOADA>(a, be, bo, kxs + boff[3], an, rsrc, rowoff, s2n, lane);
-    rotation<R0, 3, LOADA>(a, bo, be, kxs_next + boff[0], an, rsrc, rowoff, s2n, lane);
-}
-// one chunk of 64 training points against the row blocks r >= R0: A fragments two slab pairs
-// ahead in three register sets
-template <int R0>
-__device__ __forceinline__ void chunk(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
-                                      const int (&rowoff)[R], int ch, int lane, const int (&boff)[4]) {
-    AFrag a0, a1, a2;
-    BFrag be, bo;
-    load_a<R0>(a0, rsrc, rowoff, 8 * ch, lane);
-    load_a<R0>(a1, rsrc, rowoff, 8 * ch + 1, lane);
-    load_b(be, kxb, boff[0]);
-    for (int s2 = 0; s2 < 6; s2 += 3) {
-        const double* k0 = kxb + s2 * KXS2;
-        slab_pair<R0, true>(a0, be, bo, k0, k0 + KXS2, boff, a2, rsrc, rowoff, 8 * ch + s2 + 2, lane);
-        slab_pair<R0, true>(a1, be, bo, k0 + KXS2, k0 + 2 * KXS2, boff, a0, rsrc, rowoff, 8 * ch + s2 + 3, lane);
-        slab_pair<R0, true>(a2, be, bo, k0 + 2 * KXS2, k0 + 3 * KXS2, boff, a1, rsrc, rowoff, 8 * ch + s2 + 4, lane);
+// the slab pairs S2 .. 7 of a chunk, unrolled (the filler slots are compile-time positions): four
+// rotations each; `be` holds the fragments of rotation 0 on entry and those of the next slab
+// pair's rotation 0 on exit; A fragments two slab pairs ahead in three register sets
+template <int R0, int S2, class F>
+__device__ __forceinline__ void slab_pairs(AFrag (&a)[3], BFrag& be, BFrag& bo, const double* kxb,
+                                           const int (&boff)[4], __amdgpu_buffer_rsrc_t rsrc,
+                                           const int (&rowoff)[R], int ch, int lane, F& f) {
+    if constexpr (S2 < 8) {
+        constexpr bool LOADA = S2 < 6;
+        const double* kxs = kxb + S2 * KXS2;
+        const double* kxs_next = kxb + (S2 < 7 ? S2 + 1 : 7) * KXS2;
+        const AFrag& ac = a[S2 % 3];
+        AFrag& an = a[(S2 + 2) % 3];
+        const int s2n = 8 * ch + S2 + 2;
+        rotation<R0, 0, LOADA, S2, F>(ac, be, bo, kxs + boff[1], an, rsrc, rowoff, s2n, lane, f);
+        rotation<R0, 1, LOADA, S2, F>(ac, bo, be, kxs + boff[2], an, rsrc, rowoff, s2n, lane, f);
+        rotation<R0, 2, LOADA, S2, F>(ac, be, bo, kxs + boff[3], an, rsrc, rowoff, s2n, lane, f);
+        rotation<R0, 3, LOADA, S2, F>(ac, bo, be, kxs_next + boff[0], an, rsrc, rowoff, s2n, lane, f);
+        slab_pairs<R0, S2 + 1, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f);
     }
-    slab_pair<R0, false>(a0, be, bo, kxb + 6 * KXS2, kxb + 7 * KXS2, boff, a2, rsrc, rowoff, 0, lane);
-    slab_pair<R0, false>(a1, be, bo, kxb + 7 * KXS2, kxb + 7 * KXS2, boff, a2, rsrc, rowoff, 0, lane);
+}
+// one chunk of 64 training points against the row blocks r >= R0
+template <int R0, class F>
+__device__ __forceinline__ void chunk(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
+                                      const int (&rowoff)[R], int ch, int lane, const int (&boff)[4],
+                                      F& f) {
+    AFrag a[3];
+    BFrag be, bo;
+    load_a<R0>(a[0], rsrc, rowoff, 8 * ch, lane);
+    load_a<R0>(a[1], rsrc, rowoff, 8 * ch + 1, lane);
+    load_b(be, kxb, boff[0]);
+    slab_pairs<R0, 0, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f);
 }
 // q = chunk index relative to the panel's diagonal band.  Row block r of a wavefront has its
 // diagonal in chunk r of the band: blocks r >= q are active (the diagonal block's fragments are
 // zero above the diagonal), blocks r < q lie above it; q < 0: every block is active.
+template <class F>
 __device__ __forceinline__ void chunk_any(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
                                           const int (&rowoff)[R], int q, int ch, int lane,
-                                          const int (&boff)[4]) {
+                                          const int (&boff)[4], F& f) {
     switch (q) {
-        case 1: chunk<1>(rsrc, kxb, rowoff, ch, lane, boff); break;
-        case 2: chunk<2>(rsrc, kxb, rowoff, ch, lane, boff); break;
-        case 3: chunk<3>(rsrc, kxb, rowoff, ch, lane, boff); break;
-        case 4: chunk<4>(rsrc, kxb, rowoff, ch, lane, boff); break;
-        case 5: chunk<5>(rsrc, kxb, rowoff, ch, lane, boff); break;
-        case 6: chunk<6>(rsrc, kxb, rowoff, ch, lane, boff); break;
-        case 7: chunk<7>(rsrc, kxb, rowoff, ch, lane, boff); break;
-        default: chunk<0>(rsrc, kxb, rowoff, ch, lane, boff); break;
+        case 1: chunk<1, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+        case 2: chunk<2, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+        case 3: chunk<3, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+        case 4: chunk<4, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+        case 5: chunk<5, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+        case 6: chunk<6, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+        case 7: chunk<7, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+        default: chunk<0, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
     }
 }
 
@@ -346,7 +487,8 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
     double* cell_mean = part_ss + W * 4 * C;       // [C][SL_D]
     double* cell_err = cell_mean + C * SL_D;       // [C][SL_D]
     double* cin = cell_err + C * SL_D;             // [C][SL_P] scaled GP inputs of the tile's cells
-    uint64_t* sv = reinterpret_cast<uint64_t*>(cin + C * SL_P);        // [W]
+    double* runc = cin + C * SL_P;                 // [W][RUNC] x0, step, a^2, Q of each wavefront's run
+    uint64_t* sv = reinterpret_cast<uint64_t*>(runc + W * RUNC);       // [W]
     int64_t* si = reinterpret_cast<int64_t*>(sv + W);                  // [W]
 
     const SlDims nd = sl_dims<DT, MT>(M);
@@ -384,8 +526,9 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                 __syncthreads();
                 if (!XSG)
                     for (int k = tid; k < p * n_pad; k += W * 64) xs_l[k] = hd.xs[k];
-                if (alpha_doubles > 0)
-                    for (int k = tid; k < n_pad * dout; k += W * 64) alpha_l[k] = hd.alpha[k];
+                if (alpha_doubles > 0)             // alpha' zero-padded to four columns (Fill)
+                    for (int k = tid; k < n_pad * 4; k += W * 64)
+                        alpha_l[k] = (k & 3) < dout ? hd.alpha[(k >> 2) * dout + (k & 3)] : 0.0;
                 staged_head = h;
             }
             // scaled GP input [x, policy(x)] / lengthscales of the 64 cells (lane = cell of block `wave`)
@@ -461,6 +604,17 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             }
             a2 = uniform(a2);
             const double qstep = uniform(sl_exp_nonpos(-a2));
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < SL_P; ++q) {
+                    runc[wave * RUNC + q] = q < p ? x0[q] : 0.0;
+                    runc[wave * RUNC + SL_P + q] = q < p ? dlt[q] : 0.0;
+                }
+                runc[wave * RUNC + 2 * SL_P] = a2;
+                runc[wave * RUNC + 2 * SL_P + 1] = qstep;
+            }
+            // fast tiles: one affine run per wavefront, operands of the fillers in LDS
+            const bool fast = !XSG && alpha_doubles > 0 && runs == 1u && !direct && !(skip & 11);
 
             double macc[4] = {0.0, 0.0, 0.0, 0.0};   // posterior-mean accumulators (see mean_pass)
 
@@ -542,11 +696,11 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             // rotation-0 k_x fragment of cell block `wave`.  Lane (k, blk, low) ends up with the
             // mean of output dd = k at cell 4 blk + low.  (As FP64-VALU work in the (k, cell)
             // lane mapping this cost 8 % of the sweep.)
-            auto mean_pass = [&](int ch, int buf, const double* __restrict__ alpha_src) {
+            auto mean_pass = [&](int ch, int buf, const double* __restrict__ alpha_src, int stride) {
                 const double* kxr = kx_l + buf * KXBUF + wave * 128 + own;
                 // rows dd >= dout of A are zero: every lane loads a valid column, then selects
                 const bool row = low < dout;
-                const double* ap = alpha_src + (64 * ch + lk) * dout + (row ? low : 0);
+                const double* ap = alpha_src + (64 * ch + lk) * stride + (row ? low : 0);
                 // all operands first (8 fragment reads, 16 alpha' entries: one round trip instead
                 // of eight dependent ones), then the sixteen MFMAs back to back
                 sl_d2 kx[8];
@@ -554,7 +708,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
 #pragma unroll
                 for (int s2 = 0; s2 < 8; ++s2) {
                     kx[s2] = *reinterpret_cast<const sl_d2*>(kxr + s2 * KXS2);
-                    const double t0 = ap[(8 * s2) * dout], t1 = ap[(8 * s2 + 4) * dout];
+                    const double t0 = ap[(8 * s2) * stride], t1 = ap[(8 * s2 + 4) * stride];
                     a0[s2] = row ? t0 : 0.0;
                     a1[s2] = row ? t1 : 0.0;
                 }
@@ -594,19 +748,53 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                 }
                 const int nchunks = (pan + 1) * (RP / 64);
                 const int first_new_chunk = pan * (RP / 64);     // chunks not generated before
-                if (!(skip & 1)) generate(0, 0);
+                // (on fast tiles the last chunk of the previous panel has generated chunk 0)
+                if (!(fast && pan > 0) && !(skip & 1)) generate(0, 0);
                 __syncthreads();
                 for (int ch = 0; ch < nchunks; ++ch) {
                     const int buf = ch & 1;
-                    if (ch >= first_new_chunk && !(skip & 2)) {
-                        // two call sites: the LDS copy of alpha' is read with ds_read (a common
-                        // pointer would make every access a flat load that waits on both counters)
-                        if (alpha_doubles > 0) mean_pass(ch, buf, alpha_l);
-                        else mean_pass(ch, buf, hd.alpha);
-                    }
                     const int q = __builtin_amdgcn_readfirstlane(ch - 8 * pan);
-                    if (!(skip & 8)) chunk_any(rsrc, kx_l + buf * KXBUF, rowoff, q, ch, lane, boff);
-                    if (ch + 1 < nchunks && !(skip & 1)) generate(ch + 1, buf ^ 1);
+                    const double* kxb = kx_l + buf * KXBUF;
+                    if (fast) {
+                        // posterior mean of this chunk and k_x of the next one ride in the MFMA
+                        // stream (Fill).  The last chunk of a panel prepares chunk 0 for the next
+                        // panel (after the last panel: unused, the buffer is free).
+                        constexpr int PT = DT + MT;
+                        const int nxt = ch + 1 < nchunks ? ch + 1 : 0;
+                        double* wnext = kx_l + (buf ^ 1) * KXBUF + wbase + 2 * wswz;
+                        if (ch >= first_new_chunk) {
+                            Fill<true, true, PT> f;
+                            f.kxr = kxb + wave * 128 + own;
+                            f.ap = alpha_l + (64 * ch + lk) * 4 + low;
+                            f.macc = macc;
+                            f.xs = xs_l + 64 * nxt + lane;
+                            f.n_pad = n_pad;
+                            f.run = runc + wave * RUNC;
+                            f.variance = variance;
+                            f.w_lo = wnext;
+                            f.w_hi = wnext - 8 * wswz;
+                            chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, f);
+                        } else {                       // chunks of earlier panels: all row blocks
+                            Fill<false, true, PT> f;
+                            f.xs = xs_l + 64 * nxt + lane;
+                            f.n_pad = n_pad;
+                            f.run = runc + wave * RUNC;
+                            f.variance = variance;
+                            f.w_lo = wnext;
+                            f.w_hi = wnext - 8 * wswz;
+                            chunk<0>(rsrc, kxb, rowoff, ch, lane, boff, f);
+                        }
+                    } else {
+                        if (ch >= first_new_chunk && !(skip & 2)) {
+                            // two call sites: the LDS copy of alpha' is read with ds_read (a common
+                            // pointer would make every access a flat load that waits on both counters)
+                            if (alpha_doubles > 0) mean_pass(ch, buf, alpha_l, 4);
+                            else mean_pass(ch, buf, hd.alpha, dout);
+                        }
+                        NoFill nf;
+                        if (!(skip & 8)) chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, nf);
+                        if (ch + 1 < nchunks && !(skip & 1)) generate(ch + 1, buf ^ 1);
+                    }
                     __syncthreads();
                 }
                 // |a|^2 of this panel's rows.  The rows of a block live in the four lane groups
@@ -697,12 +885,13 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
 // host side
 // =============================================================================================
 static size_t gp4_fixed_lds() {
-    return sizeof(double) * (2 * gp4::KXBUF + gp4::W * 4 * gp4::C + 2 * gp4::C * SL_D + gp4::C * SL_P) +
+    return sizeof(double) * (2 * gp4::KXBUF + gp4::W * 4 * gp4::C + 2 * gp4::C * SL_D + gp4::C * SL_P +
+                             gp4::W * gp4::RUNC) +
            2 * gp4::W * sizeof(uint64_t);
 }
 
 // true when the training inputs of every head fit LDS next to the fixed buffers
-bool sl_gp4_xs_fit(sl_ctx* ctx, int p) {
+static bool sl_gp4_xs_fit(sl_ctx* ctx, int p) {
     int xs_max = 0;
     for (int h = 0; h < ctx->h_gp.nheads; ++h) {
         const int v = p * ctx->gp_heads[h].n_pad;
@@ -725,7 +914,7 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
         if (ctx->gp_heads[h].n_pad % gp4::RP)
             return sl_fail(ctx, SL_ERR_INVALID, "GP head %d: n_pad %d is not a multiple of %d", h,
                            ctx->gp_heads[h].n_pad, gp4::RP);
-        const int v = p * ctx->gp_heads[h].n_pad, a = ctx->gp_heads[h].n_pad * ctx->gp_heads[h].dout;
+        const int v = p * ctx->gp_heads[h].n_pad, a = ctx->gp_heads[h].n_pad * 4;   // alpha' padded to 4 columns
         xs_doubles = v > xs_doubles ? v : xs_doubles;
         alpha_doubles = a > alpha_doubles ? a : alpha_doubles;
     }
@@ -754,24 +943,51 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
     return SL_OK;
 }
 
+// One entry per state dimension.  The build compiles this file once per dimension
+// (-DSL_GP4_DIM=1..4, four hipcc jobs side by side: the unrolled chunks make one instantiation a
+// minute of compile time); without the macro everything lives in one translation unit.
+#define SL_GP4_DIM_ENTRY(D_)                                                                       \
+    int sl_gp4_launch_d##D_(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,          \
+                            const uint64_t* d_init_bits, const double* d_values,                   \
+                            uint64_t* d_neg_bits, int* nblocks, double* d_dbg,                     \
+                            const double* d_points, bool xsg) {                                    \
+        return xsg ? launch4<D_, 1, true>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,   \
+                                          nblocks, d_dbg, d_points)                                \
+                   : launch4<D_, 1, false>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,  \
+                                           nblocks, d_dbg, d_points);                              \
+    }
+#define SL_GP4_DIM_DECL(D_)                                                                        \
+    int sl_gp4_launch_d##D_(sl_ctx*, const SlDevModel&, int64_t, int64_t, const uint64_t*,         \
+                            const double*, uint64_t*, int*, double*, const double*, bool);
+SL_GP4_DIM_DECL(1) SL_GP4_DIM_DECL(2) SL_GP4_DIM_DECL(3) SL_GP4_DIM_DECL(4)
+#if !defined(SL_GP4_DIM) || SL_GP4_DIM == 1
+SL_GP4_DIM_ENTRY(1)
+#endif
+#if !defined(SL_GP4_DIM) || SL_GP4_DIM == 2
+SL_GP4_DIM_ENTRY(2)
+#endif
+#if !defined(SL_GP4_DIM) || SL_GP4_DIM == 3
+SL_GP4_DIM_ENTRY(3)
+#endif
+#if !defined(SL_GP4_DIM) || SL_GP4_DIM == 4
+SL_GP4_DIM_ENTRY(4)
+
 // Fast-path models (closed-form or per-vertex table policy, quadratic V) with panels of 512 rows.
 int sl_gp4_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
                         const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
                         int* nblocks, double* d_dbg, const double* d_points) {
     const int variant = sl_dim_variant_of(model);
     const bool xsg = !sl_gp4_xs_fit(ctx, model.in_dim);
-#define SL_GP4(D_, M_)                                                                            \
-    return xsg ? launch4<D_, M_, true>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,     \
-                                       nblocks, d_dbg, d_points)                                  \
-               : launch4<D_, M_, false>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,    \
-                                        nblocks, d_dbg, d_points)
+#define SL_GP4(D_)                                                                                 \
+    return sl_gp4_launch_d##D_(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,     \
+                               d_dbg, d_points, xsg)
     switch (variant) {
-#ifndef SL_GP4_ONLY_D4                 // (development: compile the 4-D instantiation only)
-        case 1: SL_GP4(1, 1);
-        case 2: SL_GP4(2, 1);
-        case 3: SL_GP4(3, 1);
+#ifndef SL_GP4_ONLY_D4                 // (development: the 4-D instantiation only, one translation unit)
+        case 1: SL_GP4(1);
+        case 2: SL_GP4(2);
+        case 3: SL_GP4(3);
 #endif
-        case 4: SL_GP4(4, 1);
+        case 4: SL_GP4(4);
         default: break;
     }
 #undef SL_GP4
@@ -783,4 +999,5 @@ int sl_gp4_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
 bool sl_gp4_supports(const SlDevModel& model) {
     return !sl_model_is_general(model) && sl_dim_variant_of(model) >= 1;
 }
+#endif  // SL_GP4_DIM: host dispatch
 #endif  // SL_NO_GP4

@@ -113,7 +113,7 @@ def test_appended_inputs_are_bit_identical_to_a_fresh_upload(sl):
     from safe_learning_amd.benchmarks import build_lyapunov, _true_dynamics_numpy
     from test_gpu_lyapunov import _engine_records
     case = cases.make_case("pendulum", num_points=24, n_gp=40, tau_scale=0.0, signal_std=0.03,
-                           noise_std=0.001, lengthscale=0.3)
+                           noise_std=0.001, lengthscale=0.37)
     lyap = build_lyapunov(case)
     _engine_records(lyap)
     rng = np.random.default_rng(5)
@@ -127,5 +127,5 @@ def test_appended_inputs_are_bit_identical_to_a_fresh_upload(sl):
     n, p = len(lyap.dynamics.X), 3
     xs, xs_ref = lyap._ctx.gp_inputs(0, n, p), ref._ctx.gp_inputs(0, n, p)
     assert_array_equal(xs, xs_ref)
-    assert_array_equal(xs, (lyap.dynamics.X / 0.3).T)
-    assert np.any(xs != (lyap.dynamics.X * (1.0 / 0.3)).T)   # the two roundings do differ
+    assert_array_equal(xs, (lyap.dynamics.X / 0.37).T)
+    assert np.any(xs != (lyap.dynamics.X * (1.0 / 0.37)).T)   # the two roundings do differ
