@@ -61,6 +61,9 @@ constexpr int RB = R * W;                  // row blocks per panel
 // cell for the rotated fragment reads to be conflict free; the shift between the row pairs and
 // the slab-pair skew leave the generation writes (lane = training point, 8 B, one cell per
 // instruction) with 2-way conflicts only.
+#ifndef SL_GP4_WRITE_SKEW
+#define SL_GP4_WRITE_SKEW 1
+#endif
 constexpr int RUNC = 2 * SL_P + 2;         // per wavefront: x0[SL_P], step[SL_P], a^2, Q (see Fill)
 constexpr int KXS2 = CB * 128 + 4;
 constexpr int KXBUF = 8 * KXS2;
@@ -212,12 +215,15 @@ struct Fill {
     double variance;
     double* w_lo;               // LDS write bases of the next chunk's buffer (cells 0-11 / 12-15)
     double* w_hi;
-    double xv[P], x0[P], dl[P], a2, qs, z, bj, x1, x2, k1, k2, r1, r2, q1, q2, e, rho;
+    bool odd;                   // odd training point: stores run one cell behind (w_lo / w_hi are
+                                // then one slot lower)
+    double xv[P], x0[P], dl[P], a2, qs, z, bj, x1, x2, k1, k2, r1, r2, q1, q2, e, rho, ep;
 
     static constexpr int G0 = 14;                       // first generation slot
+    static constexpr int NCELL = SL_GP4_WRITE_SKEW ? 17 : 16;     // store steps
     static constexpr bool has(int i) {
         return (MEAN && (i < 4 || i == 5 || (i >= 6 && i < 10) || i == 11)) ||
-               (GEN && i >= G0 && i < G0 + 8 + P + 13 + 16);
+               (GEN && i >= G0 && i < G0 + 8 + P + 13 + NCELL);
     }
     template <int H> __device__ __forceinline__ void mean_loads(int j) {
         kx[j] = *reinterpret_cast<const sl_d2*>(kxr + (4 * H + j) * KXS2);
@@ -253,6 +259,12 @@ struct Fill {
             else if constexpr (I >= 6 && I < 10) mean_loads<1>(I - 6);
             else if constexpr (I == 11) mean_mfmas();
         }
+#if defined(SL_GP4_FILLDBG) && SL_GP4_FILLDBG == 2               // (timing experiments: LDS writes only)
+        if constexpr (GEN && I >= G0 + 8 + P + 13 && I < G0 + 8 + P + 13 + 16) {   // (unskewed)
+            constexpr int c = I - G0 - (8 + P + 13);
+            (c < 12 ? w_lo : w_hi)[2 * c] = variance;
+        }
+#else
         if constexpr (GEN && I >= G0) {
             constexpr int K = I - G0;
             if constexpr (K == 0) {
@@ -301,13 +313,32 @@ struct Fill {
                     e = variance * ldexp(q1, (int)k1);
                     rho = ldexp(q2, (int)k2);
                 }
-            } else if constexpr (K < 8 + P + 13 + 16) {          // the 16 cells, one per slot
+            } else if constexpr (K < 8 + P + 13 + NCELL) {       // the 16 cells, one per slot
                 constexpr int c = K - (8 + P + 13);
+#if !defined(SL_GP4_FILLDBG) || SL_GP4_FILLDBG != 1            // (timing experiments: 1 = no LDS writes)
+#if SL_GP4_WRITE_SKEW
+                // Lanes of odd training points store one cell BEHIND the even ones.  For one cell
+                // the 16 lanes of a store group reach only 8 of the 16 bank pairs (row k and row
+                // k + 1 of a fragment share the slot of a cell - the fragment reads need that):
+                // every store was a two-way conflict.  One slot apart, the two halves of a group
+                // interleave: 17 conflict-free stores instead of 16 conflicting ones.
+                const double val = odd ? ep : e;
+                double* at = (c == 12) ? (odd ? w_lo : w_hi) : (c < 12 ? w_lo : w_hi);
+                if (c == 0) { if (!odd) at[0] = val; }
+                else if (c == 16) { if (odd) at[2 * c] = val; }
+                else at[2 * c] = val;
+                ep = e;
+#else
                 (c < 12 ? w_lo : w_hi)[2 * c] = e;
-                e *= rho;
-                rho *= qs;
+#endif
+#endif
+                if constexpr (c < 15) {
+                    e *= rho;
+                    rho *= qs;
+                }
             }
         }
+#endif
     }
 };
 
@@ -507,8 +538,23 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
     uint64_t best_v = ~0ull;
     int64_t best_i = INT64_MAX;
     int staged_head = -1;
+#ifdef SL_GP4_TIMING     // development: s_memtime stamps of wavefront 0, printed by workgroup 0
+    unsigned long long tm_chunk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tm_n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tm_barrier = 0, tm_head = 0, tm_tail = 0, tm_total = 0, tm_tiles = 0, tm_first = 0;
+    unsigned long long tm_x[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tm_last = 0;
+#define SL_TMX(k) do { const unsigned long long n__ = __builtin_readcyclecounter(); tm_x[k] += n__ - tm_last; tm_last = n__; } while (0)
+    const unsigned long long tm_begin = __builtin_readcyclecounter();
+#define SL_TM() __builtin_readcyclecounter()
+#endif
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef SL_GP4_TIMING
+        const unsigned long long tm_t0 = SL_TM();
+        unsigned long long tm_loop0 = 0, tm_loop1 = 0;
+        tm_last = tm_t0;
+#else
+#define SL_TMX(k) do { } while (0)
+#endif
         const int64_t tile_base = lo + tile * C;
         if (tile_base >= hi) {                     // padding tile: only clears mask bits
             if (tid == 0) neg_bits[(tile_base - lo) >> 6] = 0ull;
@@ -543,7 +589,9 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                 for (int q = 0; q < SL_P; ++q)
                     cin[(16 * wave + lcol) * SL_P + q] = (q < p) ? xg[q] * hd.inv_ls[q] : 0.0;
             }
+            SL_TMX(0);      // cin
             __syncthreads();
+            SL_TMX(1);      // barrier
             // Where the input is affine in the cell index, z_j(c) = |X_j - x(c)|^2 is quadratic in
             // c and k_x a Gaussian sequence.  Split the wavefront's 16 cells into maximal affine
             // runs (second differences vanish inside a run; a saturation kink or the end of a grid
@@ -614,8 +662,9 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                 runc[wave * RUNC + 2 * SL_P + 1] = qstep;
             }
             // fast tiles: one affine run per wavefront, operands of the fillers in LDS
-            const bool fast = !XSG && alpha_doubles > 0 && runs == 1u && !direct && !(skip & 11);
+            const bool fast = !XSG && alpha_doubles > 0 && runs == 1u && !direct && !(skip & 27);   // (16: force the slow path)
 
+            SL_TMX(2);      // runs, run constants
             double macc[4] = {0.0, 0.0, 0.0, 0.0};   // posterior-mean accumulators (see mean_pass)
 
             // k_x chunk `ch` -> LDS buffer `buf` (lane = training point 64 ch + lane)
@@ -739,7 +788,9 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
 
             const int npanels = n_pad / RP;
             for (int pan = 0; pan < npanels; ++pan) {
+                SL_TMX(11);
                 acc_zero_all();
+                SL_TMX(3);  // zeroing
                 int rowoff[R];                     // byte offset of each owned row block's fragments
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -750,18 +801,28 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                 const int first_new_chunk = pan * (RP / 64);     // chunks not generated before
                 // (on fast tiles the last chunk of the previous panel has generated chunk 0)
                 if (!(fast && pan > 0) && !(skip & 1)) generate(0, 0);
+                SL_TMX(4);  // rowoff, first generate
                 __syncthreads();
+                SL_TMX(5);
+#ifdef SL_GP4_TIMING
+                if (pan == 0) tm_loop0 = SL_TM();
+#endif
                 for (int ch = 0; ch < nchunks; ++ch) {
                     const int buf = ch & 1;
                     const int q = __builtin_amdgcn_readfirstlane(ch - 8 * pan);
                     const double* kxb = kx_l + buf * KXBUF;
+#ifdef SL_GP4_TIMING
+                    const unsigned long long tm_c0 = SL_TM();
+#endif
                     if (fast) {
                         // posterior mean of this chunk and k_x of the next one ride in the MFMA
                         // stream (Fill).  The last chunk of a panel prepares chunk 0 for the next
                         // panel (after the last panel: unused, the buffer is free).
                         constexpr int PT = DT + MT;
                         const int nxt = ch + 1 < nchunks ? ch + 1 : 0;
-                        double* wnext = kx_l + (buf ^ 1) * KXBUF + wbase + 2 * wswz;
+                        // (odd training points store one cell behind: their bases sit one slot lower)
+                        const bool odd = SL_GP4_WRITE_SKEW && (lane & 1);
+                        double* wnext = kx_l + (buf ^ 1) * KXBUF + wbase + 2 * wswz - (odd ? 2 : 0);
                         if (ch >= first_new_chunk) {
                             Fill<true, true, PT> f;
                             f.kxr = kxb + wave * 128 + own;
@@ -773,6 +834,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                             f.variance = variance;
                             f.w_lo = wnext;
                             f.w_hi = wnext - 8 * wswz;
+                            f.odd = odd;
                             chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, f);
                         } else {                       // chunks of earlier panels: all row blocks
                             Fill<false, true, PT> f;
@@ -782,24 +844,40 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                             f.variance = variance;
                             f.w_lo = wnext;
                             f.w_hi = wnext - 8 * wswz;
+                            f.odd = odd;
                             chunk<0>(rsrc, kxb, rowoff, ch, lane, boff, f);
                         }
                     } else {
+                        SL_TMX(11);
                         if (ch >= first_new_chunk && !(skip & 2)) {
                             // two call sites: the LDS copy of alpha' is read with ds_read (a common
                             // pointer would make every access a flat load that waits on both counters)
                             if (alpha_doubles > 0) mean_pass(ch, buf, alpha_l, 4);
                             else mean_pass(ch, buf, hd.alpha, dout);
                         }
+                        SL_TMX(6);  // mean pass
                         NoFill nf;
                         if (!(skip & 8)) chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, nf);
+                        SL_TMX(7);  // MFMA stream
                         if (ch + 1 < nchunks && !(skip & 1)) generate(ch + 1, buf ^ 1);
+                        SL_TMX(8);  // generation
                     }
+#ifdef SL_GP4_TIMING
+                    const unsigned long long tm_c1 = SL_TM();
                     __syncthreads();
+                    const unsigned long long tm_c2 = SL_TM();
+                    tm_chunk[q < 0 ? 8 : q] += tm_c1 - tm_c0;
+                    tm_n[q < 0 ? 8 : q] += 1;
+                    tm_barrier += tm_c2 - tm_c1;
+                    tm_loop1 = tm_c2;
+#else
+                    __syncthreads();
+#endif
                 }
                 // |a|^2 of this panel's rows.  The rows of a block live in the four lane groups
                 // (row = lane >> 4): fold them; every (wave, rotation) plane of part_ss then holds
                 // one partial sum per cell, owned by one lane (no other wave touches the plane).
+                SL_TMX(11);
                 asm volatile("s_nop 15\n\ts_nop 15" ::: SL_ALL_AGPRS);   // MFMA results -> reads
                 double ssr[CB][4];
 #pragma unroll
@@ -823,6 +901,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                             *slot = (pan == 0 ? 0.0 : *slot) + ssr[cb][rot];
                         }
                 }
+                SL_TMX(9);  // |a|^2 of the panel
             }
             if (lk < dout)
                 cell_mean[(16 * wave + 4 * blk + low) * SL_D + hd.col0 + lk] =
@@ -838,6 +917,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             __syncthreads();
         }
 
+        SL_TMX(10);         // variance, error, barriers
         // ---- per-cell decrease check, mask word, failing-cell key (as k_gp_sweep) -------------------
         const int64_t idx = tile_base + tid;
         const bool valid = (tid < C) && (idx < hi);
@@ -875,7 +955,27 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             if (valid && !okc) sl_key_min(best_v, best_i, sl_vbits(v_x), idx);
         }
         // (cell_mean / cell_err / cin are rewritten only after the next tile's barriers)
+#ifdef SL_GP4_TIMING
+        {
+            const unsigned long long tm_t1 = SL_TM();
+            tm_total += tm_t1 - tm_t0;
+            tm_head += tm_loop0 - tm_t0;
+            tm_tail += tm_t1 - tm_loop1;
+            tm_tiles += 1;
+        }
+#endif
     }
+#ifdef SL_GP4_TIMING
+    if (blockIdx.x == 7 && tid == 0 && tm_tiles > 0) {
+        printf("GP4TIMING tiles %llu cycles/tile %llu head %llu tail %llu barrier/tile %llu kernel %llu\n", tm_tiles,
+               tm_total / tm_tiles, tm_head / tm_tiles, tm_tail / tm_tiles, tm_barrier / tm_tiles,
+               SL_TM() - tm_begin);
+        for (int k = 0; k < 12; ++k) printf("GP4TIMING phase %d cycles/tile %llu\n", k, tm_x[k] / tm_tiles);
+        for (int k = 0; k < 9; ++k)
+            if (tm_n[k]) printf("GP4TIMING chunk q=%d n/tile %llu cycles/chunk %llu\n", k < 8 ? k : -1,
+                                tm_n[k] / tm_tiles, tm_chunk[k] / tm_n[k]);
+    }
+#endif
     __syncthreads();
     sl_block_reduce_key<true>(best_v, best_i, sv, si);
     if (tid == 0) { partials[blockIdx.x].vbits = best_v; partials[blockIdx.x].index = best_i; }
