@@ -602,6 +602,10 @@ int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
                        covered, model.m.grid.d);
     const bool general = sl_model_is_general(model);
     const int variant = sl_dim_variant_of(model);
+    // small training sets (one head, capacity <= 256 points): a wavefront per 64-cell tile
+    if (ctx->gp_cfg == 0 && sl_gp_small_supports(ctx, model))
+        return sl_gp_small_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
+                                  d_dbg, d_points);
     if (ctx->gp_cfg == 2 && sl_gp4_supports(model))
         return sl_gp4_sweep_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
                                    d_dbg, d_points);

@@ -1,0 +1,302 @@
+// sl_gp_small.hip - the GP-dynamics Lyapunov sweep for SMALL training sets (n_pad <= 256, one head):
+// the shape of the reference's own notebooks (<= 130 points on 3-9 M-cell 2-D grids with a table
+// value function and a table policy, examples/inverted_pendulum.ipynb:112, 152-177).
+//
+// k_gp_sweep (sl_gp.hip) treats such a model like a large one - a workgroup per 16-cell tile, k_x
+// through LDS, three workgroup barriers per tile - and spends 13 us per tile on 0.3 MFLOP.  Here
+// nothing is shared between wavefronts but read-only tables:
+//
+//  * a WAVEFRONT owns a tile of 64 consecutive cells and never meets a barrier after the staging
+//    of the workgroup: eight wavefronts per workgroup (two per SIMD) run at their own pace, one
+//    covering the other's latencies (table lookups, LDS round trips, exponentials);
+//  * k_x is produced in registers, directly in the B-fragment layout of v_mfma_f64_16x16x4_f64
+//    (lane = (training point k of the slab, cell)): one exponential per (point, cell), no LDS
+//    transpose.  With n <= 256 the exponentials are 10-20 % of the GEMM's time;
+//  * the lower triangle of Linv (MFMA A-fragments, 72 KB at n_pad = 128) sits in LDS next to the
+//    scaled training inputs and alpha'; for 128 < n_pad <= 256 the fragments stay in L2;
+//  * a = Linv k_x for 16 cells x 128 rows at a time: eight accumulator tiles per wavefront, every
+//    k_x fragment feeds all the row blocks below its diagonal;
+//  * the decrease check runs one cell per lane on all 64 lanes (the table flavours cost thousands
+//    of cycles per cell: value table at x and at the posterior mean, its gradient, the policy
+//    table), the 64-lane ballot is the tile's mask word.
+//
+// Same results as k_gp_sweep (same operation order per cell up to the order of the k_x . alpha'
+// and |a|^2 sums, i.e. rounding); tests/test_gpu_lyapunov.py runs both on the same models.
+#include "sl_common.h"
+
+typedef double sl_d4 __attribute__((ext_vector_type(4)));
+typedef double sl_d2 __attribute__((ext_vector_type(2)));
+
+namespace gps {
+constexpr int WAVES = 8;          // wavefronts per workgroup
+constexpr int PRB = 8;            // row blocks (of 16 rows) per pass: 128 rows
+// fragment pairs (1 KiB each: two slabs of 4 training points x 16 rows) of the lower triangle in
+// front of row block I: row block i needs the slab pairs 0 .. 2 i + 1
+__host__ __device__ constexpr int tri_offset(int I) { return I * (I + 1); }
+}  // namespace gps
+
+// ALDS: the A fragments are read from the workgroup's LDS copy (else from L2).
+template <bool GENERAL, int DT, int MT, bool ALDS>
+__global__ __launch_bounds__(64 * gps::WAVES) void k_gp_small(
+    const SlDevModel M, const SlGpDev gp, SlAux aux_arg, int64_t lo, int64_t hi, int64_t ntiles,
+    const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
+    uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
+    int xs_doubles, int alpha_doubles, int a_doubles, const double* __restrict__ points) {
+    using namespace gps;
+    __shared__ SlTriLds<GENERAL> tri_lds;
+    __shared__ uint64_t sv[WAVES];
+    __shared__ int64_t si[WAVES];
+    const SlAux aux = sl_stage_aux<GENERAL>(tri_lds, aux_arg);
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SlDims nd = sl_dims<DT, MT>(M);
+    const int d = nd.d, p = nd.p;
+    const SlGpHeadDev& hd = gp.head[0];
+    const int n_pad = hd.n_pad, dout = hd.dout, nslab2 = hd.nslab2;
+    double* xs_l = smem;                              // [p][n_pad]
+    double* alpha_l = xs_l + xs_doubles;              // [n_pad][dout]
+    double* a_l = alpha_l + alpha_doubles;            // lower-triangle fragments (ALDS)
+    double* scratch = a_l + a_doubles;                // per wavefront: cin [64][p], ssq [64], mean [64][d]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lcol = lane & 15, lk = lane >> 4;
+    const int wstride = 64 * (p + 1 + d);
+    double* cin = scratch + wave * wstride;
+    double* ssq_w = cin + 64 * p;
+    double* mean_w = ssq_w + 64;
+
+    // ---- staging (once per workgroup) -----------------------------------------------------------
+    for (int k = tid; k < p * n_pad; k += 64 * WAVES) xs_l[k] = hd.xs[k];
+    for (int k = tid; k < n_pad * dout; k += 64 * WAVES) alpha_l[k] = hd.alpha[k];
+    const int nrb = n_pad / 16;                       // row blocks
+    if (ALDS) {
+        // row block I, slab pair s2 (s2 <= 2 I + 1): 128 doubles at tri_offset(I) + s2
+        for (int I = 0; I < nrb; ++I) {
+            const double* src = hd.mpack + (size_t)I * nslab2 * 128;
+            double* dst = a_l + (size_t)tri_offset(I) * 128;
+            for (int k = tid; k < (2 * I + 2) * 128; k += 64 * WAVES) dst[k] = src[k];
+        }
+    }
+    __syncthreads();
+
+    uint64_t best_v = ~0ull;
+    int64_t best_i = INT64_MAX;
+    const double variance = hd.variance;
+    const int npass = (nrb + PRB - 1) / PRB;
+
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles;
+         tile += (int64_t)gridDim.x * WAVES) {
+        const int64_t tile_base = lo + tile * 64;
+        const int64_t idx = tile_base + lane;
+        const bool valid = idx < hi;
+        const int64_t gidx = valid ? idx : hi - 1;
+        // ---- GP input [x, policy(x)] of this lane's cell (kept for the check) ----------------------
+        double x[SL_P], u[SL_M];
+        sl_cell_state(M, d, gidx, points, x);
+        sl_policy_any<GENERAL>(M, nd, aux.tri, gidx, x, u);
+        sl_append_action(nd, u, x);
+#pragma unroll
+        for (int q = 0; q < SL_P; ++q)
+            if (q < p) cin[lane * p + q] = x[q] * hd.inv_ls[q];
+        __builtin_amdgcn_wave_barrier();
+
+        for (int pass = 0; pass < npass; ++pass) {
+            const int rb0 = pass * PRB;                         // first row block of the pass
+            const int rbn = nrb - rb0 < PRB ? nrb - rb0 : PRB;  // row blocks in it
+            const int ns2 = 2 * (rb0 + rbn);                    // slab pairs up to its diagonal
+            const int new_s2 = 2 * rb0;                         // training points not seen before
+            for (int cb = 0; cb < 4; ++cb) {
+                double xg[SL_P];
+#pragma unroll
+                for (int q = 0; q < SL_P; ++q) xg[q] = (q < p) ? cin[(16 * cb + lcol) * p + q] : 0.0;
+                sl_d4 acc[PRB];
+#pragma unroll
+                for (int r = 0; r < PRB; ++r) acc[r] = (sl_d4){0.0, 0.0, 0.0, 0.0};
+                double gm[SL_D];
+#pragma unroll
+                for (int dd = 0; dd < SL_D; ++dd) gm[dd] = 0.0;
+
+                for (int s2 = 0; s2 < ns2; ++s2) {
+                    // k_x of the slab pair, B-fragment layout: lane (k, cell) holds the points
+                    // 8 s2 + k (first slab) and 8 s2 + 4 + k (second slab)
+                    const int j0 = 8 * s2 + lk, j1 = j0 + 4;
+                    double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < SL_P; ++q) {
+                        if (q < p) {
+                            const double d0 = xs_l[q * n_pad + j0] - xg[q];
+                            const double d1 = xs_l[q * n_pad + j1] - xg[q];
+                            z0 = fma(d0, d0, z0);
+                            z1 = fma(d1, d1, z1);
+                        }
+                    }
+                    const double k0 = variance * sl_exp_nonpos(-0.5 * z0);
+                    const double k1 = variance * sl_exp_nonpos(-0.5 * z1);
+                    if (s2 >= new_s2) {                         // posterior mean k_x . alpha'
+#pragma unroll
+                        for (int dd = 0; dd < SL_D; ++dd) {
+                            if (dd < dout) {
+                                gm[dd] = fma(k0, alpha_l[j0 * dout + dd], gm[dd]);
+                                gm[dd] = fma(k1, alpha_l[j1 * dout + dd], gm[dd]);
+                            }
+                        }
+                    }
+                    // every row block on or below the diagonal of this slab pair
+                    const int rmin = (s2 >> 1) - rb0;           // first active row block of the pass
+#pragma unroll
+                    for (int r = 0; r < PRB; ++r) {
+                        if (r >= rmin && r < rbn) {
+                            const int I = rb0 + r;
+                            sl_d2 a;
+                            if (ALDS)
+                                a = *reinterpret_cast<const sl_d2*>(a_l + (size_t)(tri_offset(I) + s2) * 128 + lane * 2);
+                            else
+                                a = *reinterpret_cast<const sl_d2*>(hd.mpack + ((size_t)I * nslab2 + s2) * 128 + lane * 2);
+                            acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, k0, acc[r], 0, 0, 0);
+                            acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, k1, acc[r], 0, 0, 0);
+                        }
+                    }
+                }
+                // |a|^2 of the pass's rows for this lane's cell, folded over the four lane groups
+                double ss = 0.0;
+#pragma unroll
+                for (int r = 0; r < PRB; ++r) {
+                    const sl_d4 t = acc[r];
+                    ss = fma(t.x, t.x, ss);
+                    ss = fma(t.y, t.y, ss);
+                    ss = fma(t.z, t.z, ss);
+                    ss = fma(t.w, t.w, ss);
+                }
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+#pragma unroll
+                for (int dd = 0; dd < SL_D; ++dd) {
+                    if (dd < dout) {
+                        gm[dd] += __shfl_xor(gm[dd], 16, 64);
+                        gm[dd] += __shfl_xor(gm[dd], 32, 64);
+                    }
+                }
+                if (lane < 16) {
+                    const int c = 16 * cb + lane;
+                    ssq_w[c] = (pass == 0 ? 0.0 : ssq_w[c]) + ss;
+#pragma unroll
+                    for (int dd = 0; dd < SL_D; ++dd)
+                        if (dd < dout) mean_w[c * d + dd] = (pass == 0 ? 0.0 : mean_w[c * d + dd]) + gm[dd];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- per-cell decrease check (lane = cell), mask word, failing-cell key ----------------------
+        bool negative = false;
+        double v_x = 0.0;
+        {
+            double prior[SL_D], mean[SL_D], err[SL_D];
+            const double var = variance - ssq_w[lane];                     // functions.py:451
+            const double e = gp.beta * sqrt(var);                          // functions.py:514
+            sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);   // m(x*), functions.py:439
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) {
+                if (k < d) {
+                    mean[k] = mean_w[lane * d + k] + prior[k];
+                    err[k] = e;
+                }
+            }
+            if (valid) {
+                SlCellCheck c = sl_cell_check<SlSweepFlavour<GENERAL>::value>(M, d, aux, x, mean, err);
+                negative = c.negative;
+                v_x = values ? values[idx - lo] : c.v_x;               // ordering key: lyapunov.py:512
+                if (dbg) {
+                    double* o = dbg + (idx - lo) * (2 + 2 * d);
+                    o[0] = c.decrease; o[1] = c.threshold;
+#pragma unroll
+                    for (int k = 0; k < SL_D; ++k) if (k < d) { o[2 + k] = mean[k]; o[2 + d + k] = err[k]; }
+                }
+            }
+        }
+        const uint64_t word = __ballot(negative);
+        uint64_t init = 0ull;
+        if (init_bits) init = init_bits[(tile_base - lo) >> 6];
+        if (lane == 0) neg_bits[(tile_base - lo) >> 6] = word;
+        const bool ok = negative || ((init >> lane) & 1ull);
+        if (valid && !ok) sl_key_min(best_v, best_i, sl_vbits(v_x), idx);
+        __builtin_amdgcn_wave_barrier();      // the scratch is rewritten by the next tile
+    }
+    __syncthreads();
+    sl_block_reduce_key<true>(best_v, best_i, sv, si);
+    if (tid == 0) { partials[blockIdx.x].vbits = best_v; partials[blockIdx.x].index = best_i; }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+// models the kernel takes: one head with a padded capacity of at most 256 training points
+bool sl_gp_small_supports(sl_ctx* ctx, const SlDevModel& model) {
+    const char* env = getenv("SL_GP_SMALL");
+    if (env && env[0] == '0') return false;
+    if (ctx->h_gp.nheads != 1) return false;
+    const SlGpHeadHost& h = ctx->gp_heads[0];
+    return h.set && h.n_pad <= 256 && h.n_pad % 16 == 0 && h.p == model.in_dim;
+}
+
+template <bool GENERAL, int DT, int MT>
+static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
+                        const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
+                        int* nblocks, double* d_dbg, const double* d_points) {
+    using namespace gps;
+    const SlGpHeadHost& h = ctx->gp_heads[0];
+    const int p = model.in_dim, d = model.m.grid.d;
+    const int64_t ntiles = (hi - lo + 63) / 64;
+    const int xs_doubles = (p * h.n_pad + 1) & ~1;
+    const int alpha_doubles = (h.n_pad * h.dout + 1) & ~1;
+    const int nrb = h.n_pad / 16;
+    const size_t base = sizeof(double) * ((size_t)xs_doubles + alpha_doubles + (size_t)WAVES * 64 * (p + 1 + d));
+    const size_t tri = sizeof(double) * (size_t)tri_offset(nrb) * 128;
+    const size_t cap = 160 * 1024 - (GENERAL ? sizeof(SlTriLds<true>) : 0) - 256;
+    const bool alds = base + tri <= cap;
+    const size_t lds = base + (alds ? tri : 0);
+    if (lds > cap)
+        return sl_fail(ctx, SL_ERR_UNSUPPORTED, "k_gp_small: %zu bytes of LDS needed", lds);
+    const int a_doubles = alds ? tri_offset(nrb) * 128 : 0;
+    int64_t blocks = (ntiles + WAVES - 1) / WAVES;
+    if (blocks > ctx->num_cu) blocks = ctx->num_cu;
+    if (blocks < 1) blocks = 1;
+    *nblocks = (int)blocks;
+    SlAux aux{ctx->d_tri, ctx->d_net};
+#define SL_GPS_GO(ALDS_)                                                                           \
+    do {                                                                                           \
+        auto kern = k_gp_small<GENERAL, DT, MT, ALDS_>;                                            \
+        SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), lds, ctx->stream, model, \
+                           ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,      \
+                           ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, a_doubles, d_points); \
+    } while (0)
+    if (alds) SL_GPS_GO(true); else SL_GPS_GO(false);
+#undef SL_GPS_GO
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    sl_note_kernel(ctx, false, "k_gp_small<general=%d, d=%d, m=%d, Linv in %s>", (int)GENERAL, DT, MT,
+                   alds ? "LDS" : "L2");
+    return SL_OK;
+}
+
+int sl_gp_small_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
+                       const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
+                       int* nblocks, double* d_dbg, const double* d_points) {
+    const bool general = sl_model_is_general(model);
+    const int variant = sl_dim_variant_of(model);
+#define SL_GPS(G, D_, M_)                                                                          \
+    return launch_small<G, D_, M_>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks, \
+                                   d_dbg, d_points)
+    if (general) {
+        if (variant == 2) SL_GPS(true, 2, 1);
+        SL_GPS(true, 0, 0);
+    }
+    switch (variant) {
+        case 1: SL_GPS(false, 1, 1);
+        case 2: SL_GPS(false, 2, 1);
+        case 3: SL_GPS(false, 3, 1);
+        case 4: SL_GPS(false, 4, 1);
+        default: SL_GPS(false, 0, 0);
+    }
+#undef SL_GPS
+}

@@ -815,4 +815,7 @@ def test_last_kernel_names_what_ran(sl, monkeypatch):
     assert lyap._ctx.last_kernel().startswith("k_gp_sweep4<d=4")
     lyap = build_lyapunov(cases.make_case("pendulum", num_points=32, n_gp=100, tau_scale=0.0))
     lyap.update_safe_set()
+    assert lyap._ctx.last_kernel().startswith("k_gp_small<")          # <= 256 points, one head
+    monkeypatch.setenv("SL_GP_SMALL", "0")
+    lyap.update_safe_set()
     assert lyap._ctx.last_kernel().startswith("k_gp_sweep<")
