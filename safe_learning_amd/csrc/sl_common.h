@@ -72,6 +72,9 @@ int sl_gp4_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
                         const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
                         int* nblocks, double* d_dbg, const double* d_points);
 bool sl_gp4_supports(const SlDevModel& model);
+bool sl_det_rows_supports(const SlDevModel& model, int64_t lo, int64_t hi);
+int sl_det_rows_launch(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
+                       const double* d_values, uint64_t* d_neg_bits, int* nblocks);
 bool sl_gp_small_supports(sl_ctx* ctx, const SlDevModel& model);
 int sl_gp_small_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
                        const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,

@@ -644,6 +644,10 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
         rc = sl_gp_sweep_launch(ctx, ctx->h_model, lo, hi, d_init_bits, d_values, d_neg_bits,
                                 &blocks, d_dbg, d_points);
         if (rc) return rc;
+    } else if (!d_dbg && !d_points && sl_det_rows_supports(ctx->h_model, lo, hi)) {
+        // linear dynamics / linear policy / quadratic V: 8 cells of a grid row per thread
+        rc = sl_det_rows_launch(ctx, lo, hi, d_init_bits, d_values, d_neg_bits, &blocks);
+        if (rc) return rc;
     } else {
         blocks = sl_grid_blocks(hi - lo);
         SlAux aux{ctx->d_tri, ctx->d_net};

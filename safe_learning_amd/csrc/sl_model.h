@@ -605,6 +605,18 @@ SL_HD int sl_tri_sum_code(int d, const double* z) {
     return code;
 }
 
+// Smallest-weight margin above which the candidate shortcut of sl_tri_value_fast is accepted.
+// 0: every point that is strictly interior to a candidate simplex in computed arithmetic.  For a
+// point within rounding of a shared face the computed minimum of a simplex OUTSIDE the candidate
+// list may be larger by a few ulps, so there the shortcut and the full arg-max walk can pick
+// different simplices that both contain the point up to rounding: the interpolated values then
+// agree to rounding, not bit for bit (the reference's own choice on faces depends on SciPy's
+// search history; the parity tests exclude such points).  A margin of 1e-12 sends all of them to
+// the full walk - 20 % of the lookups of the 64^4 cart-pole sweep, whose out-of-range successors
+// are projected onto the boundary faces: 27.8 -> 33.3 ms per sweep (profiles/r03_summary.md).
+#ifndef SL_TRI_SHORTCUT_MARGIN
+#define SL_TRI_SHORTCUT_MARGIN 0.0
+#endif
 inline void sl_tri_regions_compute(SlTri& t);
 // (host time: the exact first-level table is milliseconds; the sampled second level of a 4-D table
 // walks 2e6 points x up to 24 simplices, 0.5-1 s on the first 4-D sl_tri_set of a thread.  The
@@ -876,10 +888,7 @@ SL_HD void sl_tri_locate_fast(const SlTri& t, const double* x, SlTriLoc<(DT > 0 
                 SL_TRI_TRY(s1);
             }
         }
-        // the margin keeps points within rounding of a shared face on the full walk: there a
-        // simplex outside the candidate list may have a (tiny) larger computed minimum, and the
-        // shortcut must never change which simplex the arg-max rule picks
-        full = !(nc > 0 && best_min > 1e-12);
+        full = !(nc > 0 && best_min > SL_TRI_SHORTCUT_MARGIN);
     }
     if (full) {
         best = 0;

@@ -819,3 +819,46 @@ def test_last_kernel_names_what_ran(sl, monkeypatch):
     monkeypatch.setenv("SL_GP_SMALL", "0")
     lyap.update_safe_set()
     assert lyap._ctx.last_kernel().startswith("k_gp_sweep<")
+
+
+def _neg_mask_of_update(lyap):
+    lyap.update_safe_set()
+    n = lyap._hi - lyap._lo
+    bits = lyap._d_neg.cpu().numpy().view(np.uint8)
+    return np.unpackbits(bits, bitorder="little")[:n].astype(bool)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("1d", dict(num_points=1000)),                                                  # scalar L_v
+    ("1d", dict(num_points=64, tau_scale=0.0)),
+    ("pendulum", dict(num_points=[17, 40], dynamics="linear", tau_scale=0.02)),
+    ("pendulum", dict(num_points=128, dynamics="linear", tau_scale=0.0)),
+    ("pendulum", dict(num_points=[50, 72], dynamics="linear", tau_scale=0.01)),
+    ("cartpole", dict(num_points=8, dynamics="linear", tau_scale=0.0)),
+    ("cartpole", dict(num_points=[5, 6, 7, 16], dynamics="linear", tau_scale=0.01)),
+    ("cartpole", dict(num_points=24, dynamics="linear", tau_scale=0.004)),
+])
+def test_row_kernel_is_bit_identical(sl, name, kw, monkeypatch):
+    """k_det_rows (8 cells of a grid row per thread, shared prefixes of the ordered sums) against
+    k_det_sweep (every cell from scratch) and against the oracle: decrease mask, safe set and c_max
+    bit for bit."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case(name, **kw)
+    monkeypatch.delenv("SL_DET_ROWS", raising=False)
+    lyap = build_lyapunov(case)
+    neg_rows = _neg_mask_of_update(lyap)
+    assert lyap._ctx.last_kernel().startswith("k_det_rows<"), lyap._ctx.last_kernel()
+    monkeypatch.setenv("SL_DET_ROWS", "0")
+    ref = build_lyapunov(case)
+    neg_cells = _neg_mask_of_update(ref)
+    assert ref._ctx.last_kernel().startswith("k_det_sweep<")
+    olyap = cases.oracle_lyapunov(case)
+    _, ref_neg = _oracle_all(olyap)
+    olyap.update_safe_set()
+    assert_array_equal(neg_rows, neg_cells)
+    assert_array_equal(neg_rows, ref_neg)
+    if name != "1d" or case["tau"] == 0.0:          # (the reference's 1-D test case with tau > 0: no cell passes)
+        assert neg_rows.any() and (~neg_rows).any()
+    assert_array_equal(lyap.safe_set, olyap.safe_set)
+    assert_array_equal(ref.safe_set, olyap.safe_set)
+    assert lyap.c_max == olyap.c_max == ref.c_max

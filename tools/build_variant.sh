@@ -13,12 +13,12 @@ obj=safe_learning_amd/build/variants/${name}_${unit}.o
 extra=""
 case $unit in sl_gp4_*) extra="-mllvm -amdgpu-spill-vgpr-to-agpr=0";; esac
 case $unit in sl_gp4_d?) extra="$extra -DSL_GP4_DIM=${unit#sl_gp4_d}";; esac
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC ${SL_VARIANT_VIS--fvisibility=hidden} \
     -Iinclude -Isafe_learning_amd/csrc $extra "$@" -c "$src" -o "$obj"
 objs=""
 for o in safe_learning_amd/build/*/*.o; do
     stem=$(basename "$o" .o)
-    case $o in */variants/*|*-hip-amdgcn*|*-host-*) continue;; esac
+    case $o in */sl_no_*/*|*/variants/*|*-hip-amdgcn*|*-host-*) continue;; esac
     [ "$stem" = "$unit" ] && continue
     [ "$unit" = sl_gp4_all ] && case $stem in sl_gp4_d?) continue;; esac
     objs="$objs $o"
