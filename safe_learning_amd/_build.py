@@ -18,7 +18,8 @@ ROOT = os.path.dirname(HERE)
 # translation units: (object stem, source, extra flags).  sl_gp4.hip is compiled once per state
 # dimension (its unrolled MFMA streams make one instantiation a minute of compile time; the four
 # jobs run side by side).
-GP4_FLAGS = ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps=obj"]
+GP4_R = int(os.environ.get("SL_GP4_R", "4"))     # row blocks per wavefront of k_gp_sweep4 (sl_gp4.hip)
+GP4_FLAGS = ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps=obj", "-DSL_GP4_R=%d" % GP4_R]
 UNITS = [("sl_kernels", "sl_kernels.hip", []), ("sl_gp", "sl_gp.hip", []),
          ("sl_bellman", "sl_bellman.hip", []), ("sl_bellman4", "sl_bellman4.hip", ["-save-temps=obj"]),
          ("sl_nn", "sl_nn.hip", []), ("sl_comm", "sl_comm.hip", []),
@@ -48,7 +49,9 @@ def _audit_gp4(objdir, verbose):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import audit_gp4
     for dim in (1, 2, 3, 4):
-        report, problems = audit_gp4.audit(_listing(objdir, "sl_gp4_d%d" % dim), "_Z11k_gp_sweep4", 8, 256)
+        # (one MFMA stream per number of active row blocks; 32 accumulator registers per row block)
+        report, problems = audit_gp4.audit(_listing(objdir, "sl_gp4_d%d" % dim), "_Z11k_gp_sweep4", GP4_R,
+                                           32 * GP4_R)
         if verbose:
             print("\n".join(report))
         if problems:

@@ -49,7 +49,18 @@ typedef unsigned sl_u4 __attribute__((ext_vector_type(4)));
 
 namespace gp4 {
 
-constexpr int R = 8, CB = 4, W = 4;
+// SL_GP4_R row blocks per wavefront.  8: one wavefront per SIMD with all 512 registers (128 FP64
+// accumulators, 512-row panels).  4: 256 registers (64 accumulators, 256-row panels) and at most
+// 80 KB of LDS per workgroup, so that TWO workgroups share a CU: they work on different tiles at
+// their own pace, and whatever one of them does outside its MFMA stream (k_x generation, the
+// barrier, the per-tile prologue and epilogue) runs under the other one's MFMAs.
+#ifndef SL_GP4_R
+#define SL_GP4_R 4
+#endif
+constexpr int R = SL_GP4_R, CB = 4, W = 4;
+constexpr int NACC = R * CB * 4;           // FP64 accumulators per lane (2 registers each)
+constexpr bool TWO_PER_CU = R <= 4;        // second workgroup on the CU: training inputs and alpha'
+                                           // stay in L2, the |a|^2 partials are folded per wavefront
 constexpr int C = 16 * CB;                 // cells per tile
 constexpr int RP = 16 * R * W;             // rows per panel (512)
 constexpr int RB = R * W;                  // row blocks per panel
@@ -67,7 +78,7 @@ constexpr int RB = R * W;                  // row blocks per panel
 constexpr int RUNC = 2 * SL_P + 2;         // per wavefront: x0[SL_P], step[SL_P], a^2, Q (see Fill)
 constexpr int KXS2 = CB * 128 + 4;
 constexpr int KXBUF = 8 * KXS2;
-static_assert(R * CB * 4 * 2 == 256, "the accumulators fill the 256 accumulator registers");
+static_assert(R == 8 || R == 4, "512- or 256-row panels");
 
 struct AFrag { sl_d2 v[R]; };
 struct BFrag { sl_d2 v[CB]; };
@@ -80,12 +91,18 @@ struct BFrag { sl_d2 v[CB]; };
 // so the compiler cannot keep a value of its own in an accumulator register across any of them;
 // tools/audit_gp4.py (run by the build) proves on the generated code that it never uses one.
 #define SL_A10(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
-#define SL_ALL_AGPRS                                                                               \
+#define SL_AGPRS_0_127                                                                             \
     "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", SL_A10(1), SL_A10(2), SL_A10(3),   \
         SL_A10(4), SL_A10(5), SL_A10(6), SL_A10(7), SL_A10(8), SL_A10(9), SL_A10(10), SL_A10(11),   \
-        SL_A10(12), SL_A10(13), SL_A10(14), SL_A10(15), SL_A10(16), SL_A10(17), SL_A10(18),        \
-        SL_A10(19), SL_A10(20), SL_A10(21), SL_A10(22), SL_A10(23), SL_A10(24), "a250", "a251",     \
-        "a252", "a253", "a254", "a255"
+        "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+#if SL_GP4_R == 8
+#define SL_ALL_AGPRS                                                                               \
+    SL_AGPRS_0_127, "a128", "a129", SL_A10(13), SL_A10(14), SL_A10(15), SL_A10(16), SL_A10(17),    \
+        SL_A10(18), SL_A10(19), SL_A10(20), SL_A10(21), SL_A10(22), SL_A10(23), SL_A10(24), "a250", \
+        "a251", "a252", "a253", "a254", "a255"
+#else
+#define SL_ALL_AGPRS SL_AGPRS_0_127
+#endif
 
 template <int BASE>
 __device__ __forceinline__ void acc_zero16() {
@@ -105,7 +122,7 @@ __device__ __forceinline__ void acc_zero16() {
 template <int BASE = 0>
 __device__ __forceinline__ void acc_zero_all() {
     acc_zero16<BASE>();
-    if constexpr (BASE + 16 < 256) acc_zero_all<BASE + 16>();
+    if constexpr (BASE + 16 < 2 * NACC) acc_zero_all<BASE + 16>();
 }
 template <int N>
 __device__ __forceinline__ double acc_read() {
@@ -120,7 +137,7 @@ template <int I = 0>
 __device__ __forceinline__ void acc_squares(double (&ssr)[CB][4]) {
     const double v = acc_read<2 * I>();
     ssr[(I / 4) % CB][I % 4] = fma(v, v, ssr[(I / 4) % CB][I % 4]);
-    if constexpr (I + 1 < R * CB * 4) acc_squares<I + 1>(ssr);
+    if constexpr (I + 1 < NACC) acc_squares<I + 1>(ssr);
 }
 
 // eight MFMAs of one (row block, rotation): both slabs of the pair for the four cell blocks.  The
@@ -203,7 +220,9 @@ struct Fill {
     // 16 MFMAs (A = alpha'^T, rows dd = lane & 3, zero rows beyond dout come from the padded LDS
     // copy; B = the rotation-0 k_x fragment of this wavefront's own cell block)
     const double* kxr;          // LDS: this lane's (k, cell) item of the chunk in flight
-    const double* ap;           // LDS: alpha' [point][4], this lane's column of the chunk
+    const double* ap;           // alpha' of the chunk, this lane's column: LDS copy [point][4] (zero
+    int astride;                // padded), or the [point][dout] array in L2 (arow: the lane's row
+    bool arow;                  // dd = lane & 3 exists)
     double* macc;               // [4] accumulators in rotation
     sl_d2 kx[4];
     double a0[4], a1[4];
@@ -227,8 +246,9 @@ struct Fill {
     }
     template <int H> __device__ __forceinline__ void mean_loads(int j) {
         kx[j] = *reinterpret_cast<const sl_d2*>(kxr + (4 * H + j) * KXS2);
-        a0[j] = ap[(8 * (4 * H + j)) * 4];
-        a1[j] = ap[(8 * (4 * H + j) + 4) * 4];
+        const double t0 = ap[(8 * (4 * H + j)) * astride], t1 = ap[(8 * (4 * H + j) + 4) * astride];
+        a0[j] = arow ? t0 : 0.0;
+        a1[j] = arow ? t1 : 0.0;
     }
     __device__ __forceinline__ void mean_mfmas() {
         // Accumulators in vector registers; a dependent FP64 MFMA must not issue right behind its
@@ -449,15 +469,24 @@ template <class F>
 __device__ __forceinline__ void chunk_any(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
                                           const int (&rowoff)[R], int q, int ch, int lane,
                                           const int (&boff)[4], F& f) {
-    switch (q) {
-        case 1: chunk<1, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-        case 2: chunk<2, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-        case 3: chunk<3, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-        case 4: chunk<4, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-        case 5: chunk<5, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-        case 6: chunk<6, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-        case 7: chunk<7, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-        default: chunk<0, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+    if constexpr (R == 8) {
+        switch (q) {
+            case 1: chunk<1, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            case 2: chunk<2, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            case 3: chunk<3, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            case 4: chunk<4 % R, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            case 5: chunk<5 % R, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            case 6: chunk<6 % R, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            case 7: chunk<7 % R, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            default: chunk<0, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+        }
+    } else {
+        switch (q) {
+            case 1: chunk<1, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            case 2: chunk<2, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            case 3: chunk<3, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            default: chunk<0, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+        }
     }
 }
 
@@ -501,7 +530,7 @@ __device__ __forceinline__ double uniform(double v) {
 
 // XSG: the scaled training inputs do not fit LDS and are read from L2 during generation.
 template <int DT, int MT, bool XSG>
-__global__ __launch_bounds__(256, 1) void k_gp_sweep4(
+__global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
@@ -514,8 +543,9 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
     double* xs_l = smem;                           // [p][n_pad]
     double* alpha_l = xs_l + xs_doubles;           // [n_pad][dout] when it fits
     double* kx_l = alpha_l + alpha_doubles;        // [2][KXBUF]
-    double* part_ss = kx_l + 2 * KXBUF;            // [W][4 rotations][C]
-    double* cell_mean = part_ss + W * 4 * C;       // [C][SL_D]
+    constexpr int PSS = TWO_PER_CU ? W : W * 4;    // planes of |a|^2 partials
+    double* part_ss = kx_l + 2 * KXBUF;            // [W][4 rotations][C]  (TWO_PER_CU: [W][C])
+    double* cell_mean = part_ss + PSS * C;         // [C][SL_D]
     double* cell_err = cell_mean + C * SL_D;       // [C][SL_D]
     double* cin = cell_err + C * SL_D;             // [C][SL_P] scaled GP inputs of the tile's cells
     double* runc = cin + C * SL_P;                 // [W][RUNC] x0, step, a^2, Q of each wavefront's run
@@ -662,7 +692,11 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                 runc[wave * RUNC + 2 * SL_P + 1] = qstep;
             }
             // fast tiles: one affine run per wavefront, operands of the fillers in LDS
-            const bool fast = !XSG && alpha_doubles > 0 && runs == 1u && !direct && !(skip & 27);   // (16: force the slow path)
+            // Two workgroups per CU cover each other's phases: no fillers there (and no registers
+            // for their state: 128 vector registers next to the 128 accumulator registers).
+            // (16: force the slow path)
+            const bool fast = !TWO_PER_CU && !XSG && alpha_doubles > 0 && runs == 1u && !direct &&
+                              !(skip & 27);
 
             SL_TMX(2);      // runs, run constants
             double macc[4] = {0.0, 0.0, 0.0, 0.0};   // posterior-mean accumulators (see mean_pass)
@@ -797,7 +831,8 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                     const int wsel = (r & 1) ? (W - 1 - wave) : wave;     // balance the triangle
                     rowoff[r] = (pan * RB + r * W + wsel) * hd.nslab2 * 1024;
                 }
-                const int nchunks = (pan + 1) * (RP / 64);
+                constexpr int CPP = RP / 64;                     // chunks per panel (its diagonal band)
+                const int nchunks = (pan + 1) * CPP;
                 const int first_new_chunk = pan * (RP / 64);     // chunks not generated before
                 // (on fast tiles the last chunk of the previous panel has generated chunk 0)
                 if (!(fast && pan > 0) && !(skip & 1)) generate(0, 0);
@@ -809,12 +844,14 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
 #endif
                 for (int ch = 0; ch < nchunks; ++ch) {
                     const int buf = ch & 1;
-                    const int q = __builtin_amdgcn_readfirstlane(ch - 8 * pan);
+                    const int q = __builtin_amdgcn_readfirstlane(ch - CPP * pan);
                     const double* kxb = kx_l + buf * KXBUF;
 #ifdef SL_GP4_TIMING
                     const unsigned long long tm_c0 = SL_TM();
 #endif
-                    if (fast) {
+                    bool filled = false;
+                    if constexpr (!TWO_PER_CU) if (fast) {
+                        filled = true;
                         // posterior mean of this chunk and k_x of the next one ride in the MFMA
                         // stream (Fill).  The last chunk of a panel prepares chunk 0 for the next
                         // panel (after the last panel: unused, the buffer is free).
@@ -826,9 +863,18 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                         if (ch >= first_new_chunk) {
                             Fill<true, true, PT> f;
                             f.kxr = kxb + wave * 128 + own;
-                            f.ap = alpha_l + (64 * ch + lk) * 4 + low;
+                            if constexpr (TWO_PER_CU) {
+                                f.arow = low < dout;
+                                f.astride = dout;
+                                f.ap = hd.alpha + (64 * ch + lk) * dout + (f.arow ? low : 0);
+                                f.xs = xs_glob + 64 * nxt + lane;
+                            } else {
+                                f.arow = true;
+                                f.astride = 4;
+                                f.ap = alpha_l + (64 * ch + lk) * 4 + low;
+                                f.xs = xs_l + 64 * nxt + lane;
+                            }
                             f.macc = macc;
-                            f.xs = xs_l + 64 * nxt + lane;
                             f.n_pad = n_pad;
                             f.run = runc + wave * RUNC;
                             f.variance = variance;
@@ -838,7 +884,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                             chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, f);
                         } else {                       // chunks of earlier panels: all row blocks
                             Fill<false, true, PT> f;
-                            f.xs = xs_l + 64 * nxt + lane;
+                            f.xs = (TWO_PER_CU ? xs_glob : xs_l) + 64 * nxt + lane;
                             f.n_pad = n_pad;
                             f.run = runc + wave * RUNC;
                             f.variance = variance;
@@ -847,7 +893,8 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                             f.odd = odd;
                             chunk<0>(rsrc, kxb, rowoff, ch, lane, boff, f);
                         }
-                    } else {
+                    }
+                    if (!filled) {
                         SL_TMX(11);
                         if (ch >= first_new_chunk && !(skip & 2)) {
                             // two call sites: the LDS copy of alpha' is read with ds_read (a common
@@ -892,14 +939,38 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
                         ssr[cb][rot] += __shfl_xor(ssr[cb][rot], 16, 64);
                         ssr[cb][rot] += __shfl_xor(ssr[cb][rot], 32, 64);
                     }
-                if (lane < 16) {
+                if (!TWO_PER_CU) {
+                    if (lane < 16) {
 #pragma unroll
-                    for (int cb = 0; cb < CB; ++cb)
+                        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                        for (int rot = 0; rot < 4; ++rot) {
-                            double* slot = part_ss + (wave * 4 + rot) * C + 16 * cb + 4 * ((blk + rot) & 3) + low;
-                            *slot = (pan == 0 ? 0.0 : *slot) + ssr[cb][rot];
+                            for (int rot = 0; rot < 4; ++rot) {
+                                double* slot = part_ss + (wave * 4 + rot) * C + 16 * cb + 4 * ((blk + rot) & 3) + low;
+                                *slot = (pan == 0 ? 0.0 : *slot) + ssr[cb][rot];
+                            }
+                    }
+                } else {
+                    // one plane per wavefront (LDS is short): the four rotations of a lane belong
+                    // to four different cells, and within a rotation the lanes hit distinct cells,
+                    // so the rotations are added one after the other (in-order LDS, same wavefront)
+                    if (pan == 0) {
+                        if (lane < 16) {
+#pragma unroll
+                            for (int cb = 0; cb < CB; ++cb) part_ss[wave * C + 16 * cb + lane] = 0.0;
                         }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+#pragma unroll
+                    for (int rot = 0; rot < 4; ++rot) {
+                        if (lane < 16) {
+#pragma unroll
+                            for (int cb = 0; cb < CB; ++cb) {
+                                double* slot = part_ss + wave * C + 16 * cb + 4 * ((blk + rot) & 3) + low;
+                                *slot = *slot + ssr[cb][rot];
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
                 SL_TMX(9);  // |a|^2 of the panel
             }
@@ -909,7 +980,7 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
             __syncthreads();
             if (tid < C) {
                 double sumsq = 0.0;
-                for (int k = 0; k < W * 4; ++k) sumsq += part_ss[k * C + tid];
+                for (int k = 0; k < PSS; ++k) sumsq += part_ss[k * C + tid];
                 const double var = variance - sumsq;                       // functions.py:451
                 const double e = gp.beta * sqrt(var);                      // functions.py:514
                 for (int dd = 0; dd < dout; ++dd) cell_err[tid * SL_D + hd.col0 + dd] = e;
@@ -985,8 +1056,8 @@ __global__ __launch_bounds__(256, 1) void k_gp_sweep4(
 // host side
 // =============================================================================================
 static size_t gp4_fixed_lds() {
-    return sizeof(double) * (2 * gp4::KXBUF + gp4::W * 4 * gp4::C + 2 * gp4::C * SL_D + gp4::C * SL_P +
-                             gp4::W * gp4::RUNC) +
+    return sizeof(double) * (2 * gp4::KXBUF + (gp4::TWO_PER_CU ? 1 : 4) * gp4::W * gp4::C +
+                             2 * gp4::C * SL_D + gp4::C * SL_P + gp4::W * gp4::RUNC) +
            2 * gp4::W * sizeof(uint64_t);
 }
 
@@ -1021,15 +1092,17 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
     xs_doubles = XSG ? 0 : ((xs_doubles + 1) & ~1);          // keep the k_x buffers 16-byte aligned
     alpha_doubles = (alpha_doubles + 1) & ~1;
     size_t lds = gp4_fixed_lds() + sizeof(double) * xs_doubles;
+    if (gp4::TWO_PER_CU) alpha_doubles = 0;                   // two workgroups per CU: 80 KB each
     if (lds + sizeof(double) * alpha_doubles <= 160 * 1024) lds += sizeof(double) * alpha_doubles;
     else alpha_doubles = 0;                                   // alpha' then comes from L2
-    if (lds > 160 * 1024)
+    if (lds > (gp4::TWO_PER_CU ? 80 : 160) * 1024)
         return sl_fail(ctx, SL_ERR_UNSUPPORTED, "GP training set too large for LDS staging "
                                                 "(%zu bytes needed)", lds);
     auto kern = k_gp_sweep4<DT, MT, XSG>;
     SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int64_t blocks = ntiles < ctx->num_cu ? ntiles : ctx->num_cu;
+    const int64_t resident = (int64_t)ctx->num_cu * (gp4::TWO_PER_CU ? 2 : 1);
+    int64_t blocks = ntiles < resident ? ntiles : resident;
     if (blocks > SL_MAX_GRID) blocks = SL_MAX_GRID;
     *nblocks = (int)blocks;
     SlAux aux{ctx->d_tri, ctx->d_net};
@@ -1039,7 +1112,8 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
                        ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,
                        ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, d_points, skip);
     SL_HIP_CHECK(ctx, hipGetLastError());
-    sl_note_kernel(ctx, false, "k_gp_sweep4<d=%d, m=%d, xs_global=%d>", DT, MT, (int)XSG);
+    sl_note_kernel(ctx, false, "k_gp_sweep4<d=%d, m=%d, xs_global=%d> (%d-row panels, %d workgroup(s) per CU)",
+                   DT, MT, (int)XSG, gp4::RP, gp4::TWO_PER_CU ? 2 : 1);
     return SL_OK;
 }
 
@@ -1077,7 +1151,7 @@ int sl_gp4_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
                         const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
                         int* nblocks, double* d_dbg, const double* d_points) {
     const int variant = sl_dim_variant_of(model);
-    const bool xsg = !sl_gp4_xs_fit(ctx, model.in_dim);
+    const bool xsg = gp4::TWO_PER_CU || !sl_gp4_xs_fit(ctx, model.in_dim);
 #define SL_GP4(D_)                                                                                 \
     return sl_gp4_launch_d##D_(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,     \
                                d_dbg, d_points, xsg)

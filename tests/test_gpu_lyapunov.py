@@ -857,7 +857,7 @@ def test_row_kernel_is_bit_identical(sl, name, kw, monkeypatch):
     olyap.update_safe_set()
     assert_array_equal(neg_rows, neg_cells)
     assert_array_equal(neg_rows, ref_neg)
-    if name != "1d" or case["tau"] == 0.0:          # (the reference's 1-D test case with tau > 0: no cell passes)
+    if kw.get("num_points") in (128, 24):         # the larger grids: both outcomes occur
         assert neg_rows.any() and (~neg_rows).any()
     assert_array_equal(lyap.safe_set, olyap.safe_set)
     assert_array_equal(ref.safe_set, olyap.safe_set)
