@@ -24,5 +24,9 @@ T=$(find $OUT/trace -name "*_results.db" | head -1)
 python tools/kernel_stats.py $T > $OUT/kernel_stats.md 2>&1
 python tools/pmc_dump.py k_gp_sweep $(find $OUT/pmc_a $OUT/pmc_b $OUT/pmc_c $OUT/pmc_d -name "*_results.db") > $OUT/pmc_48.txt 2>&1
 python tools/pmc_dump.py k_gp_sweep $(find $OUT/pmc_fetch $OUT/pmc_write -name "*_results.db") > $OUT/pmc_128.txt 2>&1
+python tools/pmc_traffic.py $(find $OUT/pmc_fetch -name "*_results.db" | head -1) $(find $OUT/pmc_write -name "*_results.db" | head -1) > $OUT/pmc_traffic.log 2>&1
+cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 grep -h '^{' $OUT/trace.log $OUT/pmc_a.log | cut -c1-400 > $OUT/bench_lines.txt
+# the result databases are large (gpurun copies back at most 64 MiB): keep the summaries only
+rm -rf $OUT/trace $OUT/pmc_a $OUT/pmc_b $OUT/pmc_c $OUT/pmc_d $OUT/pmc_fetch $OUT/pmc_write
 cat $OUT/kernel_stats.md $OUT/pmc_48.txt $OUT/pmc_128.txt
