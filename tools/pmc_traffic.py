@@ -34,13 +34,10 @@ def main():
     out = {"workload": workload, "kernel": kname.split("(")[0],
            "fetch_size_kib_reported": fetch_kib, "write_size_kib_reported": write_kib,
            "bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
-           "note": "L2<->fabric bytes per k_gp_sweep launch: (2 x FETCH_SIZE + WRITE_SIZE) x 1024. "
-                   "Reads: the packed inverse Cholesky factor (2 x 4 MiB per workgroup of 64 cells, "
-                   "once for the squared norms, once for the mean) where it misses the 4 MiB L2 "
-                   "of the XCD and is served by the Infinity Cache; the counter sits on the L2 "
-                   "side, so it is fabric traffic, an upper bound of the HBM reads.  Writes: the "
-                   "safe bits, candidate records and <= 52 bytes/lane of set-up scratch.  "
-                   "Algorithmic bytes are 8.25 per cell."}
+           "note": "L2<->fabric bytes per launch of the GP sweep kernel: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
+                   "(KiB units, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes): L2 misses "
+                   "of the inverse Cholesky factor's fragments served by the Infinity Cache (an upper bound "
+                   "of the HBM reads) + mask words and set-up scratch; profiles/r03_summary.md."}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(out)
