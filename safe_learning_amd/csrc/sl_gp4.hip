@@ -8,17 +8,24 @@
 //    lanes, tests/test_gpu_lyapunov.py::test_mfma_4x4x4_block_layout), so a 16-row x 16-cell x 4
 //    tile takes four instructions: the A fragment (rows) stays, the k_x fragment (cells) is read
 //    from LDS rotated by 0/4/8/12 lanes per row of 16.
-//  * FP64 VALU work shares that pipe (measured: no overlap with FP64 MFMAs, own wave or partner),
-//    so nothing is gained from a second wavefront per SIMD: ONE wavefront per SIMD (W = 4) with
-//    the whole 512-register file - 8 row blocks x 4 cell blocks x 4 rotations = 128 FP64
-//    accumulators per lane - halves the operand traffic per MFMA.
-//  * The accumulators sit at FIXED accumulator registers a[0:255] and are only touched by
-//    inline-asm MFMA groups.  With C++ accumulator variables every branch around the MFMAs (the
-//    lower triangle makes the set of active row blocks chunk dependent) costs phi copies,
-//    out-of-place MFMAs and spills (measured: 36 instead of 62 TFLOP/s for the GEMM phase).
-//  * One straight-line body per number of active row blocks (template R0), operands software
-//    pipelined: A fragments (buffer loads with scalar offsets) two slab pairs ahead in three
-//    register sets, k_x fragments one rotation ahead.
+//  * FP64 VALU work shares that pipe (measured: no overlap with FP64 MFMAs, own wave or partner).
+//    Two shapes of a workgroup (SL_GP4_R, build time):
+//      R = 4 (shipped): four wavefronts with 256 registers each - 4 row blocks x 4 cell blocks x
+//        4 rotations = 64 FP64 accumulators per lane in a[0:127] - 256-row panels and 79 KB of LDS,
+//        so that TWO workgroups share a CU and cover each other's non-MFMA phases (generation,
+//        barrier, per-tile prologue and epilogue); training inputs and alpha' come from L2.
+//      R = 8 (round 2): one wavefront per SIMD with the whole 512-register file (128
+//        accumulators in a[0:255], 512-row panels: 24 instead of 40 chunk generations per tile,
+//        half the operand traffic per MFMA); its non-MFMA phases can ride in the MFMA stream as
+//        "fillers" (struct Fill).  2 % slower than R = 4 (profiles/r03_summary.md).
+//  * The accumulators sit at FIXED accumulator registers and are only touched by inline-asm MFMA
+//    groups.  With C++ accumulator variables every branch around the MFMAs (the lower triangle
+//    makes the set of active row blocks chunk dependent) costs phi copies, out-of-place MFMAs and
+//    spills (measured: 36 instead of 62 TFLOP/s for the GEMM phase).
+//  * One straight-line body per number of active row blocks (template R0), the slab pairs of a
+//    chunk unrolled, operands software pipelined: A fragments (buffer loads with scalar offsets)
+//    two slab pairs ahead in three register sets, k_x fragments one rotation ahead - and the load
+//    instructions placed BETWEEN the MFMAs of a group (rotation<>), not in front of it.
 //  * k_x generation: where the GP input [x, policy(x)] / lengthscales is affine in the cell index
 //    along the wavefront's 16 cells (a row of the last grid axis, policy linear or saturated) the
 //    RBF values form a Gaussian sequence e_{c+1} = e_c rho_c, rho_{c+1} = rho_c Q: two
@@ -29,8 +36,8 @@
 //    The posterior mean k_x . alpha' is a 4 x 16 x 64 product per chunk and wavefront: 16 more
 //    MFMAs on the LDS copy of each new chunk.
 //
-// Measured in tools/gp_lab.hip (1 Mi cells, 1024 points): 16x16x4 structure 49.5 TFLOP/s, this
-// one 60.5; profiles/r02_summary.md has the ablation.
+// Measured in tools/gp_lab.hip (1 Mi cells, 1024 points): 16x16x4 structure 49.5 TFLOP/s, round 2's
+// 4x4x4 kernel 60.5 (profiles/r02_summary.md); round 3: 62.4 TFLOP/s at 128^4 (profiles/r03_summary.md).
 #include "sl_common.h"
 #include "sl_gp4_clobbers.h"
 
