@@ -1,4 +1,4 @@
-// sl_gp_small.hip - the GP-dynamics Lyapunov sweep for SMALL training sets (n_pad <= 256, one head):
+// sl_gp_small.hip - the GP-dynamics Lyapunov sweep for SMALL training sets (n_pad <= 256 per head):
 // the shape of the reference's own notebooks (<= 130 points on 3-9 M-cell 2-D grids with a table
 // value function and a table policy, examples/inverted_pendulum.ipynb:112, 152-177).
 //
@@ -16,6 +16,9 @@
 //    scaled training inputs and alpha'; for 128 < n_pad <= 256 the fragments stay in L2;
 //  * a = Linv k_x for 16 cells x 128 rows at a time: eight accumulator tiles per wavefront, every
 //    k_x fragment feeds all the row blocks below its diagonal;
+//  * a FunctionStack of single-output GPs (the notebooks' dynamics model: one GP per state
+//    dimension, own kernel and training inputs, functions.py:278-291) is a loop over the heads
+//    inside the tile: each head has its own scaled inputs, alpha' and factor;
 //  * the decrease check runs one cell per lane on all 64 lanes (the table flavours cost thousands
 //    of cycles per cell: value table at x and at the posterior mean, its gradient, the policy
 //    table), the 64-lane ballot is the tile's mask word.
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(64 * gps::WAVES) void k_gp_small(
     const SlDevModel M, const SlGpDev gp, SlAux aux_arg, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
-    int xs_doubles, int alpha_doubles, int a_doubles, const double* __restrict__ points) {
+    int head_doubles, const double* __restrict__ points) {
     using namespace gps;
     __shared__ SlTriLds<GENERAL> tri_lds;
     __shared__ uint64_t sv[WAVES];
@@ -50,38 +53,43 @@ __global__ __launch_bounds__(64 * gps::WAVES) void k_gp_small(
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SlDims nd = sl_dims<DT, MT>(M);
     const int d = nd.d, p = nd.p;
-    const SlGpHeadDev& hd = gp.head[0];
-    const int n_pad = hd.n_pad, dout = hd.dout, nslab2 = hd.nslab2;
-    double* xs_l = smem;                              // [p][n_pad]
-    double* alpha_l = xs_l + xs_doubles;              // [n_pad][dout]
-    double* a_l = alpha_l + alpha_doubles;            // lower-triangle fragments (ALDS)
-    double* scratch = a_l + a_doubles;                // per wavefront: cin [64][p], ssq [64], mean [64][d]
+    const int nheads = gp.nheads;
+    // LDS: per head [xs p x n_pad | alpha' n_pad x dout | lower-triangle fragments (ALDS)], then the
+    // wavefronts' scratch: cin [64][p], ssq [64], mean [64][d], err [64][d]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lcol = lane & 15, lk = lane >> 4;
-    const int wstride = 64 * (p + 1 + d);
-    double* cin = scratch + wave * wstride;
+    const int wstride = 64 * (p + 1 + 2 * d);
+    double* cin = smem + head_doubles + wave * wstride;
     double* ssq_w = cin + 64 * p;
     double* mean_w = ssq_w + 64;
+    double* err_w = mean_w + 64 * d;
 
     // ---- staging (once per workgroup) -----------------------------------------------------------
-    for (int k = tid; k < p * n_pad; k += 64 * WAVES) xs_l[k] = hd.xs[k];
-    for (int k = tid; k < n_pad * dout; k += 64 * WAVES) alpha_l[k] = hd.alpha[k];
-    const int nrb = n_pad / 16;                       // row blocks
-    if (ALDS) {
-        // row block I, slab pair s2 (s2 <= 2 I + 1): 128 doubles at tri_offset(I) + s2
-        for (int I = 0; I < nrb; ++I) {
-            const double* src = hd.mpack + (size_t)I * nslab2 * 128;
-            double* dst = a_l + (size_t)tri_offset(I) * 128;
-            for (int k = tid; k < (2 * I + 2) * 128; k += 64 * WAVES) dst[k] = src[k];
+    {
+        double* dst = smem;
+        for (int h = 0; h < nheads; ++h) {
+            const SlGpHeadDev& hd = gp.head[h];
+            const int n_pad = hd.n_pad, nrb = n_pad / 16;
+            for (int k = tid; k < p * n_pad; k += 64 * WAVES) dst[k] = hd.xs[k];
+            dst += (p * n_pad + 1) & ~1;
+            for (int k = tid; k < n_pad * hd.dout; k += 64 * WAVES) dst[k] = hd.alpha[k];
+            dst += (n_pad * hd.dout + 1) & ~1;
+            if (ALDS) {
+                // row block I, slab pair s2 (s2 <= 2 I + 1): 128 doubles at tri_offset(I) + s2
+                for (int I = 0; I < nrb; ++I) {
+                    const double* src = hd.mpack + (size_t)I * hd.nslab2 * 128;
+                    double* to = dst + (size_t)tri_offset(I) * 128;
+                    for (int k = tid; k < (2 * I + 2) * 128; k += 64 * WAVES) to[k] = src[k];
+                }
+                dst += (size_t)tri_offset(nrb) * 128;
+            }
         }
     }
     __syncthreads();
 
     uint64_t best_v = ~0ull;
     int64_t best_i = INT64_MAX;
-    const double variance = hd.variance;
-    const int npass = (nrb + PRB - 1) / PRB;
 
     for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles;
          tile += (int64_t)gridDim.x * WAVES) {
@@ -94,6 +102,19 @@ __global__ __launch_bounds__(64 * gps::WAVES) void k_gp_small(
         sl_cell_state(M, d, gidx, points, x);
         sl_policy_any<GENERAL>(M, nd, aux.tri, gidx, x, u);
         sl_append_action(nd, u, x);
+
+        const double* head_base = smem;
+        for (int h = 0; h < nheads; ++h) {
+        const SlGpHeadDev& hd = gp.head[h];
+        const int n_pad = hd.n_pad, dout = hd.dout, nslab2 = hd.nslab2, col0 = hd.col0;
+        const int nrb = n_pad / 16, npass = (nrb + PRB - 1) / PRB;
+        const double variance = hd.variance;
+        const double* xs_l = head_base;                              // [p][n_pad]
+        const double* alpha_l = xs_l + ((p * n_pad + 1) & ~1);       // [n_pad][dout]
+        const double* a_l = alpha_l + ((n_pad * dout + 1) & ~1);     // lower-triangle fragments (ALDS)
+        head_base = a_l + (ALDS ? (size_t)tri_offset(nrb) * 128 : 0);
+        // this head's scaled inputs of the tile's cells (own lengthscales per head)
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < SL_P; ++q)
             if (q < p) cin[lane * p + q] = x[q] * hd.inv_ls[q];
@@ -180,10 +201,20 @@ __global__ __launch_bounds__(64 * gps::WAVES) void k_gp_small(
                     ssq_w[c] = (pass == 0 ? 0.0 : ssq_w[c]) + ss;
 #pragma unroll
                     for (int dd = 0; dd < SL_D; ++dd)
-                        if (dd < dout) mean_w[c * d + dd] = (pass == 0 ? 0.0 : mean_w[c * d + dd]) + gm[dd];
+                        if (dd < dout)
+                            mean_w[c * d + col0 + dd] = (pass == 0 ? 0.0 : mean_w[c * d + col0 + dd]) + gm[dd];
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        {   // this head's error bound for its output columns (lane = cell)
+            const double var = variance - ssq_w[lane];                     // functions.py:451
+            const double e = gp.beta * sqrt(var);                          // functions.py:514
+#pragma unroll
+            for (int dd = 0; dd < SL_D; ++dd)
+                if (dd < dout) err_w[lane * d + col0 + dd] = e;
+        }
+        }   // heads
         __builtin_amdgcn_wave_barrier();
 
         // ---- per-cell decrease check (lane = cell), mask word, failing-cell key ----------------------
@@ -191,14 +222,12 @@ __global__ __launch_bounds__(64 * gps::WAVES) void k_gp_small(
         double v_x = 0.0;
         {
             double prior[SL_D], mean[SL_D], err[SL_D];
-            const double var = variance - ssq_w[lane];                     // functions.py:451
-            const double e = gp.beta * sqrt(var);                          // functions.py:514
             sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);   // m(x*), functions.py:439
 #pragma unroll
             for (int k = 0; k < SL_D; ++k) {
                 if (k < d) {
                     mean[k] = mean_w[lane * d + k] + prior[k];
-                    err[k] = e;
+                    err[k] = err_w[lane * d + k];
                 }
             }
             if (valid) {
@@ -229,13 +258,16 @@ __global__ __launch_bounds__(64 * gps::WAVES) void k_gp_small(
 // =============================================================================================
 // host side
 // =============================================================================================
-// models the kernel takes: one head with a padded capacity of at most 256 training points
+// models the kernel takes: every head with a padded capacity of at most 256 training points
 bool sl_gp_small_supports(sl_ctx* ctx, const SlDevModel& model) {
     const char* env = getenv("SL_GP_SMALL");
     if (env && env[0] == '0') return false;
-    if (ctx->h_gp.nheads != 1) return false;
-    const SlGpHeadHost& h = ctx->gp_heads[0];
-    return h.set && h.n_pad <= 256 && h.n_pad % 16 == 0 && h.p == model.in_dim;
+    if (ctx->h_gp.nheads < 1) return false;
+    for (int k = 0; k < ctx->h_gp.nheads; ++k) {
+        const SlGpHeadHost& h = ctx->gp_heads[k];
+        if (!h.set || h.n_pad > 256 || h.n_pad % 16 || h.p != model.in_dim) return false;
+    }
+    return true;
 }
 
 template <bool GENERAL, int DT, int MT>
@@ -243,20 +275,22 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
                         const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
                         int* nblocks, double* d_dbg, const double* d_points) {
     using namespace gps;
-    const SlGpHeadHost& h = ctx->gp_heads[0];
     const int p = model.in_dim, d = model.m.grid.d;
     const int64_t ntiles = (hi - lo + 63) / 64;
-    const int xs_doubles = (p * h.n_pad + 1) & ~1;
-    const int alpha_doubles = (h.n_pad * h.dout + 1) & ~1;
-    const int nrb = h.n_pad / 16;
-    const size_t base = sizeof(double) * ((size_t)xs_doubles + alpha_doubles + (size_t)WAVES * 64 * (p + 1 + d));
-    const size_t tri = sizeof(double) * (size_t)tri_offset(nrb) * 128;
+    // per head: scaled inputs, alpha' and (when everything fits) the factor's lower triangle
+    size_t small = 0, tri = 0;
+    for (int k = 0; k < ctx->h_gp.nheads; ++k) {
+        const SlGpHeadHost& h = ctx->gp_heads[k];
+        small += (size_t)((p * h.n_pad + 1) & ~1) + (size_t)((h.n_pad * h.dout + 1) & ~1);
+        tri += (size_t)tri_offset(h.n_pad / 16) * 128;
+    }
+    const size_t scratch = (size_t)WAVES * 64 * (p + 1 + 2 * d);
     const size_t cap = 160 * 1024 - (GENERAL ? sizeof(SlTriLds<true>) : 0) - 256;
-    const bool alds = base + tri <= cap;
-    const size_t lds = base + (alds ? tri : 0);
+    const bool alds = sizeof(double) * (small + tri + scratch) <= cap;
+    const int head_doubles = (int)(small + (alds ? tri : 0));
+    const size_t lds = sizeof(double) * ((size_t)head_doubles + scratch);
     if (lds > cap)
         return sl_fail(ctx, SL_ERR_UNSUPPORTED, "k_gp_small: %zu bytes of LDS needed", lds);
-    const int a_doubles = alds ? tri_offset(nrb) * 128 : 0;
     int64_t blocks = (ntiles + WAVES - 1) / WAVES;
     if (blocks > ctx->num_cu) blocks = ctx->num_cu;
     if (blocks < 1) blocks = 1;
@@ -269,13 +303,13 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), lds, ctx->stream, model, \
                            ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,      \
-                           ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, a_doubles, d_points); \
+                           ctx->d_partials, d_dbg, head_doubles, d_points);                     \
     } while (0)
     if (alds) SL_GPS_GO(true); else SL_GPS_GO(false);
 #undef SL_GPS_GO
     SL_HIP_CHECK(ctx, hipGetLastError());
-    sl_note_kernel(ctx, false, "k_gp_small<general=%d, d=%d, m=%d, Linv in %s>", (int)GENERAL, DT, MT,
-                   alds ? "LDS" : "L2");
+    sl_note_kernel(ctx, false, "k_gp_small<general=%d, d=%d, m=%d, Linv in %s> (%d head(s))", (int)GENERAL, DT,
+                   MT, alds ? "LDS" : "L2", ctx->h_gp.nheads);
     return SL_OK;
 }
 
