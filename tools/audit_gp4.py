@@ -20,7 +20,8 @@ def _touches_owned(code, owned):
 
 
 def audit(path, prefix="_Z11k_gp_sweep4", min_loops=8, owned=256):
-    text = open(path).read()
+    with open(path) as f:
+        text = f.read()
     kernels = re.split(r"\n(?=" + prefix + ")", text)
     problems, report = [], []
     for chunk in kernels:
@@ -102,7 +103,8 @@ def audit_in_place(path, prefix="_Z10k_bellman4"):
     accumulator inside the MFMA loop would read a result the hardware has not retired yet (no
     interlock for the asm's outputs).  Check, per instantiation, that the innermost loop with MFMAs
     holds nothing but in-place MFMAs, LDS fragment reads, buffer loads and scalar instructions."""
-    text = open(path).read()
+    with open(path) as f:
+        text = f.read()
     report, problems = [], []
     for chunk in re.split(r"\n(?=" + prefix + ")", text):
         m = re.match(r"(" + prefix + r"\w+):", chunk)
