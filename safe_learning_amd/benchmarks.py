@@ -152,7 +152,7 @@ def headline_case(num_points=128, n_gp=1024, family='cartpole', stack=False, var
 
 
 def table_case(num_points=(2001, 1501), table_points=(101, 101), n_gp=128, tau_scale=0.0005,
-               dynamics=None, stack=False):
+               dynamics=None, stack=False, limits=None):
     """The table-V / table-policy Lyapunov sweep of ``inverted_pendulum.ipynb`` (cell 14:
     ``lyapunov_function = -rl.value_function``, ``L_v = |gradient|``, the policy a Triangulation
     on the value grid; ``:112`` runs it on 2001 x 1501 cells): pendulum, RBF GP dynamics, V a
@@ -160,6 +160,8 @@ def table_case(num_points=(2001, 1501), table_points=(101, 101), n_gp=128, tau_s
     saturated LQR law sampled on the same table grid."""
     case = make_case('pendulum', num_points=list(num_points), n_gp=n_gp, tau_scale=tau_scale,
                      dynamics=dynamics, stack=stack, **GP_VARIANTS['informed'])
+    if limits is not None:
+        case['limits'] = [[float(lo), float(hi)] for lo, hi in limits]
     axes = [np.linspace(lo, hi, n) for (lo, hi), n in zip(case['limits'], table_points)]
     pts = np.stack(np.meshgrid(*axes, indexing='ij'), axis=-1).reshape(-1, case['d'])
     vals = np.einsum('ij,jk,ik->i', pts, case['P'], pts)
