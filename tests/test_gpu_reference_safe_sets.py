@@ -7,7 +7,8 @@ build container (``tests/golden/make_reference_safe_sets.py``).  Every scenario 
 with the FIXTURE, not with the oracle:
 
  * deterministic dynamics (linear, Euler pendulum): safe set, ``c_max``, refinement and value
-   table bit for bit;
+   table bit for bit (a table V interpolated between its vertices: values and ``c_max`` within
+   1e-12 relative, the safe set equal);
  * GP dynamics: the posterior differs from NumPy's in the last bits (matrix-pipe summation
    order), so a cell whose decrease sits within 1e-9 relative of its threshold may flip.  The
    oracle is consulted for exactly one thing: which cells are that close.  If there are none the
@@ -78,8 +79,16 @@ def test_engine_equals_the_reference_run(entry, batch_size):
     initial = None if meta.get("no_initial_set") else cases.initial_safe_mask(case)
     lyap = sl.Lyapunov(grid, value, dynamics, case["lf"], lv, case["tau"], policy,
                        initial_set=initial, adaptive=bool(meta.get("adaptive")))
-    assert_array_equal(lyap.values, FIXTURE[name + "/values"])
-    assert sl.smallest_boundary_value(value, grid) == float(FIXTURE[name + "/boundary"])
+    table_v = case.get("V", {}).get("kind") == "table"
+    if table_v:
+        # a table on a coarser grid than the discretization: the engine's barycentric weights
+        # differ from the reference's hyperplane products in the last bits
+        assert_allclose(lyap.values, FIXTURE[name + "/values"], rtol=1e-12, atol=1e-14)
+        assert_allclose(sl.smallest_boundary_value(value, grid), float(FIXTURE[name + "/boundary"]),
+                        rtol=1e-12)
+    else:
+        assert_array_equal(lyap.values, FIXTURE[name + "/values"])
+        assert sl.smallest_boundary_value(value, grid) == float(FIXTURE[name + "/boundary"])
 
     records = GENERATOR.replay(meta, lyap, dynamics, sl.get_safe_sample, lambda obj: obj.c_max)
     assert len(records) == entry["records"]
@@ -89,7 +98,10 @@ def test_engine_equals_the_reference_run(entry, batch_size):
             want = {key: FIXTURE["%s/step%d/%s" % (name, k, key)] for key in record}
             if "safe_set" in record:
                 assert_array_equal(record["safe_set"], want["safe_set"])
-                assert record["c_max"] == want["c_max"]
+                if table_v:
+                    assert_allclose(record["c_max"], want["c_max"], rtol=1e-12)
+                else:
+                    assert record["c_max"] == want["c_max"]
                 if not hand_marked:
                     # (cells marked safe by hand keep refinement 0 in the reference; the engine
                     # keeps no refinement array outside the adaptive branch: N(x) = safe(x))
