@@ -1,0 +1,260 @@
+"""Value tables and greedy policies computed BY THE REFERENCE'S OWN ``reinforcement_learning.py``
+(build container only).
+
+``PolicyIteration.__init__`` / ``future_values`` / ``bellmann_error`` / ``value_iteration`` /
+``discrete_policy_optimization`` (``reinforcement_learning.py:46-140, 213-279``) run unmodified,
+loaded from ``/root/reference``; where a scenario passes ``lyapunov=`` the penalty terms come from
+the reference's ``Lyapunov.v_decrease_bound`` / ``threshold`` (``lyapunov.py:265-376``).  The
+TensorFlow ops they request (``tf.stack``, ``tf.assign``, ``tf.placeholder``, ``tf.stop_gradient``,
+``tf.square``, ``tf.reduce_sum`` and the arithmetic operators) are answered by the deferred-NumPy
+stand-in of ``make_reference_safe_sets.py``; a ``tf.Variable`` is a node that returns its current
+array and ``tf.assign(...).eval()`` replaces it.  ``optimize_value_function`` (cvxpy) is out of
+scope.
+
+The LEAF functions (policy table, dynamics, reward, value table) are the oracle's NumPy callables
+behind a graph-function wrapper; the value function and the policy are ``oracle.Triangulation``
+objects whose vertex values are the assigned variable.  The fixture therefore pins the
+COMPOSITION: the Jacobi semantics of ``value_iteration`` (every read sees the old table), mean-only
+use of uncertain dynamics, the discount, the Lyapunov penalty, the per-action loop, the
+``constraint`` callback and the first-maximum rule of ``discrete_policy_optimization``.
+``tests/test_oracle_reference_policy_iteration.py`` replays every scenario on
+``oracle.PolicyIteration`` and compares bit for bit.
+
+    python tests/golden/make_reference_policy_iteration.py          (needs /root/reference)
+"""
+
+import json
+import os
+import sys
+
+import numpy as np
+import scipy.linalg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import make_reference_safe_sets as lazy_tf          # noqa: E402
+from make_reference_safe_sets import Lazy, evaluate, jsonable, from_jsonable   # noqa: E402,F401
+
+OUT = os.path.join(HERE, "reference_policy_iteration.npz")
+
+
+class Variable(Lazy):
+    """``tf.Variable``: evaluates to its current array."""
+
+    def __init__(self, value):
+        self.value = np.array(value, dtype=np.float64)
+        Lazy.__init__(self, lambda: self.value, (), self.value.shape)
+
+
+def install_variable_ops(tf):
+    def assign(variable, value, name=None):
+        def store(new):
+            variable.value = np.array(new, dtype=np.float64).reshape(variable.value.shape)
+            return variable.value
+        return Lazy(store, (value,), variable.shape)
+    tf.assign = assign
+    tf.stop_gradient = lambda x: x
+    tf.square = lambda x: Lazy(np.square, (x,), lazy_tf._shape_of(x))
+    tf.stack = lambda xs, axis=0, name=None: lazy_tf.constant(np.stack(xs, axis=axis))
+    plain_sum = tf.reduce_sum
+    tf.reduce_sum = lambda x, axis=None, keepdims=False, name=None: plain_sum(x, axis, keepdims)
+
+
+class LazyTable(object):
+    """An ``oracle.Triangulation`` as a graph function with one variable (the vertex values),
+    the interface ``PolicyIteration`` uses: ``.discretization``, ``.parameters[0]``, call."""
+
+    def __init__(self, table):
+        self.table = table
+        self.discretization = table.discretization
+        self.parameters = [Variable(table.parameters)]
+
+    def _evaluate(self, points, vertex_values):
+        self.table.parameters = vertex_values
+        return self.table(points)
+
+    def __call__(self, points):
+        return Lazy(self._evaluate, (points, self.parameters[0]), (None, self.table.output_dim))
+
+
+# --------------------------------------------------------------------------------------
+# Scenarios
+# --------------------------------------------------------------------------------------
+
+def scenarios():
+    """-> list of dicts: name, case (tests/cases.py parameters or the 1-D LQR system), value grid,
+    policy grid, reward matrix, gamma, initial tables, steps."""
+    from safe_learning_amd.benchmarks import GP_VARIANTS, make_case
+    rng = np.random.default_rng(11)
+    out = []
+
+    def entry(name, case, value_points, policy_points, steps, gamma=0.98, policy_values=None,
+              lyapunov=False):
+        d = case["d"]
+        limits = case["limits"]
+        nv = int(np.prod(np.broadcast_to(value_points, (d,))))
+        npol = int(np.prod(np.broadcast_to(policy_points, (d,))))
+        qmat = -scipy.linalg.block_diag(np.diag(1.0 + 0.5 * np.arange(d)), 0.1 * np.eye(1))
+        out.append(dict(name=name, case=case, gamma=gamma, reward=qmat, limits=limits,
+                        value_points=list(np.broadcast_to(value_points, (d,)).astype(int).tolist()),
+                        policy_points=list(np.broadcast_to(policy_points, (d,)).astype(int).tolist()),
+                        value_table=-rng.random((nv, 1)),
+                        policy_table=(rng.uniform(-1, 1, (npol, 1)) if policy_values is None
+                                      else policy_values),
+                        lyapunov=lyapunov, steps=steps))
+
+    # the system of the reference's test_rl.py:29-77 (19-vertex value table, 5-vertex policy)
+    a, b, q, r = 1.2, 0.9, 1.0, 0.1
+    lqr = dict(name="1d_lqr", d=1, m=1, limits=[[-1.0, 1.0]], saturate=None, K=np.array([[-0.9]]),
+               dynamics={"kind": "linear", "matrix": np.array([[a, b]])}, P=np.array([[1.0]]),
+               lv=("const", 1.0), lf=1.0, tau=0.1, num_points=[19], stack=False)
+    entry("1d_lqr", lqr, 19, 5,
+          [("vi", 12), ("dpo", np.linspace(-1, 1, 11)[:, None], None), ("vi", 6),
+           ("dpo", np.linspace(-1, 1, 4)[:, None], None), ("vi", 3)],
+          policy_values=-0.9 * np.linspace(-1, 1, 5)[:, None])
+
+    actions9 = np.linspace(-1, 1, 9)[:, None]
+    case = make_case("pendulum", num_points=13, dynamics="analytic")
+    entry("pendulum_analytic", case, 13, 13,
+          [("vi", 3), ("dpo", actions9, None), ("vi", 4), ("dpo", actions9, None), ("vi", 2),
+           ("fv", dict(states=rng.uniform(-0.9, 0.9, (40, 2)))),
+           ("fv", dict(states=rng.uniform(-0.9, 0.9, (40, 2)), actions=rng.uniform(-1, 1, (40, 1)))),
+           ("bellman", rng.uniform(-0.9, 0.9, (60, 2)))], gamma=0.95)
+
+    # value table finer than the policy table; two equal actions (first maximum wins)
+    case = make_case("pendulum", num_points=[9, 17], dynamics="linear")
+    entry("pendulum_linear_ties", case, [9, 17], [5, 7],
+          [("dpo", np.array([[0.5], [-0.25], [0.5], [0.0]]), None), ("vi", 3)])
+
+    hyper = GP_VARIANTS["tight"]
+    case = make_case("pendulum", num_points=11, n_gp=50, **hyper)
+    entry("pendulum_gp_constraint", case, 11, 11,
+          [("vi", 2), ("dpo", np.linspace(-1, 1, 7)[:, None], "outwards"), ("vi", 3),
+           ("dpo", np.linspace(-1, 1, 7)[:, None], "all_but_one"), ("vi", 1)], gamma=0.9)
+
+    case = make_case("pendulum", num_points=11, n_gp=50, **hyper)
+    entry("pendulum_gp_lyapunov", case, 11, 11,
+          [("vi", 2),
+           ("fv", dict(lyapunov=True, lagrange_multiplier=0.7)),
+           ("fv", dict(lyapunov=True, lagrange_multiplier=2.5, actions=np.array([[0.3]])))],
+          gamma=0.95, lyapunov=True)
+
+    case = make_case("cartpole", num_points=5, n_gp=60, stack=True, **hyper)
+    entry("cartpole_gp_stack", case, 5, 5,
+          [("dpo", np.linspace(-1, 1, 5)[:, None], None), ("vi", 2)], gamma=0.95)
+
+    case = make_case("cartpole", num_points=[3, 4, 3, 5], dynamics="analytic")
+    entry("cartpole_analytic", case, [3, 4, 3, 5], [3, 4, 3, 5],
+          [("vi", 2), ("dpo", np.linspace(-1, 1, 6)[:, None], None), ("vi", 2)], gamma=0.95)
+    return out
+
+
+def constraint_function(kind, states):
+    """Slack callbacks of ``discrete_policy_optimization`` (``:272-275``), >= 0 is feasible."""
+    if kind is None:
+        return None
+    if kind == "outwards":                      # rules out pushing away from the origin
+        return lambda action_array: -(action_array[:, 0] * states[:, 0]) + 0.05
+    if kind == "all_but_one":                   # every action infeasible except one per vertex
+        return lambda action_array: np.where(
+            np.abs(action_array[:, 0] - np.sign(states[:, 1] + 1e-3) * (1.0 / 3.0)) < 1e-9, 1.0, -1.0)
+    raise ValueError(kind)
+
+
+def replay(scenario, rl, value_table, policy_table, all_states, lyapunov, run, evaluate_fv):
+    """Steps on a PolicyIteration object (reference's or oracle's) -> list of recorded arrays.
+    ``run(op)`` executes what ``value_iteration`` returns (an assign op / nothing),
+    ``value_table()`` / ``policy_table()`` return the current vertex values,
+    ``evaluate_fv(x)`` turns the result of ``future_values`` / ``bellmann_error`` into an array."""
+    records = []
+    for step in scenario["steps"]:
+        kind = step[0]
+        if kind == "vi":
+            for _ in range(step[1]):
+                run(rl.value_iteration())
+                records.append(value_table().copy())
+        elif kind == "dpo":
+            rl.discrete_policy_optimization(step[1],
+                                            constraint=constraint_function(step[2], all_states))
+            records.append(policy_table().copy())
+        elif kind == "fv":
+            arg = dict(step[1])
+            states = arg.pop("states", all_states)
+            if arg.pop("lyapunov", False):
+                arg["lyapunov"] = lyapunov
+            if "actions" in arg and len(arg["actions"]) == 1:
+                arg["actions"] = np.broadcast_to(arg["actions"], (len(states), 1))
+            records.append(np.asarray(evaluate_fv(rl.future_values(states, **arg))))
+        elif kind == "bellman":
+            records.append(np.asarray(evaluate_fv(rl.bellmann_error(step[1]))))
+        else:
+            raise ValueError(kind)
+    return records
+
+
+def build_oracle_leaves(scenario):
+    """-> (policy table, dynamics, reward, value table, lyapunov pieces) as oracle objects."""
+    import oracle
+    from tests import cases
+    case = scenario["case"]
+    _, dynamics, lyapunov_value, lv = cases.oracle_specs(case)
+    vgrid = oracle.GridWorld(scenario["limits"], scenario["value_points"])
+    pgrid = oracle.GridWorld(scenario["limits"], scenario["policy_points"])
+    value = oracle.Triangulation(vgrid, scenario["value_table"], project=True)
+    policy = oracle.Triangulation(pgrid, scenario["policy_table"])
+    reward = oracle.QuadraticFunction(scenario["reward"])
+    return policy, dynamics, reward, value, (lyapunov_value, lv)
+
+
+def main():
+    functions, lyapunov_module = lazy_tf.load_reference()
+    tf = sys.modules["tensorflow"]
+    install_variable_ops(tf)
+    ref = lazy_tf.ref_loader
+    spec = ref.importlib.util.spec_from_file_location(
+        "safe_learning.reinforcement_learning", os.path.join(ref.REF, "reinforcement_learning.py"))
+    module = ref.importlib.util.module_from_spec(spec)
+    ref._armed[0] = False
+    spec.loader.exec_module(module)           # (`import cvxpy` fails: kept as the ImportError)
+    ref._armed[0] = True
+
+    arrays, index = {}, []
+    for scenario in scenarios():
+        name, case = scenario["name"], scenario["case"]
+        policy, dynamics, reward, value, (lyap_value, lv) = build_oracle_leaves(scenario)
+        d = case["d"]
+        uncertain = case["dynamics"]["kind"] == "gp"
+        lazy_value, lazy_policy = LazyTable(value), LazyTable(policy)
+        lazy_dynamics = lazy_tf.lazy_function(dynamics, d, uncertain)
+        rl = module.PolicyIteration(lazy_policy, lazy_dynamics, lazy_tf.lazy_function(reward, 1),
+                                    lazy_value, gamma=scenario["gamma"])
+        lyap = None
+        if scenario["lyapunov"]:
+            grid = functions.GridWorld(scenario["limits"], scenario["value_points"])
+            lyap = lyapunov_module.Lyapunov(
+                grid, lazy_tf.lazy_function(lyap_value, 1), lazy_dynamics, case["lf"],
+                lazy_tf.lazy_function(lv, d) if callable(lv) else lv, case["tau"], lazy_policy)
+        records = replay(scenario, rl, lambda: lazy_value.parameters[0].value,
+                         lambda: lazy_policy.parameters[0].value,
+                         value.discretization.all_points, lyap,
+                         run=lambda op: op.eval(rl.feed_dict),
+                         evaluate_fv=lambda node: node.eval(rl.feed_dict))
+        for k, record in enumerate(records):
+            arrays["%s/record%d" % (name, k)] = record
+        meta = dict(scenario)
+        meta["steps"] = [list(step) for step in scenario["steps"]]
+        index.append(dict(scenario=jsonable(meta, arrays, name + "/scenario"), records=len(records)))
+        print("%-26s records %2d  value table [%.4g, %.4g]  policy table: %d distinct actions"
+              % (name, len(records), lazy_value.parameters[0].value.min(),
+                 lazy_value.parameters[0].value.max(),
+                 len(np.unique(lazy_policy.parameters[0].value))))
+    arrays["_index"] = np.array(json.dumps(index))
+    np.savez_compressed(OUT, **arrays)
+    print("wrote %s (%d arrays, %.1f KiB)" % (OUT, len(arrays), os.path.getsize(OUT) / 1024.0))
+
+
+if __name__ == "__main__":
+    main()

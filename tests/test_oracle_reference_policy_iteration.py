@@ -1,0 +1,102 @@
+"""The oracle's ``PolicyIteration`` against tables computed by the reference's own
+``reinforcement_learning.py``.
+
+``tests/golden/reference_policy_iteration.npz`` was produced in the build container by
+``tests/golden/make_reference_policy_iteration.py``: the reference's ``PolicyIteration``
+(``reinforcement_learning.py:46-140, 213-279``; the Lyapunov penalty through the reference's
+``lyapunov.py:265-376``) executed unmodified with a deferred-NumPy stand-in answering its
+TensorFlow ops and the oracle's leaf functions as tables / dynamics / reward.  Every scenario
+(parameters stored in the fixture) is replayed on ``oracle.PolicyIteration`` through the same
+step driver; the value table after every ``value_iteration``, the policy table after every
+``discrete_policy_optimization`` and every ``future_values`` / ``bellmann_error`` result must be
+equal bit for bit.
+"""
+
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+from numpy.testing import assert_equal
+
+import oracle
+
+import cases
+from conftest import GOLDEN_DIR
+
+
+def _generator():
+    sys.path.insert(0, GOLDEN_DIR)
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "make_reference_policy_iteration",
+            os.path.join(GOLDEN_DIR, "make_reference_policy_iteration.py"))
+        module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(module)
+    finally:
+        sys.path.remove(GOLDEN_DIR)
+    return module
+
+
+GENERATOR = _generator()
+FIXTURE = np.load(os.path.join(GOLDEN_DIR, "reference_policy_iteration.npz"))
+INDEX = json.loads(str(FIXTURE["_index"]))
+NAMES = [entry["scenario"]["name"] for entry in INDEX]
+
+
+def _scenario(entry):
+    scenario = GENERATOR.from_jsonable(entry["scenario"], FIXTURE)
+    scenario["steps"] = [tuple(step) for step in scenario["steps"]]
+    return scenario
+
+
+def test_fixture_covers_the_scenarios_of_the_generator():
+    assert NAMES == [s["name"] for s in GENERATOR.scenarios()]
+    assert len(NAMES) >= 7
+
+
+@pytest.mark.parametrize("entry", INDEX, ids=NAMES)
+def test_tables_equal_the_reference_run(entry):
+    scenario = _scenario(entry)
+    name, case = scenario["name"], scenario["case"]
+    policy, dynamics, reward, value, (lyap_value, lv) = GENERATOR.build_oracle_leaves(scenario)
+    rl = oracle.PolicyIteration(policy, dynamics, reward, value, gamma=scenario["gamma"])
+    lyap = None
+    if scenario["lyapunov"]:
+        grid = oracle.GridWorld(scenario["limits"], scenario["value_points"])
+        lyap = oracle.Lyapunov(grid, lyap_value, dynamics, case["lf"], lv, case["tau"], policy)
+    records = GENERATOR.replay(scenario, rl, lambda: value.parameters, lambda: policy.parameters,
+                               value.discretization.all_points, lyap,
+                               run=lambda op: None, evaluate_fv=lambda result: result)
+    assert len(records) == entry["records"]
+    for k, got in enumerate(records):
+        assert_equal(got, FIXTURE["%s/record%d" % (name, k)], err_msg="%s record %d" % (name, k))
+
+
+def test_scenarios_are_not_vacuous():
+    """Constraints rule actions out, the tie scenario has a tie, the penalty changes the values."""
+    by_name = {entry["scenario"]["name"]: _scenario(entry) for entry in INDEX}
+    sc = by_name["pendulum_gp_constraint"]
+    policy, dynamics, reward, value, _ = GENERATOR.build_oracle_leaves(sc)
+    rl = oracle.PolicyIteration(policy, dynamics, reward, value, gamma=sc["gamma"])
+    x = value.discretization.all_points
+    for kind in ("outwards", "all_but_one"):
+        q, _ = rl.discrete_policy_optimization(np.linspace(-1, 1, 7)[:, None],
+                                               constraint=GENERATOR.constraint_function(kind, x))
+        assert np.isinf(q).any() and not np.isinf(q).all(axis=1).any()
+    sc = by_name["pendulum_linear_ties"]
+    policy, dynamics, reward, value, _ = GENERATOR.build_oracle_leaves(sc)
+    rl = oracle.PolicyIteration(policy, dynamics, reward, value, gamma=sc["gamma"])
+    q, best = rl.discrete_policy_optimization(sc["steps"][0][1])
+    assert (q[:, 0] == q[:, 2]).all() and (best == 0).any() and not (best == 2).any()
+    sc = by_name["pendulum_gp_lyapunov"]
+    index = NAMES.index("pendulum_gp_lyapunov")
+    penalised = FIXTURE["pendulum_gp_lyapunov/record%d" % (INDEX[index]["records"] - 2)]
+    policy, dynamics, reward, value, _ = GENERATOR.build_oracle_leaves(sc)
+    rl = oracle.PolicyIteration(policy, dynamics, reward, value, gamma=sc["gamma"])
+    rl.value_iteration()
+    rl.value_iteration()
+    plain = rl.future_values(value.discretization.all_points)
+    assert np.max(np.abs(plain - penalised)) > 1e-3
