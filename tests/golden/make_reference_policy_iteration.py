@@ -1,24 +1,20 @@
-"""Value tables and greedy policies computed BY THE REFERENCE'S OWN ``reinforcement_learning.py``
-(build container only).
+"""Value tables and greedy policies computed BY THE REFERENCE'S OWN CODE (build container only).
 
 ``PolicyIteration.__init__`` / ``future_values`` / ``bellmann_error`` / ``value_iteration`` /
 ``discrete_policy_optimization`` (``reinforcement_learning.py:46-140, 213-279``) run unmodified,
-loaded from ``/root/reference``; where a scenario passes ``lyapunov=`` the penalty terms come from
-the reference's ``Lyapunov.v_decrease_bound`` / ``threshold`` (``lyapunov.py:265-376``).  The
-TensorFlow ops they request (``tf.stack``, ``tf.assign``, ``tf.placeholder``, ``tf.stop_gradient``,
-``tf.square``, ``tf.reduce_sum`` and the arithmetic operators) are answered by the deferred-NumPy
-stand-in of ``make_reference_safe_sets.py``; a ``tf.Variable`` is a node that returns its current
-array and ``tf.assign(...).eval()`` replaces it.  ``optimize_value_function`` (cvxpy) is out of
-scope.
+loaded from ``/root/reference``, on the reference's own ``Triangulation`` objects (value function
+and policy: ``tf.Variable`` vertex values, ``tf.assign``), ``QuadraticFunction`` reward and
+``LinearSystem`` / ``InvertedPendulum`` / ``CartPole`` dynamics; where a scenario passes
+``lyapunov=`` the penalty terms come from the reference's ``Lyapunov.v_decrease_bound`` /
+``threshold`` (``lyapunov.py:265-376``).  ``tests/golden/numpy_tf.py`` answers the TensorFlow ops;
+a GP dynamics model is the oracle's callable (gpflow is absent), as in
+``make_reference_safe_sets.py``.  ``optimize_value_function`` (cvxpy) is out of scope.
 
-The LEAF functions (policy table, dynamics, reward, value table) are the oracle's NumPy callables
-behind a graph-function wrapper; the value function and the policy are ``oracle.Triangulation``
-objects whose vertex values are the assigned variable.  The fixture therefore pins the
-COMPOSITION: the Jacobi semantics of ``value_iteration`` (every read sees the old table), mean-only
-use of uncertain dynamics, the discount, the Lyapunov penalty, the per-action loop, the
-``constraint`` callback and the first-maximum rule of ``discrete_policy_optimization``.
-``tests/test_oracle_reference_policy_iteration.py`` replays every scenario on
-``oracle.PolicyIteration`` and compares bit for bit.
+Pinned this way: the Jacobi semantics of ``value_iteration`` (every read sees the old table),
+mean-only use of uncertain dynamics, the discount, the Lyapunov penalty, the per-action loop, the
+``constraint`` callback and the first-maximum rule of ``discrete_policy_optimization``, on top of
+the table interpolation itself.  ``tests/test_oracle_reference_policy_iteration.py`` replays every
+scenario on ``oracle.PolicyIteration`` and compares bit for bit.
 
     python tests/golden/make_reference_policy_iteration.py          (needs /root/reference)
 """
@@ -35,49 +31,10 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
-import make_reference_safe_sets as lazy_tf          # noqa: E402
-from make_reference_safe_sets import Lazy, evaluate, jsonable, from_jsonable   # noqa: E402,F401
+import numpy_tf                                                     # noqa: E402
+from make_reference_safe_sets import jsonable, from_jsonable, reference_specs   # noqa: E402,F401
 
 OUT = os.path.join(HERE, "reference_policy_iteration.npz")
-
-
-class Variable(Lazy):
-    """``tf.Variable``: evaluates to its current array."""
-
-    def __init__(self, value):
-        self.value = np.array(value, dtype=np.float64)
-        Lazy.__init__(self, lambda: self.value, (), self.value.shape)
-
-
-def install_variable_ops(tf):
-    def assign(variable, value, name=None):
-        def store(new):
-            variable.value = np.array(new, dtype=np.float64).reshape(variable.value.shape)
-            return variable.value
-        return Lazy(store, (value,), variable.shape)
-    tf.assign = assign
-    tf.stop_gradient = lambda x: x
-    tf.square = lambda x: Lazy(np.square, (x,), lazy_tf._shape_of(x))
-    tf.stack = lambda xs, axis=0, name=None: lazy_tf.constant(np.stack(xs, axis=axis))
-    plain_sum = tf.reduce_sum
-    tf.reduce_sum = lambda x, axis=None, keepdims=False, name=None: plain_sum(x, axis, keepdims)
-
-
-class LazyTable(object):
-    """An ``oracle.Triangulation`` as a graph function with one variable (the vertex values),
-    the interface ``PolicyIteration`` uses: ``.discretization``, ``.parameters[0]``, call."""
-
-    def __init__(self, table):
-        self.table = table
-        self.discretization = table.discretization
-        self.parameters = [Variable(table.parameters)]
-
-    def _evaluate(self, points, vertex_values):
-        self.table.parameters = vertex_values
-        return self.table(points)
-
-    def __call__(self, points):
-        return Lazy(self._evaluate, (points, self.parameters[0]), (None, self.table.output_dim))
 
 
 # --------------------------------------------------------------------------------------
@@ -210,35 +167,26 @@ def build_oracle_leaves(scenario):
 
 
 def main():
-    functions, lyapunov_module = lazy_tf.load_reference()
-    tf = sys.modules["tensorflow"]
-    install_variable_ops(tf)
-    ref = lazy_tf.ref_loader
-    spec = ref.importlib.util.spec_from_file_location(
-        "safe_learning.reinforcement_learning", os.path.join(ref.REF, "reinforcement_learning.py"))
-    module = ref.importlib.util.module_from_spec(spec)
-    ref._armed[0] = False
-    spec.loader.exec_module(module)           # (`import cvxpy` fails: kept as the ImportError)
-    ref._armed[0] = True
-
+    ref = numpy_tf.load_reference(examples=True)
+    F, module = ref.functions, ref.reinforcement_learning
     arrays, index = {}, []
     for scenario in scenarios():
         name, case = scenario["name"], scenario["case"]
-        policy, dynamics, reward, value, (lyap_value, lv) = build_oracle_leaves(scenario)
-        d = case["d"]
-        uncertain = case["dynamics"]["kind"] == "gp"
-        lazy_value, lazy_policy = LazyTable(value), LazyTable(policy)
-        lazy_dynamics = lazy_tf.lazy_function(dynamics, d, uncertain)
-        rl = module.PolicyIteration(lazy_policy, lazy_dynamics, lazy_tf.lazy_function(reward, 1),
-                                    lazy_value, gamma=scenario["gamma"])
+        _, oracle_dynamics, _, _ = build_oracle_leaves(scenario)[:4]
+        _, dynamics, lyap_value, lv = reference_specs(case, ref, oracle_dynamics)
+        value = F.Triangulation(F.GridWorld(scenario["limits"], scenario["value_points"]),
+                                scenario["value_table"], project=True)
+        policy = F.Triangulation(F.GridWorld(scenario["limits"], scenario["policy_points"]),
+                                 scenario["policy_table"])
+        reward = F.QuadraticFunction(scenario["reward"])
+        rl = module.PolicyIteration(policy, dynamics, reward, value, gamma=scenario["gamma"])
         lyap = None
         if scenario["lyapunov"]:
-            grid = functions.GridWorld(scenario["limits"], scenario["value_points"])
-            lyap = lyapunov_module.Lyapunov(
-                grid, lazy_tf.lazy_function(lyap_value, 1), lazy_dynamics, case["lf"],
-                lazy_tf.lazy_function(lv, d) if callable(lv) else lv, case["tau"], lazy_policy)
-        records = replay(scenario, rl, lambda: lazy_value.parameters[0].value,
-                         lambda: lazy_policy.parameters[0].value,
+            grid = F.GridWorld(scenario["limits"], scenario["value_points"])
+            lyap = ref.lyapunov.Lyapunov(grid, lyap_value, dynamics, case["lf"], lv, case["tau"],
+                                         policy)
+        records = replay(scenario, rl, lambda: value.parameters[0].value,
+                         lambda: policy.parameters[0].value,
                          value.discretization.all_points, lyap,
                          run=lambda op: op.eval(rl.feed_dict),
                          evaluate_fv=lambda node: node.eval(rl.feed_dict))
@@ -248,9 +196,8 @@ def main():
         meta["steps"] = [list(step) for step in scenario["steps"]]
         index.append(dict(scenario=jsonable(meta, arrays, name + "/scenario"), records=len(records)))
         print("%-26s records %2d  value table [%.4g, %.4g]  policy table: %d distinct actions"
-              % (name, len(records), lazy_value.parameters[0].value.min(),
-                 lazy_value.parameters[0].value.max(),
-                 len(np.unique(lazy_policy.parameters[0].value))))
+              % (name, len(records), value.parameters[0].value.min(),
+                 value.parameters[0].value.max(), len(np.unique(policy.parameters[0].value))))
     arrays["_index"] = np.array(json.dumps(index))
     np.savez_compressed(OUT, **arrays)
     print("wrote %s (%d arrays, %.1f KiB)" % (OUT, len(arrays), os.path.getsize(OUT) / 1024.0))

@@ -1,28 +1,29 @@
-"""Safe sets computed BY THE REFERENCE'S OWN ``lyapunov.py`` (build container only).
+"""Safe sets computed BY THE REFERENCE'S OWN CODE (build container only).
 
-What runs here is the reference's code, unmodified, loaded from ``/root/reference``:
-``Lyapunov.__init__`` / ``update_values`` / ``threshold`` / ``v_decrease_confidence`` /
-``v_decrease_bound`` / ``update_safe_set`` (``lyapunov.py:176-606``: the value sort, the
-batch loop, the prefix rule with its early exit, the ``c_max`` index arithmetic, the adaptive
-branch), ``smallest_boundary_value`` (``:22-56``), ``perturb_actions`` / ``get_safe_sample``
-(``:609-797``) and ``GridWorld`` (``functions.py:579-817``).
+What runs here, unmodified, loaded from ``/root/reference``:
 
-What does NOT run here is TensorFlow (absent from the image).  ``lyapunov.py`` builds a small
-op graph per method (``tf.placeholder`` ... ``tf.less`` ... ``.eval(feed_dict)``); the stand-in
-below (``LazyTF``) records exactly those ops as deferred NumPy expressions and evaluates them
-with NumPy when the reference calls ``.eval`` / ``session.run``: every op the reference's
-methods request is answered by the NumPy function of the same name and meaning, elementwise
-IEEE-754 double arithmetic either way.  The only reductions are row sums over <= 5 columns
-(``np.sum`` adds them left to right, as the oracle and the HIP kernels do; TensorFlow's Eigen
-kernels may pair them differently, which is why the product's contract is the oracle's order).
-An op that is not listed in ``LazyTF`` still raises ``StandInCalled``.
+* ``lyapunov.py``: ``Lyapunov.__init__`` / ``update_values`` / ``threshold`` /
+  ``v_decrease_confidence`` / ``v_decrease_bound`` / ``update_safe_set`` (``:176-606``: the value
+  sort, the batch loop, the prefix rule with its early exit, the ``c_max`` index arithmetic, the
+  adaptive branch), ``smallest_boundary_value`` (``:22-56``), ``perturb_actions`` /
+  ``get_safe_sample`` (``:609-797``);
+* ``functions.py``: ``GridWorld``, ``LinearSystem``, ``QuadraticFunction``, ``Saturation``, the
+  ``Triangulation`` graph wrapper with ``_Triangulation`` underneath (value tables, table
+  policies, ``gradient`` for L_v) - the policy, dynamics, V and L_v handed to ``Lyapunov`` are
+  the reference's own objects;
+* ``examples/utilities.py``: ``InvertedPendulum`` and ``CartPole`` (the Euler models).
 
-The LEAF functions handed to the reference's ``Lyapunov`` (policy, dynamics, V, L_v) are the
-oracle's NumPy callables (pinned one by one by the reference's known-answer tests,
-``tests/test_oracle_golden.py``).  So the fixture pins the COMPOSITION: given identical per-cell
-leaf values, the oracle's restatement of ``lyapunov.py`` (``oracle/np_lyapunov.py``) must
-reproduce the safe set, ``c_max``, the value table and the refinement array of the reference's
-own control flow bit for bit, call after call.
+What does NOT run is TensorFlow (absent from the image): ``tests/golden/numpy_tf.py`` answers the
+ops these files request with NumPy (elementwise IEEE-754 double arithmetic; ``matmul`` /
+``reduce_sum`` accumulate left to right - see that file for what this does and does not claim).
+And gpflow is absent: a GP dynamics model is the one leaf that is NOT a reference object; it is the
+oracle's ``GaussianProcess`` / ``FunctionStack`` callable (pinned by the reference's known-answer
+test) wrapped as a graph function.
+
+``tests/test_oracle_reference_safe_sets.py`` replays every scenario on ``oracle.Lyapunov`` with the
+oracle's own function classes and requires the safe set, ``c_max``, the value table, the
+refinement array and every sample to be equal bit for bit, call after call;
+``tests/test_gpu_reference_safe_sets.py`` does the same with the HIP engine.
 
 Tie order: ``lyapunov.py:512`` sorts with NumPy's default argsort, whose order of equal values
 depends on the NumPy build and the CPU (AVX-512 / AVX2 / scalar sort).  Scenarios marked
@@ -31,21 +32,15 @@ cells have the same value; the symmetric scenarios have deterministic odd-symmet
 loops, where both cells of a tied pair get the same decision and the outcome does not depend on
 their order.  What a tie does in general stays "parity unpinned" (DESIGN.md section 6).
 
-NumPy-2 compatibility of the reference (besides ``np.int``, see make_reference_fixtures.py):
-``collections.Sequence`` -> ``collections.abc.Sequence`` (``lyapunov.py:5``);
-``np.column_stack`` accepts a generator as NumPy 1 did (``functions.py:635``, ``lyapunov.py:50``).
 ``get_lyapunov_region`` (``lyapunov.py:59-139``) is Python-2 code (``tiebreaker.next()``) and
 cannot be run.
 
     python tests/golden/make_reference_safe_sets.py          (needs /root/reference)
 """
 
-import collections
-import collections.abc
 import json
 import os
 import sys
-import types
 import warnings
 
 import numpy as np
@@ -55,183 +50,60 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
-import make_reference_fixtures as ref_loader          # noqa: E402
+import numpy_tf                                         # noqa: E402
 
 OUT = os.path.join(HERE, "reference_safe_sets.npz")
 
 
 # --------------------------------------------------------------------------------------
-# Deferred NumPy expressions standing in for TensorFlow tensors
+# The reference's own function classes as leaves
 # --------------------------------------------------------------------------------------
 
-def _broadcast_shape(a, b):
-    if a is None or b is None:
-        return None
-    out = []
-    for x, y in zip(((1,) * (len(b) - len(a)) + tuple(a)), ((1,) * (len(a) - len(b)) + tuple(b))):
-        if x is None or y is None:
-            out.append(None if 1 in (x, y) or x == y else (x or y))
-        else:
-            out.append(max(x, y))
-    return tuple(out)
-
-
-def _shape_of(x):
-    if isinstance(x, Lazy):
-        return x.shape
-    return np.shape(x)
-
-
-class Lazy(object):
-    """A node of the op graph: ``fn(*args)`` evaluated at ``.eval`` time; a placeholder has no fn."""
-
-    __array_ufunc__ = None          # ndarray (op) Lazy -> Lazy.__r(op)__
-
-    def __init__(self, fn, args=(), shape=None, name=""):
-        self.fn, self.args, self.shape, self.name = fn, tuple(args), shape, name
-
-    def eval(self, feed_dict=None, session=None):
-        return evaluate(self, feed_dict or {}, {})
-
-    def _binary(self, other, fn, swap=False):
-        args = (other, self) if swap else (self, other)
-        return Lazy(fn, args, _broadcast_shape(_shape_of(args[0]), _shape_of(args[1])))
-
-    def __add__(self, o): return self._binary(o, np.add)
-    def __radd__(self, o): return self._binary(o, np.add, True)
-    def __sub__(self, o): return self._binary(o, np.subtract)
-    def __rsub__(self, o): return self._binary(o, np.subtract, True)
-    def __mul__(self, o): return self._binary(o, np.multiply)
-    def __rmul__(self, o): return self._binary(o, np.multiply, True)
-    def __truediv__(self, o): return self._binary(o, _divide)
-    def __rtruediv__(self, o): return self._binary(o, _divide, True)
-    def __neg__(self): return Lazy(np.negative, (self,), self.shape)
-
-    def __getitem__(self, key):
-        shape = None
-        if self.shape is not None and None not in self.shape:
-            shape = np.empty(self.shape)[key].shape
-        return Lazy(lambda x: x[key], (self,), shape)
-
-
-def _divide(a, b):
-    with np.errstate(divide="ignore", invalid="ignore"):     # TensorFlow returns inf / nan silently
-        return np.true_divide(a, b)
-
-
-def evaluate(node, feed_dict, memo):
-    if isinstance(node, (list, tuple)):
-        return type(node)(evaluate(x, feed_dict, memo) for x in node)
-    if not isinstance(node, Lazy):
-        return node
-    if id(node) in memo:
-        return memo[id(node)][1]
-    if node.fn is None:
-        if node not in feed_dict:
-            raise KeyError("placeholder %r was not fed" % node.name)
-        value = np.asarray(feed_dict[node])
-    elif node.fn is MAP_FN:
-        fn, elems = node.args
-        rows = evaluate(elems, feed_dict, memo)
-        # TensorFlow traces fn once on a symbolic row; tracing it per row builds the same ops
-        value = np.array([evaluate(fn(constant(row)), feed_dict, memo) for row in rows])
+def reference_specs(case, ref, oracle_dynamics):
+    """(policy, dynamics, V, L_v) of a case (tests/cases.py parameters) built from the REFERENCE'S
+    classes: ``functions.py`` ``LinearSystem`` / ``QuadraticFunction`` / ``Saturation`` /
+    ``Triangulation`` and ``examples/utilities.py`` ``InvertedPendulum`` / ``CartPole``.  Only a
+    GP model has no reference object here (gpflow is absent): it stays the oracle's callable."""
+    F, tf = ref.functions, sys.modules["tensorflow"]
+    d = case["d"]
+    if "policy_table" in case:
+        tab = case["policy_table"]
+        policy = F.Triangulation(F.GridWorld(case["limits"], tab["num_points"]), tab["values"])
     else:
-        value = node.fn(*[evaluate(a, feed_dict, memo) for a in node.args])
-    memo[id(node)] = (node, value)           # holding the node keeps its id from being reused
-    return value
-
-
-MAP_FN = object()
-
-
-def constant(value, dtype=None, **_):
-    value = np.asarray(value, dtype=None if dtype is None else dtype.as_numpy_dtype)
-    return Lazy(lambda: value, (), value.shape)
-
-
-def _static(shape):
-    return None if shape is None else tuple(None if s in (None, -1) else int(s) for s in shape)
-
-
-class _Session(object):
-    def run(self, fetches, feed_dict=None):
-        return evaluate(fetches, feed_dict or {}, {})
-
-
-def install_lazy_tf(tf):
-    """The ops ``lyapunov.py`` requests, as deferred NumPy calls."""
-    dtype = lambda np_type: types.SimpleNamespace(as_numpy_dtype=np_type)   # noqa: E731
-    tf.float64, tf.int32, tf.bool = dtype(np.float64), dtype(np.int32), dtype(np.bool_)
-    tf.name_scope = lambda name: ref_loader._Scope()                  # utilities.py:108
-    tf.get_default_session = lambda: _Session()                       # lyapunov.py:760
-    tf.placeholder = lambda dt, shape=None, name="": Lazy(None, (), _static(shape), name)
-    tf.constant = constant
-    tf.less = lambda a, b, name=None: Lazy(np.less, (a, b), _broadcast_shape(_shape_of(a), _shape_of(b)))
-    tf.squeeze = lambda x, axis=None: Lazy(lambda v: np.squeeze(v, axis=axis), (x,))
-    tf.reduce_sum = lambda x, axis=None, keepdims=False: Lazy(
-        lambda v: np.sum(v, axis=axis, keepdims=keepdims), (x,))
-    tf.reduce_min = lambda x: Lazy(np.min, (x,), ())
-    tf.reduce_all = lambda x: Lazy(np.all, (x,), ())
-
-    def norm(x, ord=None, axis=None, keepdims=False):                 # lyapunov.py:286
-        assert ord == 1
-        return Lazy(lambda v: np.sum(np.abs(v), axis=axis, keepdims=keepdims), (x,))
-    tf.norm = norm
-    # the adaptive branch, lyapunov.py:443-488
-    tf.is_nan = lambda x: Lazy(np.isnan, (x,), _shape_of(x))
-    tf.zeros_like = lambda x: Lazy(np.zeros_like, (x,), _shape_of(x))
-    tf.where = lambda c, a, b: Lazy(np.where, (c, a, b), _shape_of(a))
-    tf.maximum = lambda a, b: Lazy(np.maximum, (a, b), _broadcast_shape(_shape_of(a), _shape_of(b)))
-    tf.ceil = lambda x: Lazy(np.ceil, (x,), _shape_of(x))
-    tf.cast = lambda x, dt: Lazy(lambda v: np.asarray(v).astype(dt.as_numpy_dtype), (x,), _shape_of(x))
-    tf.reshape = lambda x, shape: Lazy(lambda v: np.reshape(v, shape), (x,), _static(shape))
-    tf.linspace = lambda a, b, n: Lazy(lambda u, v, k: np.linspace(u, v, int(k)), (a, b, n), (None,))
-    tf.concat = lambda xs, axis: Lazy(lambda *v: np.concatenate(v, axis=axis), tuple(xs))
-    tf.stack = lambda xs, axis=0: Lazy(lambda *v: np.stack(v, axis=axis), tuple(xs))
-
-    def tile(x, multiples):
-        shape = _shape_of(x)
-        shape = None if shape is None else tuple(None if s is None else s * m
-                                                 for s, m in zip(shape, multiples))
-        return Lazy(lambda v: np.tile(v, multiples), (x,), shape)
-    tf.tile = tile
-
-    def unstack(x):
-        rows = _shape_of(x)[0]                   # static, as TensorFlow requires as well
-        return [x[k] for k in range(rows)]
-    tf.unstack = unstack
-    tf.meshgrid = lambda *xs, **kw: [Lazy(lambda *v, _k=k: np.meshgrid(*v, **kw)[_k], tuple(xs))
-                                     for k in range(len(xs))]
-    tf.map_fn = lambda fn, elems, dtype=None, parallel_iterations=None: Lazy(MAP_FN, (fn, elems))
-
-
-def lazy_function(fn, ncols, uncertain=False):
-    """An oracle NumPy callable as a graph function: Lazy inputs -> Lazy output(s) with ``ncols``
-    columns (``(mean, error)`` for an uncertain dynamics model, ``lyapunov.py:340``)."""
-    def call(*inputs):
-        if not uncertain:
-            return Lazy(lambda *v: np.asarray(fn(*v)), inputs, (None, ncols))
-        pair = Lazy(lambda *v: fn(*v), inputs)
-        return (Lazy(lambda t: t[0], (pair,), (None, ncols)),
-                Lazy(lambda t: t[1], (pair,), (None, ncols)))
-    return call
-
-
-def load_reference():
-    """-> (functions, lyapunov) modules of the reference with LazyTF in place of TensorFlow."""
-    collections.Sequence = collections.abc.Sequence                   # lyapunov.py:5
-    functions = ref_loader.load_reference()
-    install_lazy_tf(sys.modules["tensorflow"])
-    stack = np.column_stack
-    np.column_stack = lambda tup: stack(tuple(tup))                   # NumPy-1 behaviour
-    spec = ref_loader.importlib.util.spec_from_file_location(
-        "safe_learning.lyapunov", os.path.join(ref_loader.REF, "lyapunov.py"))
-    lyapunov = ref_loader.importlib.util.module_from_spec(spec)
-    sys.modules["safe_learning.lyapunov"] = lyapunov
-    ref_loader._armed[0] = False
-    spec.loader.exec_module(lyapunov)
-    ref_loader._armed[0] = True
-    return functions, lyapunov
+        policy = F.LinearSystem((case["K"],))
+    if case["saturate"] is not None:
+        policy = F.Saturation(policy, *case["saturate"])
+    dyn = case["dynamics"]
+    if dyn["kind"] == "linear":
+        dynamics = F.LinearSystem((dyn["matrix"],))
+    elif dyn["kind"] == "pendulum":
+        dynamics = ref.examples.InvertedPendulum(dyn["mass"], dyn["length"], dyn["friction"],
+                                                 dyn["dt"], dyn["normalization"])
+    elif dyn["kind"] == "cartpole":
+        dynamics = ref.examples.CartPole(dyn["pendulum_mass"], dyn["cart_mass"], dyn["length"],
+                                         dyn["rot_friction"], dyn["dt"], dyn["normalization"])
+    else:
+        dynamics = numpy_tf.lazy_function(oracle_dynamics, d, uncertain=True)
+    vspec = case.get("V", {"kind": "quadratic"})
+    if vspec["kind"] == "quadratic":
+        value = F.QuadraticFunction(case["P"])
+    else:
+        value = F.Triangulation(F.GridWorld(case["limits"],
+                                            vspec.get("num_points", case["num_points"])),
+                                vspec["values"], project=vspec.get("project", False))
+    kind, arg = (case["lv"] + (None,))[:2]
+    if kind == "const":
+        lv = arg
+    elif kind == "abs_linear":                   # the notebooks' lambda x: tf.abs(V.gradient(x))
+        lv = lambda x: tf.abs(tf.matmul(x, arg.T))                    # noqa: E731
+    elif kind == "abs_grad":                     # inverted_pendulum.ipynb cell 14
+        def lv(x):
+            gradient = tf.abs(value.gradient(x))
+            gradient.shape = (None, d)           # static shape of the py_func output
+            return gradient
+    else:
+        raise ValueError(kind)
+    return policy, dynamics, value, lv
 
 
 # --------------------------------------------------------------------------------------
@@ -386,28 +258,23 @@ def from_jsonable(obj, arrays):
 
 
 def main():
-    import oracle
     from tests import cases
-    functions, lyapunov = load_reference()
-    config = sys.modules["safe_learning"].config
+    ref = numpy_tf.load_reference(examples=True)
+    functions, lyapunov, config = ref.functions, ref.lyapunov, ref.config
     arrays, index = {}, []
     for scenario in scenarios():
         name, case = scenario["name"], scenario["case"]
-        policy, dynamics, value, lv = cases.oracle_specs(case)
-        d = case["d"]
-        uncertain = case["dynamics"]["kind"] == "gp"
+        _, oracle_dynamics, _, _ = cases.oracle_specs(case)
+        policy, dynamics, value, lv = reference_specs(case, ref, oracle_dynamics)
         initial = None if scenario.get("no_initial_set") else cases.initial_safe_mask(case)
         config.gp_batch_size = scenario["batch"]
         grid = functions.GridWorld(case["limits"], case["num_points"])
-        lyap = lyapunov.Lyapunov(
-            grid, lazy_function(value, 1), lazy_function(dynamics, d, uncertain), case["lf"],
-            lazy_function(lv, d) if callable(lv) else lv, case["tau"],
-            lazy_function(policy, case["m"]), initial_set=initial,
-            adaptive=bool(scenario.get("adaptive")))
+        lyap = lyapunov.Lyapunov(grid, value, dynamics, case["lf"], lv, case["tau"], policy,
+                                 initial_set=initial, adaptive=bool(scenario.get("adaptive")))
         if scenario.get("unique"):
             assert len(np.unique(lyap.values)) == len(lyap.values), name
-        boundary = lyapunov.smallest_boundary_value(lazy_function(value, 1), grid)
-        records = replay(scenario, lyap, dynamics, lyapunov.get_safe_sample,
+        boundary = lyapunov.smallest_boundary_value(value, grid)
+        records = replay(scenario, lyap, oracle_dynamics, lyapunov.get_safe_sample,
                          lambda obj: obj.feed_dict[obj.c_max])
         arrays[name + "/values"] = lyap.values
         arrays[name + "/boundary"] = np.float64(boundary)

@@ -1,0 +1,136 @@
+"""The oracle's function classes against outputs of the reference's own classes.
+
+``tests/golden/reference_functions.npz`` was produced in the build container by
+``tests/golden/make_reference_functions.py``: the reference's ``LinearSystem``,
+``QuadraticFunction`` (+ gradient, negation), ``Saturation``, the TensorFlow ``Triangulation``
+wrapper (+ gradient), ``InvertedPendulum`` / ``CartPole`` (+ ``linearize``), ``LyapunovNetwork``,
+``dlqr``, ``batchify`` and ``unique_rows`` called unmodified behind ``tests/golden/numpy_tf.py``.
+Parameters and query points are stored in the fixture.
+"""
+
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_equal
+
+import oracle
+from oracle import np_functions, np_lyapunov, np_utilities
+
+from conftest import GOLDEN_DIR
+
+FIXTURE = np.load(os.path.join(GOLDEN_DIR, "reference_functions.npz"))
+
+
+def _spec():
+    sys.path.insert(0, GOLDEN_DIR)
+    try:
+        from make_reference_safe_sets import from_jsonable
+    finally:
+        sys.path.remove(GOLDEN_DIR)
+    return from_jsonable(json.loads(str(FIXTURE["_spec"])), FIXTURE)
+
+
+SPEC = _spec()
+
+
+def _same_scipy():
+    import scipy
+    return str(FIXTURE["_scipy_version"]) == scipy.__version__
+
+
+def test_linear_quadratic_saturation():
+    s = SPEC["linear"]
+    system = oracle.LinearSystem((s["A"], s["B"]))
+    assert_equal(system(s["x"], s["u"]), FIXTURE["linear/two_inputs"])
+    assert_equal(system(np.hstack((s["x"], s["u"]))), FIXTURE["linear/stacked"])
+    s = SPEC["quadratic"]
+    quadratic = oracle.QuadraticFunction(s["P"])
+    assert_equal(quadratic(s["x"]), FIXTURE["quadratic/values"])
+    assert_equal(np_functions.NegatedFunction(quadratic)(s["x"]), FIXTURE["quadratic/negated"])
+    # functions.py:1541-1543: points (P + P^T), what the notebooks wrap in tf.abs for L_v
+    gradient = oracle.LinearSystem(((s["P"] + s["P"].T).T,))
+    assert_equal(gradient(s["x"]), FIXTURE["quadratic/gradient"])
+    s = SPEC["saturation"]
+    saturated = oracle.Saturation(oracle.LinearSystem((s["K"],)), s["lower"], s["upper"])
+    assert_equal(saturated(s["x"]), FIXTURE["saturation/values"])
+    assert (FIXTURE["saturation/values"] == s["lower"]).any()
+    assert (FIXTURE["saturation/values"] == s["upper"]).any()
+
+
+@pytest.mark.parametrize("name,cls", [("pendulum", np_functions.InvertedPendulum),
+                                      ("cartpole", np_functions.CartPole)])
+def test_euler_models(name, cls):
+    s = SPEC[name]
+    width = s["xu"].shape[1] - 1
+    for k, kwargs in enumerate(s["variants"]):
+        model = cls(**kwargs)
+        assert_equal(model(s["xu"][:, :width], s["xu"][:, width:]),
+                     FIXTURE["%s/%d/values" % (name, k)])
+        a, b = model.linearize()
+        if _same_scipy():
+            assert_equal(a, FIXTURE["%s/%d/A" % (name, k)])
+            assert_equal(b, FIXTURE["%s/%d/B" % (name, k)])
+        else:
+            assert_allclose(a, FIXTURE["%s/%d/A" % (name, k)], rtol=1e-12, atol=1e-15)
+            assert_allclose(b, FIXTURE["%s/%d/B" % (name, k)], rtol=1e-12, atol=1e-15)
+
+
+def test_product_linearisations_equal_the_reference_run():
+    """``safe_learning_amd.functions._pendulum_linearize`` / ``_cartpole_linearize`` (host code of
+    the product: the benchmark's LQR policy and prior come from them)."""
+    from safe_learning_amd.functions import _cartpole_linearize, _pendulum_linearize
+    kw = SPEC["pendulum"]["variants"][0]
+    a, b = _pendulum_linearize(kw["mass"], kw["length"], kw["friction"], kw["dt"],
+                               kw["normalization"])
+    assert_allclose(a, FIXTURE["pendulum/0/A"], rtol=1e-13, atol=1e-16)
+    assert_allclose(b, FIXTURE["pendulum/0/B"], rtol=1e-13, atol=1e-16)
+    kw = SPEC["cartpole"]["variants"][0]
+    a, b = _cartpole_linearize(kw["pendulum_mass"], kw["cart_mass"], kw["length"],
+                               kw["rot_friction"], kw["dt"], kw["normalization"])
+    assert_allclose(a, FIXTURE["cartpole/0/A"], rtol=1e-13, atol=1e-16)
+    assert_allclose(b, FIXTURE["cartpole/0/B"], rtol=1e-13, atol=1e-16)
+
+
+def test_lyapunov_network():
+    s = SPEC["network"]
+    network = oracle.LyapunovNetwork(s["input_dim"], s["layer_dims"], s["activations"], s["eps"],
+                                     s["weights"])
+    # the oracle multiplies with BLAS, the fixture accumulates left to right
+    assert_allclose(network(s["x"]), FIXTURE["network/values"], rtol=1e-13, atol=1e-300)
+    assert FIXTURE["network/values"].min() > 0
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_triangulation_wrapper(k):
+    """``functions.py:1373-1510``: the graph the reference's sweeps actually evaluate (weights by
+    ``reduce_sum(offset * hyperplanes)``, ``tf.gather`` of the vertex values)."""
+    s = SPEC["tables"][k]
+    table = oracle.Triangulation(oracle.GridWorld(s["limits"], s["num_points"]),
+                                 s["vertex_values"], project=s["project"])
+    assert_equal(table(s["x"]), FIXTURE["tables/%d/values" % k])
+    assert_equal(table.gradient(s["x"]), FIXTURE["tables/%d/gradient" % k])
+
+
+def test_dlqr_batchify_unique_rows():
+    from safe_learning_amd import utilities as product_utilities
+    for k, s in enumerate(SPEC["dlqr"]):
+        for dlqr in (np_utilities.dlqr, product_utilities.dlqr):
+            gain, cost = dlqr(s["a"], s["b"], s["q"], s["r"])
+            if _same_scipy():
+                assert_equal(np.asarray(gain), FIXTURE["dlqr/%d/k" % k])
+                assert_equal(np.asarray(cost), FIXTURE["dlqr/%d/p" % k])
+            else:
+                assert_allclose(gain, FIXTURE["dlqr/%d/k" % k], rtol=1e-11)
+                assert_allclose(cost, FIXTURE["dlqr/%d/p" % k], rtol=1e-11)
+    assert_equal(np_lyapunov.unique_rows(SPEC["unique_rows"]["array"]),
+                 FIXTURE["unique_rows/result"])
+    s = SPEC["batchify"]
+    batches = list(np_utilities.batchify(tuple(s["arrays"]), int(s["batch_size"])))
+    assert len(batches) == int(FIXTURE["batchify/count"])
+    for k, (start, arrays) in enumerate(batches):
+        assert start == int(FIXTURE["batchify/%d/start" % k])
+        for j, batch in enumerate(arrays):
+            assert_equal(batch, FIXTURE["batchify/%d/%d" % (k, j)])

@@ -4,8 +4,9 @@
 ``tests/golden/reference_policy_iteration.npz`` was produced in the build container by
 ``tests/golden/make_reference_policy_iteration.py``: the reference's ``PolicyIteration``
 (``reinforcement_learning.py:46-140, 213-279``; the Lyapunov penalty through the reference's
-``lyapunov.py:265-376``) executed unmodified with a deferred-NumPy stand-in answering its
-TensorFlow ops and the oracle's leaf functions as tables / dynamics / reward.  Every scenario
+``lyapunov.py:265-376``) executed unmodified on the reference's own ``Triangulation`` tables,
+reward and dynamics objects, with ``tests/golden/numpy_tf.py`` answering the TensorFlow ops (a GP
+model is the oracle's callable: gpflow is absent).  Every scenario
 (parameters stored in the fixture) is replayed on ``oracle.PolicyIteration`` through the same
 step driver; the value table after every ``value_iteration``, the policy table after every
 ``discrete_policy_optimization`` and every ``future_values`` / ``bellmann_error`` result must be

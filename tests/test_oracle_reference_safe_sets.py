@@ -3,9 +3,10 @@
 ``tests/golden/reference_safe_sets.npz`` was produced in the build container by
 ``tests/golden/make_reference_safe_sets.py``: the reference's ``Lyapunov.update_safe_set`` /
 ``update_values`` / ``threshold`` / ``v_decrease_bound`` (``lyapunov.py:176-606``),
-``get_safe_sample`` (``:609-797``) and ``smallest_boundary_value`` (``:22-56``) executed unmodified,
-with a deferred-NumPy stand-in answering the TensorFlow ops they request and the oracle's leaf
-functions as policy / dynamics / V / L_v.  Here every scenario (parameters stored in the fixture)
+``get_safe_sample`` (``:609-797``) and ``smallest_boundary_value`` (``:22-56``) executed unmodified
+on the reference's own ``functions.py`` / ``examples/utilities.py`` objects (policy, dynamics, V,
+L_v; only a GP model is the oracle's callable - gpflow is absent), with ``tests/golden/numpy_tf.py``
+answering the TensorFlow ops they request.  Here every scenario (parameters stored in the fixture)
 is replayed on ``oracle.Lyapunov`` through the same step driver: safe set, ``c_max``, refinement
 array after every ``update_safe_set`` call, the sample and its bound after every
 ``get_safe_sample`` call, the value table and the boundary minimum - bit for bit.
