@@ -27,14 +27,26 @@ Third-party arithmetic that is not in the upstream checkout: the RBF kernel and
 ``oracle.np_functions.RBF`` and pinned by the reference's own known-answer test
 ``safe_learning/tests/test_functions.py:237-261``.
 
-Pinning: the reference cannot be imported in the build container (no tensorflow /
-gpflow).  The oracle is therefore pinned by the literal known-answer values of the
-reference's own tests, transcribed in ``tests/golden/reference_known_answers.json``
-and checked by ``tests/test_oracle_golden.py``.  Two things are pinned only by
-reading the code and are flagged "parity unpinned" in DESIGN.md: the order of
-equal-valued cells in ``update_safe_set`` (the reference uses NumPy's unstable
-default argsort; the oracle fixes ascending (value, flat index)), and the 4-D
-unit-cell triangulation (Qhull output frozen in ``tests/golden``).
+Pinning, three layers:
+
+1. the literal known-answer values of the reference's own tests, transcribed in
+   ``tests/golden/reference_known_answers.json`` (``tests/test_oracle_golden.py``);
+2. arrays computed by the reference's own ``GridWorld`` / ``_Triangulation`` (pure
+   NumPy/SciPy) run in the build container (``tests/golden/make_reference_fixtures.py``);
+3. the reference's hot path run END TO END in the build container: its ``lyapunov.py``,
+   ``reinforcement_learning.py``, function classes and Euler models executed unmodified
+   behind ``tests/golden/numpy_tf.py``, a deferred-NumPy stand-in for the TensorFlow ops
+   they request (TensorFlow 1.x is absent).  The committed fixtures
+   (``reference_safe_sets.npz``, ``reference_policy_iteration.npz``,
+   ``reference_functions.npz``) are reproduced by this oracle bit for bit
+   (``tests/test_oracle_reference_*.py``): safe sets, ``c_max``, refinement arrays,
+   samples, value and policy tables, per-class outputs.
+
+What stays "parity unpinned": the order of equal-valued cells in ``update_safe_set``
+(the reference uses NumPy's default argsort, whose tie order depends on the NumPy build
+and the CPU; the oracle fixes ascending (value, flat index)), ``get_lyapunov_region``
+(Python-2 code that cannot run), and the GP posterior beyond the reference's one
+known-answer test (gpflow is absent).
 
 Canonical arithmetic: small linear-algebra forms (policy, linear dynamics,
 quadratic V, thresholds) are evaluated left-to-right, one IEEE-754 rounding per
