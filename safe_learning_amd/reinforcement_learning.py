@@ -19,6 +19,11 @@ from .functions import ConstantFunction, Triangulation
 __all__ = ['PolicyIteration', 'OptimizationError']
 
 
+def _same_grid(a, b):
+    return (a is b) or (np.array_equal(a.limits, b.limits)
+                        and np.array_equal(a.num_points, b.num_points))
+
+
 class OptimizationError(Exception):
     """``reinforcement_learning.py:22-23``."""
 
@@ -159,6 +164,11 @@ class PolicyIteration(object):
             v_new, _, _, stats = self._sweep(self.policy, None)
         else:
             action_space = np.atleast_2d(np.asarray(action_space, dtype=np.float64))
+            if isinstance(self.policy, Triangulation) and not _same_grid(
+                    self.policy.discretization, self.discretization):
+                raise ValueError('value_iteration(action_space) adopts the greedy action per VALUE '
+                                 'vertex; the policy table lives on another grid - call '
+                                 'discrete_policy_optimization() and value_iteration() instead')
             v_new, argmax, _, stats = self._sweep(self.policy, action_space)
             self._adopt_greedy_policy(action_space, argmax)
         full = self._gather(v_new)
@@ -201,6 +211,11 @@ class PolicyIteration(object):
         import torch
         action_space = np.atleast_2d(np.asarray(action_space, dtype=np.float64))
         n_act = action_space.shape[0]
+        policy_grid = getattr(self.policy, 'discretization', None)
+        if isinstance(self.policy, Triangulation) and not _same_grid(policy_grid,
+                                                                     self.discretization):
+            return self._discrete_policy_optimization_at(policy_grid, action_space, constraint,
+                                                         return_values)
         want_q = return_values or constraint is not None
         _, argmax, q, _ = self._sweep(self.policy, action_space, want_q=want_q)
         q_all = None
@@ -220,6 +235,26 @@ class PolicyIteration(object):
             best = torch.from_numpy(np.argmax(q_all.cpu().numpy(), axis=1)).to(q_all.device)
         self._adopt_greedy_policy(action_space, argmax, best)
         return q_all if return_values else None
+
+    def _discrete_policy_optimization_at(self, policy_grid, action_space, constraint,
+                                         return_values):
+        """The policy table lives on another grid than the value table: the reference optimises
+        over ``self.policy.discretization.all_points`` (``:227``), which the sweep kernel (one
+        thread per VALUE vertex) does not walk - the action values come from the point-evaluation
+        kernels, the arg-max and the constraint callback run on the host like the reference's."""
+        import torch
+        states = policy_grid.all_points
+        n, n_act = len(states), action_space.shape[0]
+        values = np.empty((n, n_act), dtype=np.float64)
+        for i, action in enumerate(action_space):                        # :266-275
+            values[:, i] = self._future_values_at(states, None, action[None, :], None, 1.)[:, 0]
+            if constraint is not None:
+                slack = constraint(np.broadcast_to(action, (n, action_space.shape[1])))
+                values[np.asarray(slack).reshape(-1) < 0, i] = -np.inf
+        self.policy.parameters = action_space[np.argmax(values, axis=1)]  # :278 first max wins
+        if return_values:
+            return torch.from_numpy(values).to(self._ctx.torch_device)
+        return None
 
     def optimize_value_function(self, **solver_options):
         """The cvxpy linear program of ``:142-211`` is outside the accelerated path."""

@@ -1,0 +1,171 @@
+"""The HIP engine's ``PolicyIteration`` against tables computed by the reference's own
+``reinforcement_learning.py`` (needs an MI355X).
+
+``tests/golden/reference_policy_iteration.npz`` holds the value table after every
+``value_iteration``, the policy table after every ``discrete_policy_optimization`` and every
+``future_values`` / ``bellmann_error`` result of the reference run in the build container
+(``tests/golden/make_reference_policy_iteration.py``).  The engine executes the same steps through
+the C ABI; after every step its result is compared with the FIXTURE and the engine's table is then
+set to the fixture's, so every step starts from the reference's own numbers.
+
+Bars: value tables and future values within 1e-9 relative (GP mean, device ``sin``/``cos``,
+barycentric weights differ in the last bits from NumPy's); greedy actions equal, except where the
+two best action values are within 1e-9 relative.  The oracle is consulted only to say where a
+comparison is not defined: query points at which the reference's interpolated value depends on
+SciPy's search history (``test_gpu_rl.ambiguous_points``), successor states within 1e-9 of a
+grid line of the value table (the reference's ``%`` wrap-around returns another cell's value for
+a point one rounding error BELOW a grid line - e.g. the successor of the origin under a policy
+whose interpolated action is +-1e-17: oracle and engine agree on both values, the sign of the
+rounding noise picks one) and near-ties of the arg-max.
+"""
+
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_array_equal
+
+import oracle
+
+from conftest import GOLDEN_DIR
+from test_gpu_rl import ambiguous_points
+
+pytestmark = pytest.mark.gpu
+
+
+def _generator():
+    sys.path.insert(0, GOLDEN_DIR)
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "make_reference_policy_iteration",
+            os.path.join(GOLDEN_DIR, "make_reference_policy_iteration.py"))
+        module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(module)
+    finally:
+        sys.path.remove(GOLDEN_DIR)
+    return module
+
+
+GENERATOR = _generator()
+FIXTURE = np.load(os.path.join(GOLDEN_DIR, "reference_policy_iteration.npz"))
+INDEX = json.loads(str(FIXTURE["_index"]))
+NAMES = [entry["scenario"]["name"] for entry in INDEX]
+RTOL, ATOL = 1e-9, 1e-12
+
+
+def _on_table_face(table, points, eps=1e-9):
+    """Computed (not clipped) coordinates within ``eps`` cells of a grid line of ``table``, or
+    points whose value depends on SciPy's search history."""
+    grid = table.discretization
+    limits = np.asarray(grid.limits)
+    computed = (points > limits[:, 0]) & (points < limits[:, 1])
+    frac = ((points - grid.offset) / grid.unit_maxes) % 1.0
+    near = (np.minimum(frac, 1.0 - frac) < eps) & computed
+    return near.any(axis=1) | ambiguous_points(table, points)
+
+
+def _mean(next_states):
+    return next_states[0] if isinstance(next_states, tuple) else next_states
+
+
+@pytest.mark.parametrize("entry", INDEX, ids=NAMES)
+def test_engine_tables_equal_the_reference_run(entry):
+    import safe_learning_amd as sl
+    from safe_learning_amd.benchmarks import build_specs
+    scenario = GENERATOR.from_jsonable(entry["scenario"], FIXTURE)
+    name, case = scenario["name"], scenario["case"]
+    _, dynamics, lyap_value, lv = build_specs(case)
+    vgrid = sl.GridWorld(scenario["limits"], scenario["value_points"])
+    pgrid = sl.GridWorld(scenario["limits"], scenario["policy_points"])
+    value = sl.Triangulation(vgrid, scenario["value_table"], project=True)
+    policy = sl.Triangulation(pgrid, scenario["policy_table"])
+    rl = sl.PolicyIteration(policy, dynamics, sl.QuadraticFunction(scenario["reward"]), value,
+                            gamma=scenario["gamma"])
+    lyap = None
+    if scenario["lyapunov"]:
+        lyap = sl.Lyapunov(vgrid, lyap_value, dynamics, case["lf"], lv, case["tau"], policy)
+
+    # the oracle twin: only for the exclusion masks
+    opolicy, odynamics, oreward, ovalue, _ = GENERATOR.build_oracle_leaves(scenario)
+    orl = oracle.PolicyIteration(opolicy, odynamics, oreward, ovalue, gamma=scenario["gamma"])
+    x = ovalue.discretization.all_points
+
+    record, compared = 0, 0
+    for step in scenario["steps"]:
+        kind = step[0]
+        if kind == "vi":
+            for _ in range(step[1]):
+                want = FIXTURE["%s/record%d" % (name, record)]
+                ok = ~ambiguous_points(opolicy, x)
+                ok &= ~_on_table_face(ovalue, _mean(odynamics(x, opolicy(x))))
+                rl.value_iteration()
+                got = value._host_parameters()
+                assert ok.mean() > 0.5
+                assert_allclose(got[ok], want[ok], rtol=RTOL, atol=ATOL,
+                                err_msg="%s record %d" % (name, record))
+                compared += int(ok.sum())
+                value.parameters = want.copy()
+                ovalue.parameters = want.copy()
+                record += 1
+        elif kind == "dpo":
+            actions = np.asarray(step[1], dtype=np.float64)
+            want = FIXTURE["%s/record%d" % (name, record)]
+            xp = opolicy.discretization.all_points
+            constraint = GENERATOR.constraint_function(step[2], xp)
+            oq, _ = orl.discrete_policy_optimization(actions, constraint=constraint)
+            assert_array_equal(opolicy.parameters, want)            # (the CPU test's statement)
+            rl.discrete_policy_optimization(actions, constraint=constraint)
+            got = policy._host_parameters()
+            ok = np.ones(len(xp), dtype=bool)
+            for action in actions:
+                ok &= ~_on_table_face(ovalue, _mean(odynamics(
+                    xp, np.broadcast_to(action, (len(xp), actions.shape[1])))))
+            masked = np.where(np.isfinite(oq), oq, -np.inf)
+            top2 = np.sort(masked, axis=1)[:, -2:]
+            tie = ~np.isfinite(top2[:, 0]) & ~np.isfinite(top2[:, 1])
+            with np.errstate(invalid="ignore"):
+                tie |= np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1])
+            # duplicates in the action set are a tie by value, not by index: compare the ACTIONS
+            differs = (got != want).any(axis=1)
+            assert not np.any(differs & ok & ~tie), "%s record %d" % (name, record)
+            assert (ok & ~tie).mean() > 0.3
+            compared += int((ok & ~tie).sum())
+            policy.parameters = want.copy()
+            opolicy.parameters = want.copy()
+            record += 1
+        elif kind in ("fv", "bellman"):
+            want = FIXTURE["%s/record%d" % (name, record)]
+            if kind == "bellman":
+                states = step[1]
+                nxt = _mean(odynamics(states, opolicy(states)))
+                ok = ~_on_table_face(ovalue, nxt) & ~ambiguous_points(ovalue, states)
+                ok &= ~ambiguous_points(opolicy, states)
+                if ok.all():
+                    assert_allclose(rl.bellmann_error(states), want, rtol=1e-8)
+                    compared += 1
+            else:
+                arg = dict(step[1])
+                states = arg.pop("states", None)
+                if arg.pop("lyapunov", False):
+                    arg["lyapunov"] = lyap
+                points = x if states is None else states
+                if "actions" in arg:
+                    actions = np.broadcast_to(arg["actions"], (len(points), arg["actions"].shape[1]))
+                    arg["actions"] = np.array(actions)
+                else:
+                    actions = opolicy(points)
+                ok = ~_on_table_face(ovalue, _mean(odynamics(points, actions)))
+                if "actions" not in arg:
+                    ok &= ~ambiguous_points(opolicy, points)
+                got = rl.future_values(states, **arg)
+                assert ok.mean() > 0.5
+                tolerance = 1e-8 if "lyapunov" in arg else RTOL
+                assert_allclose(got[ok], want[ok], rtol=tolerance, atol=1e-11,
+                                err_msg="%s record %d" % (name, record))
+                compared += int(ok.sum())
+            record += 1
+    assert record == entry["records"]
+    assert compared > 50
