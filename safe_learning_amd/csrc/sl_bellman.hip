@@ -748,6 +748,11 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
         // worthwhile for piecewise-constant policies; one shared-input head
         const int pkind = M.m.policy.kind;
         if (pkind != SL_POLICY_TRI && pkind != SL_POLICY_TABLE && pkind != SL_POLICY_CONST) return SL_OK;
+        // few distinct actions, last axis a multiple of 64 cells: the 4x4x4 kernel (sl_bellman4.hip)
+        int done4 = 0;
+        const int rc4 = sl_bellman4_policy_launch(ctx, lo, hi, d_v_new, d_stats, &done4);
+        if (rc4 != SL_OK) return rc4;
+        if (done4) { *done = 1; return SL_OK; }
         for (int h = 0; h < nheads; ++h)
             if (ctx->gp_heads[h].dout > SL_D) return SL_OK;
     }

@@ -46,6 +46,10 @@ int sl_bellman4_launch(sl_ctx*, int64_t, int64_t, int, double*, int32_t*, double
     *done = 0;
     return SL_OK;
 }
+int sl_bellman4_policy_launch(sl_ctx*, int64_t, int64_t, double*, double*, int* done) {
+    *done = 0;
+    return SL_OK;
+}
 #else
 
 typedef double sl_d2 __attribute__((ext_vector_type(2)));
@@ -559,6 +563,564 @@ __global__ __launch_bounds__(256, SL_B4_LOOKUP_BLOCKS) void k_bellman_lookup(
         atomicMax(reinterpret_cast<unsigned long long*>(&stats[0]),
                   (unsigned long long)__double_as_longlong(lmax));
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Policy evaluation, V <- r(x, pi(x)) + gamma V(f(x, pi(x))), for piecewise-constant table policies
+// ---------------------------------------------------------------------------------------------
+// The greedy policies of the value-iteration loop take their values from a finite action set, and
+// the 64 cells of a tile (one segment of a row of the last grid axis) use only a few of them.  The
+// means of ONE action for a tile are a quarter block as in k_bellman4 above - its <= 4 rows
+// (outputs) given to all four MFMA blocks, each block a different slab - so a tile costs 1024
+// MFMAs per distinct action instead of the 9 x 1024 of the max sweep or the 16-column GEMM of
+// k_bellman_policy_mfma (sl_bellman.hip, v_mfma_f64_16x16x4_f64, one exponential per slab and lane).
+//
+// The factors are grouped the other way round than in k_bellman4:
+//   mean[dd][cell] = sum_j (A_a[dd][j] P_j) T_last[cell][j],   A_a = sigma^2 E_j(u_a) alpha'[j][dd],
+// i.e. the product P_j of the leading axes' tables goes into the A operand (one multiply per lane
+// and group of 16 points) and the B operand is the last axis' table alone - the SAME for every tile
+// of a segment.  k_bellman4_policy_pack writes it once per sweep in the LDS fragment layout; a
+// workgroup copies a 32-point chunk into LDS once for its eight wavefronts (double buffered, one
+// barrier per chunk) instead of every wavefront generating its own S chunk from 512 KB of table
+// reads per tile (137 GB of L2 traffic per pass at 64^4 x 1024: 19 ms).
+//   * k_bellman4_policy_distinct collects the distinct policy values of [lo, hi) (at most PMAX = 64,
+//     otherwise the caller keeps k_bellman_policy_mfma); the pack kernel packs A_a per distinct
+//     action in quarter-block order;
+//   * a workgroup step = eight tiles of one segment, one per wavefront: the tile's distinct actions
+//     by ballots, mapped to the launch's list; PG action slots (16 accumulators each) per pass over
+//     the chunks; the workgroup makes as many passes as its busiest tile needs;
+//   * the epilogue is k_bellman_policy_mfma's: one cell per lane, its own action's mean, prior
+//     mean, reward, value-table lookup, residuals.
+namespace bm4 {
+constexpr int PG = 4;                      // action slots per pass
+constexpr int PMAX = 64;                   // distinct (rounded) policy values per launch
+constexpr int PROW = 5;                    // staged means of one slot: [32 cells][4 outputs + 1]
+constexpr unsigned long long P_EMPTY = 0x7ff8dead0000beefull;   // a NaN no policy produces
+
+struct PolicyPack {
+    int64_t btq;                // [n_glob][n_pad / 16][64 lanes]: lane (i, k): row i & 3, point 16 g + 4 (i >> 2) + k
+    int64_t tfrag;              // [segments][n_pad / 32][KXBUF]: T_last of a 32-point chunk, fragment layout
+    int64_t tab[SL_D];          // T_k [N_k][n_pad], the leading axes
+    int32_t n_pad, n_glob;
+    unsigned long long action_bits[PMAX];
+};
+
+template <int COL0, int H>
+__device__ __forceinline__ void stage_slot(const AccQ& q, double* mean_l, int lane) {
+    const int g = (lane >> 2) & 3;
+#pragma unroll
+    for (int cbh = 0; cbh < 2; ++cbh) {
+        double sum = q.v[2 * H + cbh][0];
+#pragma unroll
+        for (int rot = 1; rot < 4; ++rot)
+            sum += __shfl(q.v[2 * H + cbh][rot], (lane & ~12) | (((g - rot) & 3) << 2), 64);
+        mean_l[(16 * cbh + 4 * g + (lane & 3)) * PROW + COL0 + (lane >> 4)] = sum;
+    }
+}
+// B operands of group sgl (four slabs): all 16 requested at once (with two in flight, as in
+// quarter(), a single action slot waits for the LDS latency eight times per chunk)
+struct BQ { double v[4][CB]; };
+__device__ __forceinline__ void load_bq(BQ& b, const double* kxb, int sgl, const int (&qoff)[4]) {
+    const double* base = kxb + 2 * sgl * KXS2;
+#pragma unroll
+    for (int rot = 0; rot < 4; ++rot)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) b.v[rot][cb] = base[cb * 128 + qoff[rot]];
+}
+// the MFMAs of one group for NACT action slots: every B operand feeds NACT of them
+template <int NACT>
+__device__ __forceinline__ void quarter_n(AccQ (&q)[PG], const double (&aq)[PG], const BQ& b) {
+#pragma unroll
+    for (int g = 0; g < NACT; ++g) group_q<0>(q[g], aq[g], b.v[0]);
+#pragma unroll
+    for (int g = 0; g < NACT; ++g) group_q<1>(q[g], aq[g], b.v[1]);
+#pragma unroll
+    for (int g = 0; g < NACT; ++g) group_q<2>(q[g], aq[g], b.v[2]);
+#pragma unroll
+    for (int g = 0; g < NACT; ++g) group_q<3>(q[g], aq[g], b.v[3]);
+}
+
+// One pass of the workgroup over the chunks: this wavefront's action slots [g0, g0 + NACT) of its
+// tile (NACT = 0: it only keeps the chunk copies and barriers going).  Leaves the means of the
+// lanes whose action is one of the slots in mean[].
+template <int DT, int NACT>
+__device__ __forceinline__ void policy_pass(double* chunk_l, double* stage_l,
+                                            const double* __restrict__ tfrag,
+                                            const double* p_l, int d, int n_pad,
+                                            int tid, int lane, const int (&qoff)[4],
+                                            const double* btq, const int* slot_action, int g0,
+                                            int gid, double* mean_l) {
+    const int nchunks = n_pad / 32;
+    // A operand of this lane: row dd = lane & 3 of point 16 g + jq of every group g of 16 points
+    const int jq = 4 * ((lane >> 2) & 3) + (lane >> 4);
+    const double* bq[PG];                              // wave-uniform bases, indexed by the lane
+#pragma unroll
+    for (int g = 0; g < PG; ++g) {
+        const int a = NACT > 0 ? __builtin_amdgcn_readfirstlane(slot_action[g0 + (g < NACT ? g : 0)]) : 0;
+        bq[g] = btq + (int64_t)a * (n_pad / 16) * 64;
+    }
+    AccQ accq[PG];
+#pragma unroll
+    for (int g = 0; g < PG; ++g)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int rot = 0; rot < 4; ++rot) accq[g].v[cb][rot] = 0.0;
+    // A operands of chunk ch: the packed values of the slots' actions (global, L2) and P_j of the
+    // tile's row (LDS, computed once per tile).  Only LOADS here: the products are formed when the
+    // chunk is consumed, one iteration later (multiplying right away puts the round trips in
+    // front of the MFMAs of the chunk in flight).
+    auto load_a = [&](int ch, double (&raw0)[PG], double (&raw1)[PG], double& p0, double& p1) {
+        const int j0 = 32 * ch + jq;
+        p0 = p_l[j0];
+        p1 = p_l[j0 + 16];
+#pragma unroll
+        for (int g = 0; g < PG; ++g) {
+            raw0[g] = g < NACT ? bq[g][(2 * ch) * 64 + lane] : 0.0;
+            raw1[g] = g < NACT ? bq[g][(2 * ch + 1) * 64 + lane] : 0.0;
+        }
+    };
+    constexpr int COPIES = (KXBUF + 64 * W - 1) / (64 * W);
+    double copy[COPIES];
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+        for (int r = 0; r < COPIES; ++r) {
+            const int e = tid + 64 * W * r;
+            copy[r] = e < KXBUF ? tfrag[(int64_t)ch * KXBUF + e] : 0.0;
+        }
+    };
+    auto store_chunk = [&](double* dst) {
+#pragma unroll
+        for (int r = 0; r < COPIES; ++r) {
+            const int e = tid + 64 * W * r;
+            if (e < KXBUF) dst[e] = copy[r];
+        }
+    };
+    // Software pipeline: the B chunk ch + 1 is written into the other buffer at the top of
+    // iteration ch (its global loads were issued one iteration earlier), the A operands of chunk
+    // ch + 1 are requested before the MFMAs of chunk ch.  One barrier per chunk: behind it every
+    // wavefront has finished reading `cur` and writing `nxt`.
+    load_chunk(0);
+    __syncthreads();                                   // the previous pass has left both buffers
+    store_chunk(chunk_l);
+    load_chunk(nchunks > 1 ? 1 : 0);
+    double raw0[PG], raw1[PG], p0 = 1.0, p1 = 1.0;
+    if constexpr (NACT > 0) load_a(0, raw0, raw1, p0, p1);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const double* cur = chunk_l + (ch & 1) * KXBUF;
+        store_chunk(chunk_l + ((ch + 1) & 1) * KXBUF);
+        load_chunk(ch + 2 < nchunks ? ch + 2 : nchunks - 1);
+        if constexpr (NACT > 0) {
+            double aq0[PG], aq1[PG];
+#pragma unroll
+            for (int g = 0; g < PG; ++g) {
+                aq0[g] = (DT > 1) ? raw0[g] * p0 : raw0[g];
+                aq1[g] = (DT > 1) ? raw1[g] * p1 : raw1[g];
+            }
+            load_a(ch + 1 < nchunks ? ch + 1 : ch, raw0, raw1, p0, p1);
+            if constexpr (NACT <= 2) {
+                // few MFMAs per B operand: both groups requested up front
+                BQ b0, b1;
+                load_bq(b0, cur, 0, qoff);
+                load_bq(b1, cur, 1, qoff);
+                quarter_n<NACT>(accq, aq0, b0);
+                quarter_n<NACT>(accq, aq1, b1);
+            } else {
+                BQ b;
+                load_bq(b, cur, 0, qoff);
+                quarter_n<NACT>(accq, aq0, b);
+                load_bq(b, cur, 1, qoff);
+                quarter_n<NACT>(accq, aq1, b);
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (NACT > 0) {
+#pragma unroll
+        for (int g = 0; g < NACT; ++g) retire_q(accq[g]);
+        // slot by slot and half by half through the staging buffer: lane (row, block, col) holds
+        // partial sums, lane = cell collects its own action's means
+#pragma unroll
+        for (int g = 0; g < NACT; ++g) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                wave_sync();
+                if (h2 == 0) stage_slot<0, 0>(accq[g], stage_l, lane); else stage_slot<0, 1>(accq[g], stage_l, lane);
+                wave_sync();
+                if (gid == g0 + g && (lane >> 5) == h2) {
+#pragma unroll
+                    for (int k = 0; k < SL_D; ++k)
+                        if (k < d) mean_l[lane * SL_D + k] = stage_l[(lane & 31) * PROW + k];
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+}  // namespace bm4
+
+// The key the cells of a tile are grouped by, and the action value the packed A operand is built
+// from: the policy value rounded to a multiple of 2^-40 (-0 -> +0).  A table policy read at its own
+// vertices through the interpolant (SL_POLICY_TRI, what the reference does) returns the vertex
+// value only up to the rounding of the barycentric weights (a few 1e-14 on a 64^4 grid);
+// k_bellman_policy_mfma groups such values with a 1e-14 tolerance around a leader, here the
+// grouping has to be the same in every wavefront of the launch.  The rounding moves an action by
+// at most 4.5e-13 (its kernel factor E_j by ~1e-12 relative); the cell's own value is used for
+// the prior mean and the reward.
+__device__ __forceinline__ unsigned long long sl_b4_action_bits(double u) {
+    const double c = fabs(u) < 256.0 ? __builtin_rint(u * 0x1p40) * 0x1p-40 : u;
+    return (unsigned long long)__double_as_longlong(c + 0.0);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_bellman4_policy_distinct(
+    const SlDevModel M, SlAux aux, int64_t lo, int64_t hi, unsigned long long* list,
+    double* __restrict__ ucache) {
+    using namespace bm4;
+    const SlDims nd = sl_dims<DT, 1>(M);
+    const int d = nd.d, lane = threadIdx.x & 63;
+    // an interpolated policy walks the unit-cell simplices of its table: descriptor in LDS
+    __shared__ SlTriLds<true> tri_l;
+    aux = sl_stage_aux<true>(tri_l, aux);
+    for (int64_t base = lo + (int64_t)blockIdx.x * blockDim.x; base < hi;
+         base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t idx = base + threadIdx.x;
+        const bool valid = idx < hi;
+        const int64_t cidx = valid ? idx : hi - 1;
+        double x[SL_P], u[SL_M];
+        sl_index_to_state(M.m.grid, M.gf, d, cidx, x);
+        sl_policy_any<true>(M, nd, aux.tri, cidx, x, u);
+        if (valid) ucache[idx - lo] = u[0];
+        const unsigned long long bits = sl_b4_action_bits(u[0]);
+        // lanes 0 .. PMAX-1 hold a snapshot of the list: a value that is already in it costs no
+        // memory access (2.6e5 wavefronts walking 16 words with compare-and-swap cost 250 ms)
+        const unsigned long long seen =
+            lane < PMAX ? __atomic_load_n(&list[lane], __ATOMIC_RELAXED) : P_EMPTY;
+        uint64_t remaining = __ballot(valid);
+        while (remaining) {
+            const int leader = __ffsll((unsigned long long)remaining) - 1;
+            const unsigned long long lb = __shfl(bits, leader, 64);
+            remaining &= ~__ballot(bits == lb);
+            if (__ballot(seen == lb) != 0ull) continue;
+            if (lane == leader) {
+                bool placed = false;
+                for (int s = 0; s < PMAX && !placed; ++s) {
+                    const unsigned long long old = atomicCAS(&list[s], P_EMPTY, lb);
+                    placed = old == P_EMPTY || old == lb;
+                }
+                if (!placed) atomicExch(&list[PMAX], 1ull);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bellman4_policy_pack(const SlDevModel M, const SlGpDev gp,
+                                                              bm4::PolicyPack pk,
+                                                              double* __restrict__ pack) {
+    using namespace bm4;
+    const int d = M.m.grid.d;
+    const SlGpHeadDev& hd = gp.head[0];
+    const int src_pad = hd.n_pad, n_pad = pk.n_pad, dout = hd.dout;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    double* btq = pack + pk.btq;
+    const int64_t per_action = (int64_t)(n_pad / 16) * 64;
+    for (int64_t t = tid; t < per_action * pk.n_glob; t += nthreads) {
+        const int a = (int)(t / per_action);
+        const int64_t r = t - a * per_action;
+        const int l = (int)(r & 63), g = (int)(r >> 6);
+        const int dd = l & 3, j = 16 * g + 4 * ((l >> 2) & 3) + (l >> 4);
+        double v = 0.0;
+        if (dd < dout && j < hd.n) {
+            const double ua = __longlong_as_double((long long)pk.action_bits[a]);
+            const double dlt = hd.xs[d * src_pad + j] - ua * hd.inv_ls[d];
+            v = hd.variance * sl_exp_nonpos(-0.5 * (dlt * dlt)) * hd.alpha[j * dout + dd];
+        }
+        btq[t] = v;
+    }
+    int64_t stride = M.m.grid.num_points[d - 1];       // flat-index stride of axis d - 2
+    for (int k = d - 2; k >= 0; --k) {
+        const int nk = (int)M.m.grid.num_points[k];
+        double* tab = pack + pk.tab[k];
+        for (int64_t t = tid; t < (int64_t)nk * n_pad; t += nthreads) {
+            const int i = (int)(t / n_pad), j = (int)(t % n_pad);
+            double x[SL_P];
+            sl_index_to_state(M.m.grid, M.gf, d, (int64_t)i * stride, x);
+            double v = 0.0;
+            if (j < hd.n) {
+                const double dlt = hd.xs[k * src_pad + j] - x[k] * hd.inv_ls[k];
+                v = sl_exp_nonpos(-0.5 * (dlt * dlt));
+            }
+            tab[t] = v;
+        }
+        stride *= nk;
+    }
+    // the last axis in the fragment layout of a chunk buffer (k_bellman4's generation writes):
+    // point jj of the chunk, cell c of the segment -> (jj >> 3) KXS2 + (c >> 4) 128 + 32 (jj & 3)
+    // + ((jj >> 2) & 1) + 2 (((c & 15) + 4 ((jj & 3) >> 1)) & 15)
+    const int n_last = (int)M.m.grid.num_points[d - 1];
+    const int nchunks = n_pad / 32, segs = n_last / C;
+    double* tfrag = pack + pk.tfrag;
+    // (the padding words of the buffers were zeroed by the launcher)
+    for (int64_t t = tid; t < (int64_t)segs * nchunks * 32 * C; t += nthreads) {
+        const int c = (int)(t % C);
+        const int jj = (int)((t / C) % 32);
+        const int ch = (int)((t / (C * 32)) % nchunks);
+        const int seg = (int)(t / ((int64_t)C * 32 * nchunks));
+        const int j = 32 * ch + jj;
+        double x[SL_P];
+        sl_index_to_state(M.m.grid, M.gf, d, (int64_t)(seg * C + c), x);
+        double v = 0.0;
+        if (j < hd.n) {
+            const double dlt = hd.xs[(d - 1) * src_pad + j] - x[d - 1] * hd.inv_ls[d - 1];
+            v = sl_exp_nonpos(-0.5 * (dlt * dlt));
+        }
+        const int off = (jj >> 3) * KXS2 + (c >> 4) * 128 + 32 * (jj & 3) + ((jj >> 2) & 1) +
+                        2 * (((c & 15) + 4 * ((jj & 3) >> 1)) & 15);
+        tfrag[((int64_t)seg * nchunks + ch) * KXBUF + off] = v;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(64 * bm4::W) void k_bellman4_policy(
+    const SlDevModel M, const SlGpDev gp, SlAux aux, bm4::PolicyPack pk, int64_t lo, int64_t hi,
+    const double* __restrict__ pack, const double* __restrict__ ucache, double* __restrict__ v_new,
+    double* __restrict__ stats, int flags) {
+    // ucache[idx - lo]: the policy's action at every cell (k_bellman4_policy_distinct evaluated it)
+    // flags (SL_B4P_FLAGS, diagnostics): 1 no GEMM passes, 2 no value-table lookups
+    using namespace bm4;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red_max[W], red_sum[W];
+    __shared__ int slot_action[W][PMAX];
+    __shared__ int wave_ng[W];
+    __shared__ SlTri vt_lds;
+    sl_stage_tri(&vt_lds, &aux.tri[0]);
+    const SlTri& vt = vt_lds;
+    const SlDims nd = sl_dims<DT, 1>(M);
+    const int d = nd.d, p = nd.p;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double* chunk_l = smem;                            // two chunk buffers of the workgroup
+    double* stage_l = smem + 2 * KXBUF + (size_t)wave * 32 * PROW;
+    double* mean_l = smem + 2 * KXBUF + (size_t)W * 32 * PROW + (size_t)wave * 64 * SL_D;
+    double* p_l = smem + 2 * KXBUF + (size_t)W * 32 * PROW + (size_t)W * 64 * SL_D + (size_t)wave * pk.n_pad;
+    const int n_pad = pk.n_pad, nchunks = n_pad / 32;
+    const int lk = lane >> 4, blk = (lane >> 2) & 3, low = lane & 3;
+    int qoff[4];
+#pragma unroll
+    for (int rot = 0; rot < 4; ++rot)
+        qoff[rot] = (blk >> 1) * KXS2 + 32 * lk + 2 * ((4 * ((blk + rot) & 3) + low + 4 * (lk >> 1)) & 15) + (blk & 1);
+    const double* btq = pack + pk.btq;
+    int* my_slots = slot_action[wave];
+
+    double lmax = 0.0, lsum = 0.0;
+    // workgroup step = eight consecutive rows of the last axis x one 64-cell segment
+    const int64_t n_last = M.m.grid.num_points[d - 1];
+    const int64_t segs = n_last / C;
+    const int64_t row_lo = lo / n_last, row_hi = (hi + n_last - 1) / n_last;
+    const int64_t nsteps = ((row_hi - row_lo + W - 1) / W) * segs;
+    for (int64_t step = blockIdx.x; step < nsteps; step += gridDim.x) {
+        const int64_t seg = step % segs, row = row_lo + (step / segs) * W + wave;
+        const int64_t wbase = row * n_last + seg * C;
+        const bool live = row < row_hi && wbase >= lo && wbase < hi;   // wave-uniform
+        const int64_t tbase = live ? wbase : lo;          // wave-uniform
+        const int64_t idx = tbase + lane;
+        int64_t ijk[SL_D];
+        sl_unravel(M.m.grid, M.gf, d, tbase, ijk);
+        const double* trow[SL_D];                      // wave-uniform row pointers (scalar registers)
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) {
+            const int ik = k < d - 1 ? __builtin_amdgcn_readfirstlane((int)ijk[k]) : 0;
+            trow[k] = pack + pk.tab[k < d - 1 ? k : 0] + (int64_t)ik * n_pad;
+        }
+        const double u0 = ucache[idx - lo];
+        // P_j = prod_{k < d-1} T_k[i_k][j] of the tile's row, once per tile
+        for (int j = lane; j < n_pad; j += 64) {
+            double v = 1.0;
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k)
+                if (k < d - 1) v = (k == 0) ? trow[0][j] : v * trow[k][j];
+            p_l[j] = v;
+        }
+        // the tile's distinct actions, as indices into the launch's list
+        const unsigned long long bits = sl_b4_action_bits(u0);
+        int gid = 0, ng = 0;
+        uint64_t remaining = live ? ~0ull : 0ull;
+        while (remaining) {
+            const int leader = __ffsll((unsigned long long)remaining) - 1;
+            const unsigned long long lb = __shfl(bits, leader, 64);
+            const uint64_t same = __ballot(bits == lb);
+            if ((same >> lane) & 1ull) gid = ng;
+            int a = 0;
+            for (int s = 1; s < pk.n_glob; ++s) a = pk.action_bits[s] == lb ? s : a;
+            if (lane == 0) my_slots[ng] = a;
+            remaining &= ~same;
+            ++ng;
+        }
+        ng = __builtin_amdgcn_readfirstlane(ng);
+        if (lane == 0) wave_ng[wave] = ng;
+        __syncthreads();
+        int ng_max = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) ng_max = wave_ng[w] > ng_max ? wave_ng[w] : ng_max;
+        const double* tfrag = pack + pk.tfrag + seg * nchunks * (int64_t)KXBUF;
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) mean_l[lane * SL_D + k] = 0.0;
+        for (int g0 = (flags & 1) ? ng_max : 0; g0 < ng_max; g0 += PG) {
+            const int nact = ng - g0 < 0 ? 0 : (ng - g0 < PG ? ng - g0 : PG);
+            if (nact == 0) policy_pass<DT, 0>(chunk_l, stage_l, tfrag, p_l, d, n_pad, tid, lane, qoff, btq, my_slots, g0, gid, mean_l);
+            else if (nact == 1) policy_pass<DT, 1>(chunk_l, stage_l, tfrag, p_l, d, n_pad, tid, lane, qoff, btq, my_slots, g0, gid, mean_l);
+            else if (nact == 2) policy_pass<DT, 2>(chunk_l, stage_l, tfrag, p_l, d, n_pad, tid, lane, qoff, btq, my_slots, g0, gid, mean_l);
+            else if (nact == 3) policy_pass<DT, 3>(chunk_l, stage_l, tfrag, p_l, d, n_pad, tid, lane, qoff, btq, my_slots, g0, gid, mean_l);
+            else policy_pass<DT, 4>(chunk_l, stage_l, tfrag, p_l, d, n_pad, tid, lane, qoff, btq, my_slots, g0, gid, mean_l);
+        }
+        wave_sync();
+        if (live) {
+            // (state and action are recomputed here: nothing of the cell stays in registers
+            // across the passes)
+            double x[SL_P], u[SL_M], prior[SL_D], nxt[SL_D];
+            sl_index_to_state(M.m.grid, M.gf, d, idx, x);
+            u[0] = ucache[idx - lo];
+            sl_append_action(nd, u, x);
+            sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) if (k < d) nxt[k] = mean_l[lane * SL_D + k] + prior[k];
+            const double r = sl_quadratic(M.m.reward, p, x);
+            double v = (flags & 2) ? nxt[0] : sl_tri_value_fast<DT>(vt, nxt);
+            if (M.m.value.negate) v = v * -1.0;
+            const double tq = M.m.gamma * v;
+            const double q = r + tq;
+            v_new[idx - lo] = q;
+            double v_old = vt.table[idx * vt.ncols];
+            double v_int = (flags & 2) ? x[0] : sl_tri_value_fast<DT>(vt, x);
+            if (M.m.value.negate) { v_old = v_old * -1.0; v_int = v_int * -1.0; }
+            lmax = fmax(lmax, fabs(q - v_old));
+            const double diff = q - v_int;
+            lsum = fma(diff, diff, lsum);
+        }
+        __syncthreads();                               // wave_ng and the slot lists are reused
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        lmax = fmax(lmax, __shfl_xor(lmax, o, 64));
+        lsum += __shfl_xor(lsum, o, 64);
+    }
+    if (lane == 0) { red_max[wave] = lmax; red_sum[wave] = lsum; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < W; ++w) { lmax = fmax(lmax, red_max[w]); lsum += red_sum[w]; }
+        atomicMax(reinterpret_cast<unsigned long long*>(&stats[0]),
+                  (unsigned long long)__double_as_longlong(lmax));
+        atomicAdd(&stats[1], lsum);
+    }
+}
+
+// Sets *done = 1 when k_bellman4_policy took the policy-evaluation sweep: the conditions of the max
+// sweep below, a policy with at most PMAX distinct values on [lo, hi).
+int sl_bellman4_policy_launch(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_v_new, double* d_stats,
+                              int* done) {
+    using namespace bm4;
+    *done = 0;
+    const bool verbose = getenv("SL_BELLMAN4_POLICY_VERBOSE") != nullptr;
+#define SL_B4P_DECLINE(why)                                                          \
+    do {                                                                             \
+        if (verbose) fprintf(stderr, "k_bellman4_policy declined: %s\n", why);      \
+        return SL_OK;                                                                \
+    } while (0)
+    const char* env = getenv("SL_BELLMAN4");
+    if (env && env[0] == '0') SL_B4P_DECLINE("SL_BELLMAN4=0");
+    env = getenv("SL_BELLMAN4_POLICY");
+    if (env && env[0] == '0') SL_B4P_DECLINE("SL_BELLMAN4_POLICY=0");
+    const SlDevModel& M = ctx->h_model;
+    const int d = M.m.grid.d;
+    if (M.m.policy.m != 1 || ctx->h_gp.nheads != 1) SL_B4P_DECLINE("action dimension / number of GP heads");
+    const int variant = sl_dim_variant_of(M);
+    if (variant != 4 && variant != 2) SL_B4P_DECLINE("state dimension");
+    const SlGpHeadHost& hh = ctx->gp_heads[0];
+    if (hh.dout != d || hh.col0 != 0) SL_B4P_DECLINE("the head does not cover the state");
+    const int n_pad = ((hh.n + 31) / 32) * 32;
+    const int64_t n_last = M.m.grid.num_points[d - 1];
+    if (n_last % C != 0 || lo % C != 0 || hi % C != 0 || hi <= lo)
+        SL_B4P_DECLINE("last axis / index range not a multiple of 64 cells");
+    // two chunk buffers of the workgroup, staged means, final means and P_j per wavefront
+    const size_t lds = sizeof(double) * (size_t)(2 * KXBUF + W * 32 * PROW + W * 64 * SL_D + W * n_pad);
+    if (lds + sizeof(SlTri) + 4096 > 160 * 1024) SL_B4P_DECLINE("too many training points for the LDS budget");
+    PolicyPack pk;
+    memset(&pk, 0, sizeof(pk));
+    pk.n_pad = n_pad;
+    int64_t cursor = PMAX + 8;                         // the distinct list sits in front
+    pk.btq = cursor;
+    cursor += (int64_t)PMAX * (n_pad / 16) * 64;
+    pk.tfrag = cursor;
+    cursor += (n_last / C) * (int64_t)(n_pad / 32) * KXBUF;
+    for (int k = 0; k < d - 1; ++k) {
+        pk.tab[k] = cursor;
+        cursor += M.m.grid.num_points[k] * (int64_t)n_pad;
+    }
+    const int64_t ucache_off = cursor;                 // the policy's action at every cell
+    cursor += hi - lo;
+    const size_t need = sizeof(double) * (size_t)cursor;
+    if (need > ctx->scratch_bytes) {
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_scratch, need));
+        ctx->scratch_bytes = need;
+    }
+    double* pack = reinterpret_cast<double*>(ctx->d_scratch);
+    double* ucache = pack + ucache_off;
+    unsigned long long* list = reinterpret_cast<unsigned long long*>(pack);
+    unsigned long long h_list[PMAX + 1];
+    for (int s = 0; s < PMAX; ++s) h_list[s] = P_EMPTY;
+    h_list[PMAX] = 0;
+    SL_HIP_CHECK(ctx, hipMemcpyAsync(list, h_list, sizeof(h_list), hipMemcpyHostToDevice, ctx->stream));
+    SlAux aux{ctx->d_tri, ctx->d_net};
+    {
+        const int64_t nblk = (hi - lo + 255) / 256;
+        const int blocks = (int)(nblk < 8 * (int64_t)ctx->num_cu ? nblk : 8 * (int64_t)ctx->num_cu);
+        if (variant == 4)
+            hipLaunchKernelGGL(k_bellman4_policy_distinct<4>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               ctx->h_model, aux, lo, hi, list, ucache);
+        else
+            hipLaunchKernelGGL(k_bellman4_policy_distinct<2>, dim3(blocks), dim3(256), 0, ctx->stream,
+                               ctx->h_model, aux, lo, hi, list, ucache);
+        SL_HIP_CHECK(ctx, hipGetLastError());
+    }
+    SL_HIP_CHECK(ctx, hipMemcpyAsync(h_list, list, sizeof(h_list), hipMemcpyDeviceToHost, ctx->stream));
+    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_list[PMAX] != 0) SL_B4P_DECLINE("more than 64 distinct policy values (a smooth policy)");
+    for (int s = 0; s < PMAX; ++s)
+        if (h_list[s] != P_EMPTY) pk.action_bits[pk.n_glob++] = h_list[s];
+    if (pk.n_glob == 0) SL_B4P_DECLINE("no policy value found");
+#undef SL_B4P_DECLINE
+    SL_HIP_CHECK(ctx, hipMemsetAsync(pack + pk.tfrag, 0,
+                                     sizeof(double) * (size_t)((n_last / C) * (int64_t)(n_pad / 32) * KXBUF),
+                                     ctx->stream));
+    hipLaunchKernelGGL(k_bellman4_policy_pack, dim3(512), dim3(256), 0, ctx->stream, ctx->h_model,
+                       ctx->h_gp, pk, pack);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    const int64_t rows = (hi + n_last - 1) / n_last - lo / n_last;
+    const int64_t nsteps = ((rows + W - 1) / W) * (n_last / C);
+    const int blocks = (int)(nsteps < ctx->num_cu ? nsteps : ctx->num_cu);
+#define SL_B4P_LAUNCH(D_)                                                                         \
+    do {                                                                                          \
+        auto kern = k_bellman4_policy<D_>;                                                        \
+        SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                              (int)lds));                                         \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds, ctx->stream, ctx->h_model,      \
+                           ctx->h_gp, aux, pk, lo, hi, pack, ucache, d_v_new, d_stats, flags);    \
+    } while (0)
+    const char* fenv = getenv("SL_B4P_FLAGS");
+    const int flags = fenv ? atoi(fenv) : 0;
+    if (variant == 4) SL_B4P_LAUNCH(4); else SL_B4P_LAUNCH(2);
+#undef SL_B4P_LAUNCH
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    sl_note_kernel(ctx, false, "k_bellman4_policy<d=%d> (%d distinct actions)", variant == 4 ? 4 : 2,
+                   pk.n_glob);
+    *done = 1;
+    return SL_OK;
 }
 
 // Sets *done = 1 when this kernel took the sweep: one shared-input GP head covering the state,

@@ -81,6 +81,8 @@ int sl_gp_small_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
                        int* nblocks, double* d_dbg, const double* d_points);
 int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, double* d_v_new,
                        int32_t* d_argmax, double* d_q, double* d_stats, int* done);
+int sl_bellman4_policy_launch(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_v_new, double* d_stats,
+                              int* done);
 int sl_nn_values_launch(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values);
 int sl_nn_check_launch(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
                        const double* d_values, const double* d_records, uint64_t* d_neg_bits,

@@ -374,3 +374,82 @@ def test_bellman_optimality_sweep(sl, name, kw, nv, na):
     r1 = rl.value_iteration(actions)
     r2 = rl.value_iteration(actions)
     assert r2 < r1
+
+
+@pytest.mark.parametrize("name,kw,nv,na,style", [
+    ("pendulum", dict(n_gp=70), [12, 64], 9, "greedy"),        # the loop's own policy
+    ("pendulum", dict(n_gp=70), [5, 128], 3, "random"),        # two tiles per row, <= 3 per tile
+    ("pendulum", dict(n_gp=100), [7, 64], 9, "random"),        # 9 distinct per tile: three passes
+    ("cartpole", dict(n_gp=90), [3, 4, 3, 64], 16, "random"),  # 16 distinct: four passes of four
+    ("cartpole", dict(n_gp=130), [2, 3, 2, 128], 5, "blocks"), # runs of equal actions, 5 = 4 + 1
+    ("pendulum", dict(n_gp=70), [6, 64], 1, "random"),         # a constant table
+])
+def test_policy_evaluation_4x4x4_kernel(sl, name, kw, nv, na, style, monkeypatch):
+    """k_bellman4_policy (sl_bellman4.hip): policy evaluation with a piecewise-constant table
+    policy on v_mfma_f64_4x4x4_4b_f64 - one quarter-block GEMM per distinct action of a 64-cell
+    tile - against the oracle (reinforcement_learning.py:98-104, 135-140) and against
+    k_bellman_policy_mfma (SL_BELLMAN4_POLICY=0) on the same inputs."""
+    case = cases.make_case(name, num_points=nv, **kw)
+    actions = np.linspace(-1, 1, na)[:, None] if na > 1 else np.array([[0.3]])
+    rng = np.random.default_rng(5)
+    results = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SL_BELLMAN4_POLICY", flag)
+        rl, orl, vf, ovf = _rl_pair(sl, case, nv)
+        grid, ogrid = vf.discretization, ovf.discretization
+        n = grid.nindex
+        if style == "greedy":
+            rl.policy = sl.Triangulation(grid, np.zeros((n, 1)))
+            rl.discrete_policy_optimization(actions)
+            table = rl.policy._host_parameters().copy()
+        elif style == "random":
+            table = actions[np.random.default_rng(6).integers(0, na, n)]
+        else:
+            runs = np.repeat(np.random.default_rng(7).integers(0, na, -(-n // 23)), 23)[:n]
+            table = actions[runs]
+        if style == "greedy":
+            # a Triangulation read at its own vertices, like the reference's loop
+            rl.policy = sl.Triangulation(grid, table)
+            orl.policy = oracle.Triangulation(ogrid, table)
+        else:
+            # a per-vertex action table (what value_iteration(action_space) adopts): a random table
+            # read through the interpolant has more than 16 distinct values (the `%` wrap-around)
+            rl.policy = np.ascontiguousarray(table)
+            orl.policy = lambda states, _table=table: _table
+        v0 = -rng.random((n, 1)) if flag == "1" else results["v0"]
+        results.setdefault("v0", v0)
+        vf.parameters = v0.copy()
+        ovf.parameters = v0.copy()
+        rl.value_iteration()
+        kernel = rl._ctx.last_kernel()
+        results[flag] = (vf._host_parameters().copy(), rl.last_residual, rl.bellmann_error(), kernel)
+    new, old = results["1"], results["0"]
+    assert "k_bellman4_policy" in new[3] and "k_bellman_policy_mfma" in old[3], (new[3], old[3])
+    assert_allclose(new[0], old[0], rtol=1e-11, atol=1e-13)
+    assert_allclose(new[1], old[1], rtol=1e-9)
+    assert_allclose(new[2], old[2], rtol=1e-9)
+    x = orl.state_space
+    nxt = orl.dynamics(x, orl.policy(x))
+    ok = ~ambiguous_points(ovf, nxt[0])
+    if style == "greedy":
+        ok &= ~ambiguous_points(orl.policy, x)
+    orl.value_iteration()
+    assert ok.mean() > 0.5
+    assert_allclose(new[0][ok], ovf.parameters[ok], rtol=1e-9, atol=1e-12)
+
+
+def test_policy_evaluation_smooth_policy_keeps_the_16x16x4_kernel(sl):
+    """More than 32 distinct policy values: k_bellman4_policy declines, k_bellman_policy_mfma (or
+    the scalar kernel) evaluates the policy as before."""
+    case = cases.make_case("pendulum", num_points=[6, 64], n_gp=70)
+    rl, orl, vf, ovf = _rl_pair(sl, case, [6, 64])
+    grid, ogrid = vf.discretization, ovf.discretization
+    table = np.linspace(-1, 1, grid.nindex)[:, None]
+    rl.policy = sl.Triangulation(grid, table)
+    orl.policy = oracle.Triangulation(ogrid, table)
+    rl.value_iteration()
+    assert "k_bellman4_policy" not in rl._ctx.last_kernel()
+    x = orl.state_space
+    ok = ~ambiguous_points(orl.policy, x) & ~ambiguous_points(ovf, orl.dynamics(x, orl.policy(x))[0])
+    orl.value_iteration()
+    assert_allclose(vf._host_parameters()[ok], ovf.parameters[ok], rtol=1e-9, atol=1e-12)

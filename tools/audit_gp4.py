@@ -97,7 +97,7 @@ def audit(path, prefix="_Z11k_gp_sweep4", min_loops=8, owned=256):
     return report, problems
 
 
-def audit_in_place(path, prefix="_Z10k_bellman4"):
+def audit_in_place(path, prefix=r"_Z1[07]k_bellman4(?:_policy)?I"):
     """k_bellman4 keeps its accumulators as ordinary register values that inline-asm MFMAs update
     in place.  The compiler sees those asm statements as opaque: a register copy or a spill of an
     accumulator inside the MFMA loop would read a result the hardware has not retired yet (no
@@ -117,47 +117,53 @@ def audit_in_place(path, prefix="_Z10k_bellman4"):
             mm = re.match(r"^(\.LBB\d+_\d+):", line)
             if mm:
                 labels[mm.group(1)] = i
-        best = None
+        loops = []
         for i, line in enumerate(body):
             mm = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", line)
             if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
-                seg = body[labels[mm.group(1)]:i + 1]
-                if any("v_mfma" in l for l in seg) and (best is None or len(seg) < len(best)):
-                    best = seg
-        if best is None:
+                start = labels[mm.group(1)]
+                if any("v_mfma" in l for l in body[start:i + 1]):
+                    loops.append((start, i))
+        # innermost MFMA loops: those that contain no other MFMA loop (k_bellman4 has one chunk
+        # loop, k_bellman4_policy one per number of action slots)
+        inner = [(a, b) for (a, b) in loops
+                 if not any((c, e) != (a, b) and a <= c and e <= b for (c, e) in loops)]
+        if not inner:
             problems.append("%s: no MFMA loop found" % name)
             continue
-        mfmas = [l for l in best if "v_mfma" in l]
-        moved = [l.strip() for l in mfmas if not re.search(
-            r"v_mfma_f64_4x4x4_4b_f64 (v\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], \1", l)]
-        # registers the MFMAs accumulate into, and every other instruction of the loop naming one
-        accs = set()
-        for l in mfmas:
-            mm = re.search(r"v_mfma_f64_4x4x4_4b_f64 v\[(\d+):(\d+)\]", l)
-            accs.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
-        touching = []
-        for l in best:
-            code = l.split(";")[0]
-            if "v_mfma" in code or not code.strip() or code.strip().startswith("."):
-                continue
-            regs = set()
-            for mm in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", code):
-                if mm.group(3) is not None:
-                    regs.add(int(mm.group(3)))
-                else:
-                    regs.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
-            if regs & accs:
-                touching.append(code.strip())
-        spills = [l.strip() for l in best if "scratch_" in l]
-        report.append("%s: %d MFMAs on %d accumulator registers in the chunk loop, %d out of place, "
-                      "%d other instructions touch an accumulator, %d scratch accesses"
-                      % (name, len(mfmas), len(accs), len(moved), len(touching), len(spills)))
-        if moved:
-            problems.append("%s: out-of-place MFMAs: %s" % (name, moved[:2]))
-        if touching:
-            problems.append("%s: accumulators touched inside the MFMA loop: %s" % (name, touching[:3]))
-        if spills:
-            problems.append("%s: scratch traffic inside the MFMA loop: %s" % (name, spills[:2]))
+        for start, end in inner:
+            best = body[start:end + 1]
+            mfmas = [l for l in best if "v_mfma" in l]
+            moved = [l.strip() for l in mfmas if not re.search(
+                r"v_mfma_f64_4x4x4_4b_f64 (v\[\d+:\d+\]), v\[\d+:\d+\], v\[\d+:\d+\], \1", l)]
+            # registers the MFMAs accumulate into, and every other instruction of the loop naming one
+            accs = set()
+            for l in mfmas:
+                mm = re.search(r"v_mfma_f64_4x4x4_4b_f64 v\[(\d+):(\d+)\]", l)
+                accs.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+            touching = []
+            for l in best:
+                code = l.split(";")[0]
+                if "v_mfma" in code or not code.strip() or code.strip().startswith("."):
+                    continue
+                regs = set()
+                for mm in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", code):
+                    if mm.group(3) is not None:
+                        regs.add(int(mm.group(3)))
+                    else:
+                        regs.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+                if regs & accs:
+                    touching.append(code.strip())
+            spills = [l.strip() for l in best if "scratch_" in l]
+            report.append("%s: %d MFMAs on %d accumulator registers in the chunk loop, %d out of "
+                          "place, %d other instructions touch an accumulator, %d scratch accesses"
+                          % (name, len(mfmas), len(accs), len(moved), len(touching), len(spills)))
+            if moved:
+                problems.append("%s: out-of-place MFMAs: %s" % (name, moved[:2]))
+            if touching:
+                problems.append("%s: accumulators touched inside the MFMA loop: %s" % (name, touching[:3]))
+            if spills:
+                problems.append("%s: scratch traffic inside the MFMA loop: %s" % (name, spills[:2]))
     if not report:
         problems.append("no %s kernel found in %s" % (prefix, path))
     return report, problems
