@@ -223,6 +223,8 @@ struct Pack {
                                 // point 16 g + 4 (i >> 2) + k
     int64_t bt;                 // Bt fragments [NRB][nslab2][64 lanes][2]
     int64_t tab[SL_D];          // T_k [N_k][n_pad], every axis
+    int64_t tfrag;              // < 0, or [segments][n_pad / 32][KXBUF]: the last axis' table of a
+                                // 32-point chunk in fragment layout (k_bellman4s)
     int32_t nslab2, n_pad, nrb, quarter;
 };
 
@@ -291,6 +293,32 @@ __global__ __launch_bounds__(256) void k_bellman4_pack(const SlDevModel M, const
             tab[t] = v;
         }
         stride *= nk;
+    }
+    if (pk.tfrag >= 0) {
+        // point jj of a chunk, cell c of a segment -> (jj >> 3) KXS2 + (c >> 4) 128 + 32 (jj & 3)
+        // + ((jj >> 2) & 1) + 2 (((c & 15) + 4 ((jj & 3) >> 1)) & 15): what the generation of
+        // k_bellman4 writes (the padding words were zeroed by the launcher)
+        using namespace bm4;
+        const int n_last = (int)M.m.grid.num_points[d - 1];
+        const int nchunks = n_pad / 32, segs = n_last / C;
+        double* tfrag = pack + pk.tfrag;
+        for (int64_t t = tid; t < (int64_t)segs * nchunks * 32 * C; t += nthreads) {
+            const int c = (int)(t % C);
+            const int jj = (int)((t / C) % 32);
+            const int ch = (int)((t / (C * 32)) % nchunks);
+            const int seg = (int)(t / ((int64_t)C * 32 * nchunks));
+            const int j = 32 * ch + jj;
+            double x[SL_P];
+            sl_index_to_state(M.m.grid, M.gf, d, (int64_t)(seg * C + c), x);
+            double v = 0.0;
+            if (j < hd.n) {
+                const double dlt = hd.xs[(d - 1) * src_pad + j] - x[d - 1] * hd.inv_ls[d - 1];
+                v = sl_exp_nonpos(-0.5 * (dlt * dlt));
+            }
+            const int off = (jj >> 3) * KXS2 + (c >> 4) * 128 + 32 * (jj & 3) + ((jj >> 2) & 1) +
+                            2 * (((c & 15) + 4 * ((jj & 3) >> 1)) & 15);
+            tfrag[((int64_t)seg * nchunks + ch) * KXBUF + off] = v;
+        }
     }
 }
 
@@ -761,6 +789,218 @@ __device__ __forceinline__ void policy_pass(double* chunk_l, double* stage_l,
 
 }  // namespace bm4
 
+// ---------------------------------------------------------------------------------------------
+// k_bellman4s: the GEMM half of the split max sweep with the B operand shared by the workgroup
+// ---------------------------------------------------------------------------------------------
+// Same rows, accumulators and MFMA groups as k_bellman4, with the factors grouped as in
+// k_bellman4_policy: mean[(a, dd)][cell] = sum_j (Bt[(a, dd)][j] P_j) T_last[cell][j].  The product
+// P_j of the leading axes' tables (once per tile, in LDS) scales the A fragments after they
+// arrive - two multiplies per row block and slab pair instead of one multiply, one L2 load and one
+// LDS store per element of S - and the B operand, the last axis' table in fragment layout
+// (Pack::tfrag, written once per sweep), is copied into LDS once per workgroup and chunk for all
+// eight wavefronts (double buffered, one barrier per chunk).  A fragments of chunk ch + 1 are
+// requested as soon as the MFMAs of their slab pair of chunk ch are issued.  Split mode only: the
+// means go to means[row][cell] for k_bellman_lookup, one row block at a time through a
+// [32 cells][17] staging buffer per wavefront.
+namespace bm4 {
+constexpr int SROW = 17;
+
+template <int NRB, int R, int H>
+__device__ __forceinline__ void stage_row_block(const Acc<NRB>& acc, double* st, int lane) {
+    const int b = (lane >> 2) & 3;
+#pragma unroll
+    for (int cbh = 0; cbh < 2; ++cbh)
+#pragma unroll
+        for (int rot = 0; rot < 4; ++rot)
+            st[(16 * cbh + 4 * ((b + rot) & 3) + (lane & 3)) * SROW + 4 * b + (lane >> 4)] =
+                acc.v[R][2 * H + cbh][rot];
+}
+template <int NRB>
+__device__ __forceinline__ void scale_a(AFrag<NRB>& a, double px, double py) {
+#pragma unroll
+    for (int r = 0; r < NRB; ++r) {
+        a.v[r].x = a.v[r].x * px;
+        a.v[r].y = a.v[r].y * py;
+    }
+}
+// rows [row0, row0 + nrows) of the staged half to means[row][cell]: lane = (cell, half of the rows)
+__device__ __forceinline__ void write_rows(const double* st, int stride_l, int row0, int nrows,
+                                           int rows, double* dst, int64_t means_stride, int lane) {
+    const int cell = lane & 31;
+    for (int row = lane >> 5; row < nrows; row += 2)
+        if (row0 + row < rows) dst[(int64_t)(row0 + row) * means_stride + cell] = st[cell * stride_l + row];
+}
+}  // namespace bm4
+
+template <int DT, int NRB, bool Q>
+__global__ __launch_bounds__(64 * bm4::W) void k_bellman4s(
+    const SlDevModel M, const SlGpDev gp, bm4::Pack pk, int64_t tfrag_off, int64_t lo, int64_t hi,
+    int n_actions, const double* __restrict__ pack, double* __restrict__ means_out,
+    int64_t means_stride) {
+    using namespace bm4;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SlDims nd = sl_dims<DT, 1>(M);
+    const int d = nd.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const SlGpHeadDev& hd = gp.head[0];
+    const int n_pad = pk.n_pad, nslab2 = pk.nslab2, rows = n_actions * hd.dout;
+    const int nchunks = n_pad / 32;
+    double* chunk_l = smem;                            // two chunk buffers of the workgroup
+    double* stage_l = smem + 2 * KXBUF + (size_t)wave * 32 * SROW;
+    double* p_l = smem + 2 * KXBUF + (size_t)W * 32 * SROW + (size_t)wave * n_pad;
+    __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(pack + pk.bt), 0, 0x7fffffff, 0x27000);
+    const int lk = lane >> 4, blk = (lane >> 2) & 3, low = lane & 3;
+    int boff[4], qoff[4];
+#pragma unroll
+    for (int rot = 0; rot < 4; ++rot) {
+        boff[rot] = 2 * (16 * lk + ((4 * ((blk + rot) & 3) + low + 4 * (lk >> 1)) & 15));
+        qoff[rot] = (blk >> 1) * KXS2 + 32 * lk + 2 * ((4 * ((blk + rot) & 3) + low + 4 * (lk >> 1)) & 15) + (blk & 1);
+    }
+    const int jq = 4 * blk + lk;                       // quarter block: point 16 g + jq of group g
+    const double* btq = pack + pk.btq;
+    constexpr int COPIES = (KXBUF + 64 * W - 1) / (64 * W);
+
+    const int64_t n_last = M.m.grid.num_points[d - 1];
+    const int64_t segs = n_last / C;
+    const int64_t row_lo = lo / n_last, row_hi = (hi + n_last - 1) / n_last;
+    const int64_t nsteps = ((row_hi - row_lo + W - 1) / W) * segs;
+    for (int64_t step = blockIdx.x; step < nsteps; step += gridDim.x) {
+        const int64_t seg = step % segs, row = row_lo + (step / segs) * W + wave;
+        const int64_t wbase = row * n_last + seg * C;
+        const bool live = row < row_hi && wbase >= lo && wbase < hi;   // wave-uniform
+        const int64_t tbase = live ? wbase : lo;
+        int64_t ijk[SL_D];
+        sl_unravel(M.m.grid, M.gf, d, tbase, ijk);
+        // P_j = prod_{k < d-1} T_k[i_k][j] of the tile's row, once per tile
+        {
+            const double* trow[SL_D];
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) {
+                const int ik = k < d - 1 ? __builtin_amdgcn_readfirstlane((int)ijk[k]) : 0;
+                trow[k] = pack + pk.tab[k < d - 1 ? k : 0] + (int64_t)ik * n_pad;
+            }
+            for (int j = lane; j < n_pad; j += 64) {
+                double v = 1.0;
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k)
+                    if (k < d - 1) v = (k == 0) ? trow[0][j] : v * trow[k][j];
+                p_l[j] = v;
+            }
+        }
+        const double* tfrag = pack + tfrag_off + seg * nchunks * (int64_t)KXBUF;
+        Acc<NRB> acc;
+#pragma unroll
+        for (int r = 0; r < NRB; ++r)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int rot = 0; rot < 4; ++rot) acc.v[r][cb][rot] = 0.0;
+        AccQ accq;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int rot = 0; rot < 4; ++rot) accq.v[cb][rot] = 0.0;
+        double copy[COPIES];
+        auto load_chunk = [&](int ch) {
+#pragma unroll
+            for (int r = 0; r < COPIES; ++r) {
+                const int e = tid + 64 * W * r;
+                copy[r] = e < KXBUF ? tfrag[(int64_t)ch * KXBUF + e] : 0.0;
+            }
+        };
+        auto store_chunk = [&](double* dst) {
+#pragma unroll
+            for (int r = 0; r < COPIES; ++r) {
+                const int e = tid + 64 * W * r;
+                if (e < KXBUF) dst[e] = copy[r];
+            }
+        };
+        load_chunk(0);
+        __syncthreads();                               // the previous step has left both buffers
+        store_chunk(chunk_l);
+        load_chunk(nchunks > 1 ? 1 : 0);
+        AFrag<NRB> a0, a1, a2, a3;
+        load_a<NRB>(a0, rsrc, nslab2, 0, lane);
+        load_a<NRB>(a1, rsrc, nslab2, 1, lane);
+        load_a<NRB>(a2, rsrc, nslab2, 2, lane);
+        load_a<NRB>(a3, rsrc, nslab2, 3, lane);
+        double aq0 = 0.0, aq1 = 0.0;
+        if (Q) {
+            aq0 = btq[lane];
+            aq1 = btq[64 + lane];
+        }
+        __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const double* cur = chunk_l + (ch & 1) * KXBUF;
+            store_chunk(chunk_l + ((ch + 1) & 1) * KXBUF);
+            load_chunk(ch + 2 < nchunks ? ch + 2 : nchunks - 1);
+            const int chn = ch + 1 < nchunks ? ch + 1 : ch;
+            // the fragments requested during the previous chunk, scaled by P_j of their points:
+            // .x = slab 2 s, .y = slab 2 s + 1 of slab pair s: points 32 ch + 8 s + (0 | 4) + lk
+            if (DT > 1) {
+                const double* pc = p_l + 32 * ch + lk;
+                scale_a<NRB>(a0, pc[0], pc[4]);
+                scale_a<NRB>(a1, pc[8], pc[12]);
+                scale_a<NRB>(a2, pc[16], pc[20]);
+                scale_a<NRB>(a3, pc[24], pc[28]);
+                if (Q) {
+                    aq0 = aq0 * p_l[32 * ch + jq];
+                    aq1 = aq1 * p_l[32 * ch + 16 + jq];
+                }
+            }
+            BFrag be, bo;
+            load_b(be, cur, boff[0]);
+            slab_pair<NRB>(acc, a0, be, bo, cur, cur + KXS2, boff);
+            load_a<NRB>(a0, rsrc, nslab2, 4 * chn, lane);
+            slab_pair<NRB>(acc, a1, be, bo, cur + KXS2, cur + 2 * KXS2, boff);
+            load_a<NRB>(a1, rsrc, nslab2, 4 * chn + 1, lane);
+            if (Q) {
+                quarter(accq, aq0, cur, 0, qoff);
+                aq0 = btq[(2 * chn) * 64 + lane];
+            }
+            slab_pair<NRB>(acc, a2, be, bo, cur + 2 * KXS2, cur + 3 * KXS2, boff);
+            load_a<NRB>(a2, rsrc, nslab2, 4 * chn + 2, lane);
+            slab_pair<NRB>(acc, a3, be, bo, cur + 3 * KXS2, cur + 3 * KXS2, boff);
+            load_a<NRB>(a3, rsrc, nslab2, 4 * chn + 3, lane);
+            if (Q) {
+                quarter(accq, aq1, cur, 1, qoff);
+                aq1 = btq[(2 * chn + 1) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        retire<NRB>(acc);
+        if (Q) retire_q(accq);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            double* dst = means_out + (tbase + SUB * h2 - lo);
+#pragma unroll
+            for (int r = 0; r < NRB; ++r) {
+                wave_sync();
+                if (h2 == 0) {
+                    if (r == 0) stage_row_block<NRB, 0, 0>(acc, stage_l, lane);
+                    if (r == 1) stage_row_block<NRB, (NRB > 1 ? 1 : 0), 0>(acc, stage_l, lane);
+                    if (r == 2) stage_row_block<NRB, (NRB > 2 ? 2 : 0), 0>(acc, stage_l, lane);
+                } else {
+                    if (r == 0) stage_row_block<NRB, 0, 1>(acc, stage_l, lane);
+                    if (r == 1) stage_row_block<NRB, (NRB > 1 ? 1 : 0), 1>(acc, stage_l, lane);
+                    if (r == 2) stage_row_block<NRB, (NRB > 2 ? 2 : 0), 1>(acc, stage_l, lane);
+                }
+                wave_sync();
+                if (live) write_rows(stage_l, SROW, 16 * r, 16, rows, dst, means_stride, lane);
+            }
+            if (Q) {
+                wave_sync();
+                if (h2 == 0) stage_slot<0, 0>(accq, stage_l, lane); else stage_slot<0, 1>(accq, stage_l, lane);
+                wave_sync();
+                if (live) write_rows(stage_l, PROW, 16 * NRB, 4, rows, dst, means_stride, lane);
+            }
+        }
+        wave_sync();
+    }
+}
+
 // The key the cells of a tile are grouped by, and the action value the packed A operand is built
 // from: the policy value rounded to a multiple of 2^-40 (-0 -> +0).  A table policy read at its own
 // vertices through the interpolant (SL_POLICY_TRI, what the reference does) returns the vertex
@@ -1172,6 +1412,15 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
     const int64_t round_cells = split ? ((hi - lo) < (4ll << 20) ? (hi - lo) : (4ll << 20)) : 0;
     const int64_t means_off = cursor;
     cursor += (int64_t)rows * round_cells;
+    // k_bellman4s (B operand shared by the workgroup) for the GEMM half of the split sweep
+    const char* shenv = getenv("SL_BELLMAN4_SHARED");
+    const size_t lds_s = sizeof(double) * (size_t)(2 * KXBUF + W * 32 * SROW + W * n_pad);
+    const bool shared = split && !(shenv && shenv[0] == '0') && lds_s + 2048 <= 160 * 1024;
+    pk.tfrag = -1;
+    if (shared) {
+        pk.tfrag = cursor;
+        cursor += (n_last / C) * (int64_t)(n_pad / 32) * KXBUF;
+    }
     const size_t need = sizeof(double) * (size_t)cursor;
     if (need > ctx->scratch_bytes) {
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -1181,6 +1430,10 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
         ctx->scratch_bytes = need;
     }
     double* pack = reinterpret_cast<double*>(ctx->d_scratch);
+    if (shared)
+        SL_HIP_CHECK(ctx, hipMemsetAsync(pack + pk.tfrag, 0,
+                                         sizeof(double) * (size_t)((n_last / C) * (int64_t)(n_pad / 32) * KXBUF),
+                                         ctx->stream));
     hipLaunchKernelGGL(k_bellman4_pack, dim3(512), dim3(256), 0, ctx->stream, ctx->h_model, ctx->h_gp,
                        pk, n_actions, ctx->d_actions, pack);
     SL_HIP_CHECK(ctx, hipGetLastError());
@@ -1209,14 +1462,39 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
         else if (pk.nrb == 2) SL_B4_LAUNCH(D_, 2, false);                 \
         else SL_B4_LAUNCH(D_, 3, false);                                  \
     } while (0)
+#define SL_B4S_LAUNCH(D_, N_, Q_)                                                                 \
+    do {                                                                                          \
+        auto kern = k_bellman4s<D_, N_, Q_>;                                                      \
+        SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                              (int)lds_s));                                       \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds_s, ctx->stream, ctx->h_model,    \
+                           ctx->h_gp, pk, pk.tfrag, rlo, rhi, n_actions, pack, means,             \
+                           round_cells);                                                          \
+    } while (0)
+#define SL_B4S_ROWS(D_)                                                   \
+    do {                                                                  \
+        if (pk.nrb == 1 && pk.quarter) SL_B4S_LAUNCH(D_, 1, true);        \
+        else if (pk.nrb == 1) SL_B4S_LAUNCH(D_, 1, false);                \
+        else if (pk.nrb == 2 && pk.quarter) SL_B4S_LAUNCH(D_, 2, true);   \
+        else if (pk.nrb == 2) SL_B4S_LAUNCH(D_, 2, false);                \
+        else SL_B4S_LAUNCH(D_, 3, false);                                 \
+    } while (0)
     double* means = split ? pack + means_off : nullptr;
     const int64_t step_cells = split ? round_cells : (hi - lo);
     for (int64_t rlo = lo; rlo < hi; rlo += step_cells) {
         const int64_t rhi = rlo + step_cells < hi ? rlo + step_cells : hi;
         const int64_t wtiles = (rhi - rlo) / C;
         const int64_t wg = (wtiles + W - 1) / W;
-        const int blocks = (int)(wg < ctx->num_cu ? wg : ctx->num_cu);
-        if (variant == 4) SL_B4_ROWS(4); else SL_B4_ROWS(2);
+        int blocks = (int)(wg < ctx->num_cu ? wg : ctx->num_cu);
+        if (shared) {
+            const int64_t nrows = (rhi + n_last - 1) / n_last - rlo / n_last;
+            const int64_t nsteps = ((nrows + W - 1) / W) * (n_last / C);
+            blocks = (int)(nsteps < ctx->num_cu ? nsteps : ctx->num_cu);
+            if (variant == 4) SL_B4S_ROWS(4); else SL_B4S_ROWS(2);
+        } else {
+            if (variant == 4) SL_B4_ROWS(4); else SL_B4_ROWS(2);
+        }
         SL_HIP_CHECK(ctx, hipGetLastError());
         if (split) {
             const int64_t nblk = (rhi - rlo + 255) / 256;
@@ -1234,9 +1512,12 @@ int sl_bellman4_launch(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doubl
     }
 #undef SL_B4_ROWS
 #undef SL_B4_LAUNCH
+#undef SL_B4S_ROWS
+#undef SL_B4S_LAUNCH
     SL_HIP_CHECK(ctx, hipGetLastError());
-    sl_note_kernel(ctx, false, split ? "k_bellman4<d=%d, row blocks=%d, quarter=%d> + k_bellman_lookup<%d>"
-                                     : "k_bellman4<d=%d, row blocks=%d, quarter=%d> (fused lookup)",
+    sl_note_kernel(ctx, false, shared ? "k_bellman4s<d=%d, row blocks=%d, quarter=%d> + k_bellman_lookup<%d>"
+                       : split ? "k_bellman4<d=%d, row blocks=%d, quarter=%d> + k_bellman_lookup<%d>"
+                               : "k_bellman4<d=%d, row blocks=%d, quarter=%d> (fused lookup)",
                    variant == 4 ? 4 : 2, pk.nrb, (int)pk.quarter, variant == 4 ? 4 : 2);
     *done = 1;
     return SL_OK;

@@ -313,14 +313,16 @@ def test_bellman_sweep_4x4x4_kernel(sl, name, kw, nv, na, monkeypatch):
     case = cases.make_case(name, num_points=nv, **kw)
     actions = np.linspace(-1, 1, na)[:, None]
     results = {}
-    # "1": GEMM kernel + k_bellman_lookup (shipped); "fused": the same GEMM with its own epilogue;
-    # "0": the 16x16x4 kernel
-    for flag in ("1", "fused", "0"):
+    # "1": k_bellman4s (B operand shared by the workgroup) + k_bellman_lookup (shipped); "split":
+    # k_bellman4 + k_bellman_lookup; "fused": k_bellman4 with its own epilogue; "0": the 16x16x4 kernel
+    for flag in ("1", "split", "fused", "0"):
         monkeypatch.setenv("SL_BELLMAN4", "0" if flag == "0" else "1")
         monkeypatch.setenv("SL_BELLMAN4_SPLIT", "0" if flag == "fused" else "1")
+        monkeypatch.setenv("SL_BELLMAN4_SHARED", "1" if flag == "1" else "0")
         rl, orl, vf, ovf = _rl_pair(sl, case, nv)
         q = rl.discrete_policy_optimization(actions, return_values=True)
-        results[flag] = (q.cpu().numpy(), rl.policy.parameters[:, 0].copy())
+        results[flag] = (q.cpu().numpy(), rl.policy.parameters[:, 0].copy(), rl._ctx.last_kernel())
+    assert "k_bellman4s" in results["1"][2] and "k_bellman4<" in results["split"][2]
     orl.policy = oracle.Triangulation(ovf.discretization, np.zeros((ovf.discretization.nindex, 1)))
     oq, obest = orl.discrete_policy_optimization(actions)
     x = orl.state_space
@@ -329,12 +331,14 @@ def test_bellman_sweep_4x4x4_kernel(sl, name, kw, nv, na, monkeypatch):
         nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))
         ok &= ~ambiguous_points(ovf, nxt[0] if isinstance(nxt, tuple) else nxt)
     assert ok.mean() > 0.3
-    q4, best4 = results["1"]
-    q16, best16 = results["0"]
+    q4, best4 = results["1"][:2]
+    q16, best16 = results["0"][:2]
     assert_allclose(q4[ok], oq[ok], rtol=1e-9, atol=1e-12)
     assert_allclose(q4, q16, rtol=1e-11, atol=1e-13)
-    assert_array_equal(results["fused"][0], q4)          # same GEMM, same per-pair arithmetic
-    assert_array_equal(results["fused"][1], best4)
+    # the shared-B kernel multiplies (Bt P_j) T_last instead of Bt (P_j T_last): last-bit differences
+    assert_allclose(results["split"][0], q4, rtol=1e-12, atol=1e-14)
+    assert_array_equal(results["fused"][0], results["split"][0])    # same GEMM, same per-pair arithmetic
+    assert_array_equal(results["fused"][1], results["split"][1])
     top2 = np.sort(oq, axis=1)[:, -2:]
     tie = np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1])
     assert not np.any((best4 != actions[obest, 0]) & ok & ~tie)

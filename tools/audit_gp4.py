@@ -97,7 +97,7 @@ def audit(path, prefix="_Z11k_gp_sweep4", min_loops=8, owned=256):
     return report, problems
 
 
-def audit_in_place(path, prefix=r"_Z1[07]k_bellman4(?:_policy)?I"):
+def audit_in_place(path, prefix=r"_Z1[017]k_bellman4(?:s|_policy)?I"):
     """k_bellman4 keeps its accumulators as ordinary register values that inline-asm MFMAs update
     in place.  The compiler sees those asm statements as opaque: a register copy or a spill of an
     accumulator inside the MFMA loop would read a result the hardware has not retired yet (no
