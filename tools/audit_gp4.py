@@ -155,9 +155,40 @@ def audit_in_place(path, prefix=r"_Z1[017]k_bellman4(?:s|_policy)?I"):
                 if regs & accs:
                     touching.append(code.strip())
             spills = [l.strip() for l in best if "scratch_" in l]
+            # The MFMAs are inline asm: the compiler's hazard recogniser does not see them.  A
+            # vector ALU instruction that writes an A / B source register must not sit in the two
+            # issue slots in front of the MFMA that reads it.
+            def regs_of(text):
+                out = set()
+                for mm in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+                    if mm.group(3) is not None:
+                        out.add(int(mm.group(3)))
+                    else:
+                        out.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+                return out
+            code_lines = [l.split(";")[0].strip() for l in best]
+            code_lines = [c for c in code_lines if c and not c.startswith(".") and not c.endswith(":")]
+            close = []
+            for i, c in enumerate(code_lines):
+                if not c.startswith("v_mfma"):
+                    continue
+                ops = c.split(None, 1)[1].split(", ")
+                sources = regs_of(ops[1]) | regs_of(ops[2])
+                for back in (1, 2):
+                    if i - back < 0:
+                        continue
+                    prev = code_lines[i - back]
+                    if prev.startswith("v_") and not prev.startswith("v_mfma"):
+                        dest = regs_of(prev.split(None, 1)[1].split(", ")[0]) if " " in prev else set()
+                        if dest & sources:
+                            close.append("%s -> %s" % (prev, c))
             report.append("%s: %d MFMAs on %d accumulator registers in the chunk loop, %d out of "
-                          "place, %d other instructions touch an accumulator, %d scratch accesses"
-                          % (name, len(mfmas), len(accs), len(moved), len(touching), len(spills)))
+                          "place, %d other instructions touch an accumulator, %d scratch accesses, "
+                          "%d sources written within two slots of their MFMA"
+                          % (name, len(mfmas), len(accs), len(moved), len(touching), len(spills),
+                             len(close)))
+            if close:
+                problems.append("%s: MFMA source written right in front of it: %s" % (name, close[:2]))
             if moved:
                 problems.append("%s: out-of-place MFMAs: %s" % (name, moved[:2]))
             if touching:
