@@ -136,6 +136,18 @@ def _worker(rank, world, port, results, backend="gloo"):
         ok &= ~test_gpu_rl.ambiguous_points(ovf, nxt[0] if isinstance(nxt, tuple) else nxt)
     if q.shape != oq.shape or not np.allclose(q[ok], oq[ok], rtol=1e-9, atol=1e-12):
         failures.append(("rl", "4x4x4 action values"))
+    # ... and the policy-evaluation sweep with the greedy table (k_bellman4_policy: six live rows
+    # per rank in a workgroup step of eight)
+    rl.policy.parameters = orl.policy.parameters.copy()
+    vf.parameters = ovf.parameters.copy()
+    nxt = orl.dynamics(x, orl.policy(x))
+    ok = ~test_gpu_rl.ambiguous_points(orl.policy, x) & ~test_gpu_rl.ambiguous_points(ovf, nxt[0])
+    rl.value_iteration()
+    orl.value_iteration()
+    if "k_bellman4_policy" not in rl._ctx.last_kernel():
+        failures.append(("rl", "policy kernel", rl._ctx.last_kernel()))
+    if not np.allclose(vf._host_parameters()[ok], ovf.parameters[ok], rtol=1e-9, atol=1e-12):
+        failures.append(("rl", "4x4x4 policy evaluation"))
     results[rank] = failures
     dist.barrier()
     dist.destroy_process_group()
