@@ -457,3 +457,35 @@ def test_policy_evaluation_smooth_policy_keeps_the_16x16x4_kernel(sl):
     ok = ~ambiguous_points(orl.policy, x) & ~ambiguous_points(ovf, orl.dynamics(x, orl.policy(x))[0])
     orl.value_iteration()
     assert_allclose(vf._host_parameters()[ok], ovf.parameters[ok], rtol=1e-9, atol=1e-12)
+
+
+def test_4x4x4_kernels_on_sub_ranges(sl):
+    """k_bellman4s and k_bellman4_policy group eight grid rows per workgroup step; an index range
+    that starts and ends in the middle of a row (what a rank's shard looks like) must give the
+    values of the full-range sweep on its slice, bit for bit."""
+    import torch
+    case = cases.make_case("pendulum", num_points=[7, 128], n_gp=70)
+    rl, orl, vf, ovf = _rl_pair(sl, case, [7, 128])
+    n = vf.discretization.nindex
+    actions = np.linspace(-1, 1, 9)[:, None]
+    table = actions[np.random.default_rng(3).integers(0, 5, n)]
+    policy = np.ascontiguousarray(table)
+
+    def sweeps():
+        v_max, argmax, q, _ = rl._sweep(rl.policy, actions, want_q=True)
+        max_kernel = rl._ctx.last_kernel()
+        v_pol, _, _, _ = rl._sweep(policy, None)
+        count = rl._hi - rl._lo
+        return (v_max[:count].cpu().numpy(), argmax[:count].cpu().numpy(),
+                q[:count].cpu().numpy(), v_pol[:count].cpu().numpy(), max_kernel,
+                rl._ctx.last_kernel())
+
+    full = sweeps()
+    assert "k_bellman4s" in full[4] and "k_bellman4_policy" in full[5], full[4:]
+    for lo, hi in ((64, n - 192), (128 + 64, 128 * 3), (0, 64)):
+        rl._lo, rl._hi = lo, hi
+        part = sweeps()
+        assert "k_bellman4s" in part[4] and "k_bellman4_policy" in part[5], part[4:]
+        for got, want in zip(part[:4], full[:4]):
+            assert_array_equal(got, want[lo:hi])
+    torch.cuda.synchronize()
