@@ -174,14 +174,18 @@ def audit_in_place(path, prefix=r"_Z1[017]k_bellman4(?:s|_policy)?I"):
                     continue
                 ops = c.split(None, 1)[1].split(", ")
                 sources = regs_of(ops[1]) | regs_of(ops[2])
-                for back in (1, 2):
-                    if i - back < 0:
-                        continue
+                slots = 0                        # issue slots between the producer and the MFMA
+                for back in range(1, 4):
+                    if i - back < 0 or slots >= 2:
+                        break
                     prev = code_lines[i - back]
-                    if prev.startswith("v_") and not prev.startswith("v_mfma"):
-                        dest = regs_of(prev.split(None, 1)[1].split(", ")[0]) if " " in prev else set()
-                        if dest & sources:
+                    if prev.startswith("s_nop"):
+                        slots += int(prev.split()[1]) + 1
+                        continue
+                    if prev.startswith("v_") and not prev.startswith("v_mfma") and " " in prev:
+                        if regs_of(prev.split(None, 1)[1].split(", ")[0]) & sources:
                             close.append("%s -> %s" % (prev, c))
+                    slots += 1
             report.append("%s: %d MFMAs on %d accumulator registers in the chunk loop, %d out of "
                           "place, %d other instructions touch an accumulator, %d scratch accesses, "
                           "%d sources written within two slots of their MFMA"
