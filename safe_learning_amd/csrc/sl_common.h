@@ -56,6 +56,17 @@ struct sl_ctx {
     void* d_comm_records = nullptr;    // [world] gathered sl_sweep_result records
     int comm_rank = 0, comm_world = 1;
     char last_kernel[160] = "";        // dominant kernel(s) of the last sweep call (sl_last_kernel)
+    // k_bellman4_policy: what is derived from the policy alone (its action at every cell, the
+    // distinct values, the tile order) is kept between sweeps as long as the policy is the same
+    void* d_policy_cache = nullptr;
+    size_t policy_cache_bytes = 0;
+    struct {
+        bool valid = false;
+        int64_t lo = 0, hi = 0;
+        unsigned long long table_sum = 0, desc_hash = 0;
+        int n_glob = 0;
+        unsigned long long bits[64];
+    } policy_cache;
 };
 
 extern thread_local std::string g_sl_last_error;

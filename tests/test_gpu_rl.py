@@ -489,3 +489,37 @@ def test_4x4x4_kernels_on_sub_ranges(sl):
         for got, want in zip(part[:4], full[:4]):
             assert_array_equal(got, want[lo:hi])
     torch.cuda.synchronize()
+
+
+def test_policy_data_are_reused_until_the_policy_changes(sl):
+    """k_bellman4_policy keeps what depends on the policy alone (actions, distinct values, tile
+    order) between sweeps, keyed by a checksum of the policy table: a second sweep reuses them, an
+    in-place edit of one table entry is noticed, results equal the uncached ones bit for bit."""
+    case = cases.make_case("pendulum", num_points=[12, 64], n_gp=70)
+    rl, orl, vf, ovf = _rl_pair(sl, case, [12, 64])
+    grid = vf.discretization
+    actions = np.linspace(-1, 1, 5)[:, None]
+    table = actions[np.random.default_rng(9).integers(0, 5, grid.nindex)]
+    rl.policy = sl.Triangulation(grid, table)
+    v0 = ovf.parameters.copy()
+
+    def sweep():
+        vf.parameters = v0.copy()
+        rl.value_iteration()
+        return vf._host_parameters().copy(), rl._ctx.last_kernel()
+
+    first, k1 = sweep()
+    second, k2 = sweep()
+    assert "k_bellman4_policy" in k1 and "reused" not in k1
+    assert "reused" in k2
+    assert_array_equal(first, second)
+    edited = table.copy()
+    edited[grid.nindex // 2 + 7] = actions[(np.argmax(actions == edited[grid.nindex // 2 + 7]) + 1) % 5]
+    rl.policy.parameters = edited
+    third, k3 = sweep()
+    assert "reused" not in k3
+    assert not np.array_equal(third, first)
+    rl.policy.parameters = table
+    fourth, k4 = sweep()
+    assert "reused" not in k4                     # the key is the last policy's, not a history
+    assert_array_equal(fourth, first)
