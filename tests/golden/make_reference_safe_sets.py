@@ -87,6 +87,19 @@ def reference_specs(case, ref, oracle_dynamics):
     vspec = case.get("V", {"kind": "quadratic"})
     if vspec["kind"] == "quadratic":
         value = F.QuadraticFunction(case["P"])
+    elif vspec["kind"] == "network":
+        # examples/utilities.py:48-104; tf.get_variable hands out the case's weights by name
+        names, in_dim = [], d
+        for i, out_dim in enumerate(vspec["layer_dims"]):
+            names.append("weights_posdef_%d" % i)
+            if out_dim > in_dim:
+                names.append("weights_%d" % i)
+            in_dim = out_dim
+        numpy_tf.set_named_variables(dict(zip(names, vspec["weights"])))
+        activations = {"tanh": tf.tanh, "relu": lambda x, name=None: tf.maximum(x, 0.0)}
+        value = ref.examples.LyapunovNetwork(d, vspec["layer_dims"],
+                                             [activations[a] for a in vspec["activations"]],
+                                             eps=vspec["eps"])
     else:
         value = F.Triangulation(F.GridWorld(case["limits"],
                                             vspec.get("num_points", case["num_points"])),
@@ -188,6 +201,17 @@ def scenarios():
                           tau_scale=tau_scale, limits=[[-1, 1.03], [-0.97, 1]])
         out.append(dict(name="table_gp%d" % n_gp, case=case, batch=128, unique=True,
                         steps=[("update", {}), ("update", {"can_shrink": False})]))
+
+    # V a LyapunovNetwork (config C3's family): the reference's class multiplies left to right here,
+    # the oracle with BLAS - values agree to 1e-13, the safe set must be the same
+    from tests import cases as _cases
+    case = skew(make_case("pendulum", num_points=27, dynamics="analytic", tau_scale=0.0),
+                [[-1, 1.03], [-0.97, 1]])
+    dims = [8, 8, 16]
+    case["V"] = {"kind": "network", "layer_dims": dims, "activations": ["tanh"] * 3, "eps": 1e-8,
+                 "weights": _cases.lyapunov_like_network_weights(case["P"], dims)}
+    out.append(dict(name="pendulum_network", case=case, batch=100, unique=True, values_rtol=1e-12,
+                    steps=[("update", {}), ("update", {"can_shrink": False})]))
 
     # adaptive discretisation (lyapunov.py:443-488, 540-582)
     for tau_scale in (0.1, 0.03, 0.003):
