@@ -43,7 +43,9 @@ class PolicyIteration(object):
     def bellmann_error(self, states):
         """Reference: ``reinforcement_learning.py:116-133``."""
         target = self.future_values(states)
-        return np.sum(np.square(target - self.value_function(states)))
+        squares = np.square(target - self.value_function(states)).ravel()
+        # left-to-right, like every sum of the oracle (np.sum adds pairwise from 8 terms on)
+        return np.cumsum(squares)[-1] if len(squares) else 0.0
 
     def value_iteration(self):
         """One Jacobi sweep: every read sees the old table.  Reference: ``:135-140``."""

@@ -134,8 +134,8 @@ def replay(scenario, rl, value_table, policy_table, all_states, lyapunov, run, e
                 run(rl.value_iteration())
                 records.append(value_table().copy())
         elif kind == "dpo":
-            rl.discrete_policy_optimization(step[1],
-                                            constraint=constraint_function(step[2], all_states))
+            rl.discrete_policy_optimization(
+                step[1], constraint=constraint_function(step[2], rl.policy.discretization.all_points))
             records.append(policy_table().copy())
         elif kind == "fv":
             arg = dict(step[1])
@@ -203,5 +203,97 @@ def main():
     print("wrote %s (%d arrays, %.1f KiB)" % (OUT, len(arrays), os.path.getsize(OUT) / 1024.0))
 
 
+def reference_run(scenario, ref):
+    """The scenario on the reference's PolicyIteration -> recorded arrays."""
+    F, module = ref.functions, ref.reinforcement_learning
+    case = scenario["case"]
+    oracle_dynamics = build_oracle_leaves(scenario)[1]
+    _, dynamics, lyap_value, lv = reference_specs(case, ref, oracle_dynamics)
+    value = F.Triangulation(F.GridWorld(scenario["limits"], scenario["value_points"]),
+                            scenario["value_table"], project=True)
+    policy = F.Triangulation(F.GridWorld(scenario["limits"], scenario["policy_points"]),
+                             scenario["policy_table"])
+    rl = module.PolicyIteration(policy, dynamics, F.QuadraticFunction(scenario["reward"]), value,
+                                gamma=scenario["gamma"])
+    lyap = None
+    if scenario["lyapunov"]:
+        grid = F.GridWorld(scenario["limits"], scenario["value_points"])
+        lyap = ref.lyapunov.Lyapunov(grid, lyap_value, dynamics, case["lf"], lv, case["tau"], policy)
+    return replay(scenario, rl, lambda: value.parameters[0].value,
+                  lambda: policy.parameters[0].value, value.discretization.all_points, lyap,
+                  run=lambda op: op.eval(rl.feed_dict),
+                  evaluate_fv=lambda node: node.eval(rl.feed_dict))
+
+
+def oracle_run(scenario):
+    import oracle
+    case = scenario["case"]
+    policy, dynamics, reward, value, (lyap_value, lv) = build_oracle_leaves(scenario)
+    rl = oracle.PolicyIteration(policy, dynamics, reward, value, gamma=scenario["gamma"])
+    lyap = None
+    if scenario["lyapunov"]:
+        grid = oracle.GridWorld(scenario["limits"], scenario["value_points"])
+        lyap = oracle.Lyapunov(grid, lyap_value, dynamics, case["lf"], lv, case["tau"], policy)
+    return replay(scenario, rl, lambda: value.parameters, lambda: policy.parameters,
+                  value.discretization.all_points, lyap, run=lambda op: None,
+                  evaluate_fv=lambda result: result)
+
+
+def random_scenarios(count, seed):
+    """Seeded random variations for the LIVE comparison (tests/test_oracle_live_reference.py)."""
+    from safe_learning_amd.benchmarks import GP_VARIANTS, make_case
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(count):
+        kind = ["linear", "analytic", "gp"][int(rng.integers(0, 3))]
+        family = "pendulum" if rng.random() < 0.75 else "cartpole"
+        d = 2 if family == "pendulum" else 4
+        value_points = [int(v) for v in (rng.integers(6, 16, 2) if d == 2 else rng.integers(3, 6, 4))]
+        policy_points = value_points if rng.random() < 0.6 else \
+            [int(v) for v in (rng.integers(4, 10, 2) if d == 2 else rng.integers(3, 5, 4))]
+        kw = dict(num_points=value_points)
+        if kind == "gp":
+            kw.update(n_gp=int(rng.integers(20, 60)), **GP_VARIANTS["tight"])
+            if rng.random() < 0.4:
+                kw["stack"] = True
+        else:
+            kw["dynamics"] = kind
+        case = make_case(family, **kw)
+        nv, npol = int(np.prod(value_points)), int(np.prod(policy_points))
+        actions = np.sort(rng.uniform(-1, 1, int(rng.integers(2, 10))))[:, None]
+        steps = [("vi", int(rng.integers(1, 4))),
+                 ("dpo", actions, [None, "outwards"][int(rng.integers(0, 2))] if d == 2 else None),
+                 ("vi", int(rng.integers(1, 4)))]
+        if rng.random() < 0.5:
+            steps.append(("fv", dict(states=rng.uniform(-0.9, 0.9, (30, d)))))
+        if kind == "gp" and rng.random() < 0.5:
+            steps.append(("fv", dict(lyapunov=True, lagrange_multiplier=float(rng.uniform(0.2, 3.0)))))
+        steps.append(("bellman", rng.uniform(-0.9, 0.9, (25, d))))
+        qmat = -scipy.linalg.block_diag(np.diag(rng.uniform(0.5, 2.0, d)), rng.uniform(0.05, 0.5) * np.eye(1))
+        out.append(dict(name="random_%d_%s_%s" % (k, family, kind), case=case,
+                        gamma=float(rng.uniform(0.8, 0.99)), reward=qmat, limits=case["limits"],
+                        value_points=value_points, policy_points=policy_points,
+                        value_table=-rng.random((nv, 1)), policy_table=rng.uniform(-1, 1, (npol, 1)),
+                        lyapunov=kind == "gp", steps=steps))
+    return out
+
+
+def check_live(count, seed):
+    """Reference and oracle side by side on random scenarios, in this process (no fixture)."""
+    ref = numpy_tf.load_reference(examples=True)
+    for scenario in random_scenarios(count, seed):
+        want = reference_run(scenario, ref)
+        got = oracle_run(scenario)
+        assert len(got) == len(want)
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), "%s record %d" % (scenario["name"], k)
+        print("%-34s value grid %-16s policy grid %-16s records %d"
+              % (scenario["name"], scenario["value_points"], scenario["policy_points"], len(want)))
+    print("LIVE OK: %d scenarios compared" % count)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--check-live":
+        check_live(int(sys.argv[2]), int(sys.argv[3]))
+    else:
+        main()

@@ -319,5 +319,90 @@ def main():
     print("wrote %s (%d arrays, %.1f KiB)" % (OUT, len(arrays), os.path.getsize(OUT) / 1024.0))
 
 
+def random_scenarios(count, seed):
+    """Seeded random variations for the LIVE comparison (tests/test_oracle_live_reference.py):
+    grid sizes and limits, tau, batch size, dynamics kind, adaptive or not, call sequences."""
+    from safe_learning_amd.benchmarks import GP_VARIANTS, make_case
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(count):
+        kind = ["linear", "analytic", "gp"][int(rng.integers(0, 3))]
+        family = "pendulum" if rng.random() < 0.75 else "cartpole"
+        if family == "pendulum":
+            num_points = [int(v) for v in rng.integers(9, 33, 2)]
+        else:
+            num_points = [int(v) for v in rng.integers(4, 8, 4)]
+        kw = dict(num_points=num_points, tau_scale=float(10.0 ** rng.uniform(-4.5, -1.5)))
+        if kind == "gp":
+            kw.update(n_gp=int(rng.integers(20, 60)), **GP_VARIANTS["tight"])
+            if rng.random() < 0.4:
+                kw["stack"] = True
+        else:
+            kw["dynamics"] = kind
+        case = make_case(family, **kw)
+        d = case["d"]
+        lows = -1.0 + rng.uniform(-0.05, 0.05, d)
+        highs = 1.0 + rng.uniform(0.01, 0.09, d)
+        case["limits"] = [[float(a), float(b)] for a, b in zip(lows, highs)]
+        case["initial_radius"] = float(rng.uniform(0.1, 0.35))
+        adaptive = kind != "gp" and rng.random() < 0.35
+        update = {}
+        if adaptive:
+            update = dict(max_refinement=int(rng.integers(2, 7)),
+                          safety_factor=float(rng.uniform(1.0, 1.6)))
+        n = int(np.prod(num_points))
+        steps = [("update", dict(update))]
+        if rng.random() < 0.5:
+            steps.append(("mark_safe", rng.choice(n, max(n // 20, 1), replace=False)))
+        steps.append(("update", dict(update, can_shrink=False)))
+        steps.append(("update", dict(update)))
+        out.append(dict(name="random_%d_%s_%s" % (k, family, kind), case=case, adaptive=adaptive,
+                        batch=int(rng.integers(7, 400)), steps=steps))
+    return out
+
+
+def check_live(count, seed):
+    """Reference and oracle side by side on random scenarios, in this process (no fixture)."""
+    import oracle
+    from oracle import np_lyapunov
+    from tests import cases
+    ref = numpy_tf.load_reference(examples=True)
+    compared = 0
+    for scenario in random_scenarios(count, seed):
+        name, case = scenario["name"], scenario["case"]
+        initial = cases.initial_safe_mask(case)
+        # the reference's run
+        _, oracle_dynamics, _, _ = cases.oracle_specs(case)
+        policy, dynamics, value, lv = reference_specs(case, ref, oracle_dynamics)
+        ref.config.gp_batch_size = scenario["batch"]
+        grid = ref.functions.GridWorld(case["limits"], case["num_points"])
+        lyap = ref.lyapunov.Lyapunov(grid, value, dynamics, case["lf"], lv, case["tau"], policy,
+                                     initial_set=initial, adaptive=scenario["adaptive"])
+        if len(np.unique(lyap.values)) != len(lyap.values):
+            print("%s: equal values on the grid, skipped (tie order is unpinned)" % name)
+            continue
+        want = replay(scenario, lyap, oracle_dynamics, ref.lyapunov.get_safe_sample,
+                      lambda obj: obj.feed_dict[obj.c_max])
+        # the oracle's
+        np_lyapunov.config.gp_batch_size = scenario["batch"]
+        opolicy, odynamics, ovalue, olv = cases.oracle_specs(case)
+        olyap = oracle.Lyapunov(oracle.GridWorld(case["limits"], case["num_points"]), ovalue,
+                                odynamics, case["lf"], olv, case["tau"], opolicy, initial_set=initial)
+        olyap.adaptive = scenario["adaptive"]
+        got = replay(scenario, olyap, odynamics, oracle.get_safe_sample, lambda obj: obj.c_max)
+        assert np.array_equal(olyap.values, lyap.values), name
+        for k, (a, b) in enumerate(zip(got, want)):
+            for key in b:
+                assert np.array_equal(a[key], b[key]), "%s step %d %s" % (name, k, key)
+        compared += 1
+        print("%-34s cells %5d batch %3d safe %s%s" % (
+            name, grid.nindex, scenario["batch"], [int(r["safe_set"].sum()) for r in want],
+            "  adaptive" if scenario["adaptive"] else ""))
+    print("LIVE OK: %d scenarios compared" % compared)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--check-live":
+        check_live(int(sys.argv[2]), int(sys.argv[3]))
+    else:
+        main()
