@@ -5,7 +5,7 @@ Restates ``safe_learning/lyapunov.py:142-606`` (class ``Lyapunov``) and ``:22-56
 callables; the batch loop, the prefix rule, the early exit and the ``c_max`` index
 arithmetic of ``update_safe_set`` are kept as they are in the reference, quirks included -
 and checked against the reference's own ``update_safe_set`` / ``get_safe_sample`` run in the build
-container (``tests/golden/make_reference_safe_sets.py``, 19 scenarios incl. the adaptive branch).
+container (``tests/golden/make_reference_safe_sets.py``, 35 scenarios incl. the adaptive branch).
 
 Tie order: the reference sorts with NumPy's default (unstable) argsort
 (``lyapunov.py:512``); the oracle defines the canonical order as ascending

@@ -106,6 +106,9 @@ def scenarios():
     case = make_case("cartpole", num_points=[3, 4, 3, 5], dynamics="analytic")
     entry("cartpole_analytic", case, [3, 4, 3, 5], [3, 4, 3, 5],
           [("vi", 2), ("dpo", np.linspace(-1, 1, 6)[:, None], None), ("vi", 2)], gamma=0.95)
+    # ten of the random variations of the live comparison (seed 7), so that the engine meets them
+    # too (tests/test_gpu_reference_policy_iteration.py)
+    out.extend(random_scenarios(10, 7))
     return out
 
 

@@ -227,6 +227,11 @@ def scenarios():
                 [[-1, 1.03], [-0.97, 1]])
     out.append(dict(name="adaptive_gp", case=case, batch=80, unique=True, adaptive=True,
                     steps=[("update", dict(max_refinement=4, safety_factor=1.2))]))
+    # sixteen of the random variations of the live comparison (seed 7), so that the engine meets
+    # them too (tests/test_gpu_reference_safe_sets.py)
+    for scenario in random_scenarios(16, 7):
+        scenario["unique"] = True
+        out.append(scenario)
     return out
 
 
