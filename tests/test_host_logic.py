@@ -1,6 +1,7 @@
 """Host-side logic of the product that needs no GPU: spec helpers, sharding arithmetic."""
 
 import numpy as np
+import pytest
 from numpy.testing import assert_allclose
 
 import oracle
@@ -47,3 +48,26 @@ def test_upload_cache_tokens_are_unique():
         assert tri._table_version not in seen
         seen.add(tri._table_version)
         del tri
+
+
+@pytest.mark.parametrize("name", ["1d", "2d", "2d_test", "3d", "4d_64", "4d_aniso"])
+def test_product_gridworld_equals_the_reference_run(name):
+    """``safe_learning_amd.GridWorld`` (host metadata and index <-> state maps of the product)
+    against the arrays the reference's own ``GridWorld`` produced (``functions.py:579-817``,
+    tests/golden/make_reference_fixtures.py): bit for bit."""
+    import os
+    from numpy.testing import assert_array_equal
+    import safe_learning_amd as sl
+    from conftest import GOLDEN_DIR
+    fix = np.load(os.path.join(GOLDEN_DIR, "reference_grid_triangulation.npz"))
+    grid = sl.GridWorld(fix[name + "/limits"], fix[name + "/num_points"])
+    points, indices, rects = fix[name + "/points"], fix[name + "/indices"], fix[name + "/rectangles"]
+    assert_array_equal(np.asarray(grid.unit_maxes), fix[name + "/unit_maxes"])
+    assert_array_equal(grid.index_to_state(indices), fix[name + "/index_to_state"])
+    assert_array_equal(np.asarray(grid.state_to_index(points)), fix[name + "/state_to_index"])
+    assert_array_equal(np.asarray(grid.state_to_rectangle(points)), fix[name + "/state_to_rectangle"])
+    assert_array_equal(grid.rectangle_to_state(rects), fix[name + "/rectangle_to_state"])
+    assert_array_equal(np.asarray(grid.rectangle_corner_index(rects)),
+                       fix[name + "/rectangle_corner_index"])
+    if name + "/all_points" in fix.files:
+        assert_array_equal(grid.all_points, fix[name + "/all_points"])
