@@ -523,3 +523,48 @@ def test_policy_data_are_reused_until_the_policy_changes(sl):
     fourth, k4 = sweep()
     assert "reused" not in k4                     # the key is the last policy's, not a history
     assert_array_equal(fourth, first)
+
+
+@pytest.mark.parametrize("name,kw,nv,na", [
+    ("pendulum", dict(n_gp=70), [9, 65], 9),          # one whole and one 1-cell tile per row
+    ("pendulum", dict(n_gp=70), [6, 101], 5),
+    ("pendulum", dict(n_gp=70), 15, 9),               # rows shorter than a tile
+    ("cartpole", dict(n_gp=90), [3, 3, 2, 70], 9),
+    ("cartpole", dict(n_gp=90), 5, 9),
+    ("pendulum", dict(n_gp=70), [5, 120], 9),         # 120 of 128 cells: taken without forcing
+])
+def test_max_sweep_ragged_rows_on_4x4x4(sl, name, kw, nv, na, monkeypatch):
+    """k_bellman4s takes grids whose last axis is NOT a multiple of 64 cells too (ragged last tile
+    of a row, writes masked cell by cell): against k_bellman_mfma (SL_BELLMAN4=0) on the same
+    inputs and against the oracle, and on index ranges that cut rows."""
+    case = cases.make_case(name, num_points=nv, **kw)
+    actions = np.linspace(-1, 1, na)[:, None]
+    results = {}
+    monkeypatch.setenv("SL_BELLMAN4_RAGGED", "1")     # also where the rows fill less than 70 %
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SL_BELLMAN4", flag)
+        rl, orl, vf, ovf = _rl_pair(sl, case, nv)
+        q = rl.discrete_policy_optimization(actions, return_values=True)
+        results[flag] = (q.cpu().numpy(), rl._ctx.last_kernel())
+    assert "k_bellman4s" in results["1"][1] and "k_bellman4" not in results["0"][1], \
+        (results["1"][1], results["0"][1])
+    assert_allclose(results["1"][0], results["0"][0], rtol=1e-11, atol=1e-13)
+    orl.policy = oracle.Triangulation(ovf.discretization, np.zeros((ovf.discretization.nindex, 1)))
+    oq, _ = orl.discrete_policy_optimization(actions)
+    x = orl.state_space
+    ok = np.ones(len(x), dtype=bool)
+    for action in actions:
+        nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))
+        ok &= ~ambiguous_points(ovf, nxt[0] if isinstance(nxt, tuple) else nxt)
+    assert ok.mean() > 0.3
+    assert_allclose(results["1"][0][ok], oq[ok], rtol=1e-9, atol=1e-12)
+    # a shard-like range (multiples of 64 cells) that cuts rows
+    monkeypatch.setenv("SL_BELLMAN4", "1")
+    rl, orl, vf, ovf = _rl_pair(sl, case, nv)
+    n = vf.discretization.nindex
+    if n >= 256:
+        lo, hi = 64, (n // 64 - 1) * 64
+        rl._lo, rl._hi = lo, hi
+        _, _, q, _ = rl._sweep(rl.policy, actions, want_q=True)
+        assert "k_bellman4s" in rl._ctx.last_kernel()
+        assert_array_equal(q[:hi - lo].cpu().numpy(), results["1"][0][lo:hi])
