@@ -568,3 +568,48 @@ def test_max_sweep_ragged_rows_on_4x4x4(sl, name, kw, nv, na, monkeypatch):
         _, _, q, _ = rl._sweep(rl.policy, actions, want_q=True)
         assert "k_bellman4s" in rl._ctx.last_kernel()
         assert_array_equal(q[:hi - lo].cpu().numpy(), results["1"][0][lo:hi])
+
+
+@pytest.mark.parametrize("name,kw,nv,na", [
+    ("pendulum", dict(n_gp=70), [9, 65], 5),
+    ("pendulum", dict(n_gp=70), [6, 101], 9),
+    ("pendulum", dict(n_gp=70), 15, 3),
+    ("cartpole", dict(n_gp=90), [3, 3, 2, 70], 9),
+    ("pendulum", dict(n_gp=70), [5, 120], 16),
+])
+def test_policy_evaluation_ragged_rows_on_4x4x4(sl, name, kw, nv, na, monkeypatch):
+    """k_bellman4_policy on grids whose last axis is not a multiple of 64 cells (masked lanes in the
+    ragged tile of a row): against k_bellman_policy_mfma on the same inputs, against the oracle, and
+    on an index range that cuts rows."""
+    case = cases.make_case(name, num_points=nv, **kw)
+    actions = np.linspace(-1, 1, na)[:, None]
+    monkeypatch.setenv("SL_BELLMAN4_RAGGED", "1")
+    results = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SL_BELLMAN4_POLICY", flag)
+        rl, orl, vf, ovf = _rl_pair(sl, case, nv)
+        n = vf.discretization.nindex
+        table = actions[np.random.default_rng(6).integers(0, na, n)]
+        rl.policy = np.ascontiguousarray(table)
+        rl.value_iteration()
+        results[flag] = (vf._host_parameters().copy(), rl.last_residual, rl._ctx.last_kernel())
+    assert "k_bellman4_policy" in results["1"][2] and "k_bellman4_policy" not in results["0"][2], \
+        (results["1"][2], results["0"][2])
+    assert_allclose(results["1"][0], results["0"][0], rtol=1e-11, atol=1e-13)
+    assert_allclose(results["1"][1], results["0"][1], rtol=1e-9)
+    orl.policy = lambda states, _table=table: _table
+    x = orl.state_space
+    ok = ~ambiguous_points(ovf, orl.dynamics(x, table)[0])
+    orl.value_iteration()
+    assert ok.mean() > 0.5
+    assert_allclose(results["1"][0][ok], ovf.parameters[ok], rtol=1e-9, atol=1e-12)
+    # a shard-like range that cuts rows: the same values on its slice
+    monkeypatch.setenv("SL_BELLMAN4_POLICY", "1")
+    rl, orl, vf, ovf = _rl_pair(sl, case, nv)
+    n = vf.discretization.nindex
+    if n >= 256:
+        lo, hi = 64, (n // 64 - 1) * 64
+        rl._lo, rl._hi = lo, hi
+        v_part, _, _, _ = rl._sweep(np.ascontiguousarray(table), None)
+        assert "k_bellman4_policy" in rl._ctx.last_kernel()
+        assert_array_equal(v_part[:hi - lo].cpu().numpy(), results["1"][0][lo:hi, 0])

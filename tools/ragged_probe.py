@@ -22,3 +22,13 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t) / 3 * 1e3
 print({"grid": "%d^4" % n, "cells": grid.nindex, "SL_BELLMAN4": os.environ.get("SL_BELLMAN4", "1"),
        "ms_per_sweep": ms, "pairs_per_s": grid.nindex * 9 / ms * 1e3, "kernel": rl._ctx.last_kernel()})
+# policy evaluation with the greedy table policy of the sweeps above (k_bellman4_policy against
+# k_bellman_policy_mfma: SL_BELLMAN4_POLICY=0)
+rl.discrete_policy_optimization(actions)
+def evaluate():
+    rl.value_iteration()
+evaluate(); torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(3): evaluate()
+torch.cuda.synchronize()
+print({"grid": "%d^4" % n, "policy evaluation ms": (time.perf_counter() - t) / 3 * 1e3,
+       "SL_BELLMAN4_POLICY": os.environ.get("SL_BELLMAN4_POLICY", "1"), "kernel": rl._ctx.last_kernel()})
