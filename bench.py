@@ -37,7 +37,7 @@ FP64_MFMA_PEAK_TFLOPS = 78.6        # MI355X FP64 matrix (= vector) peak, SURVEY
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 HEADLINE_METRIC = "grid-cell Lyapunov checks/sec + ms/safe_set-update, 4D 128^4 grid, 1k-pt GP"
 CONFIGS = ("C1", "C2", "C2-table", "C2-table-large", "C2-table-stack", "C2-table-det", "C3", "C4", "C4-lin",
-           "C4-det", "C5")
+           "C4-det", "C5", "C5-policy")
 
 
 def flops_per_check(n, p, d_out, heads=1):
@@ -107,6 +107,14 @@ def build_workload(args):
         label = ("cartpole %d^4 value table x 9 actions, %d-point RBF GP mean dynamics, "
                  "PolicyIteration.value_iteration(action_space) Bellman sweeps" % (npts, n_gp))
         return "bellman", label, case
+    elif cfg == "C5-policy":
+        # the other sweep of the loop: evaluation of the greedy table policy (the policy that
+        # discrete_policy_optimization leaves after three max sweeps from V = 0)
+        npts, n_gp = args.num_points or 64, args.n_gp or 1024
+        case = headline_case(num_points=npts, n_gp=n_gp)
+        label = ("cartpole %d^4 value table, %d-point RBF GP mean dynamics, greedy 9-action table "
+                 "policy, PolicyIteration.value_iteration() policy-evaluation sweeps" % (npts, n_gp))
+        return "policy", label, case
     else:
         raise ValueError(cfg)
     return "lyapunov", label, case
@@ -282,6 +290,14 @@ def run_rank(args, rank, world, local_rank, backend):
         units = obj.discretization.nindex
         step = obj.update_safe_set
         cells_per_launch = obj._hi - obj._lo
+    elif kind == "policy":
+        obj, actions = build_policy_iteration(case)
+        for _ in range(3):
+            obj.value_iteration(actions)
+        obj.discrete_policy_optimization(actions)
+        units = obj.discretization.nindex
+        step = obj.value_iteration
+        cells_per_launch = obj._hi - obj._lo
     else:
         obj, actions = build_policy_iteration(case)
         units = obj.discretization.nindex * len(actions)
@@ -346,6 +362,11 @@ def run_rank(args, rank, world, local_rank, backend):
             # let one cell of 2.7e8 pass - that variant exists to show the cost is the same)
             raise SystemExit("bench.py: degenerate workload - the level set did not grow (%d safe "
                              "cells, %d initial)" % (extra["safe_cells"], extra["initial_cells"]))
+    elif kind == "policy":
+        end_to_end_ms = None
+        table = obj.policy._host_parameters().reshape(-1, case["num_points"][-1])
+        extra["distinct_actions_per_row"] = float(
+            np.mean((np.diff(np.sort(table, axis=1), axis=1) != 0).sum(axis=1) + 1))
     else:
         end_to_end_ms = None
         # sweeps to convergence at max|dV| <= 1e-6 max|V| (SURVEY 8d metric iii), continuing from
@@ -369,9 +390,11 @@ def run_rank(args, rank, world, local_rank, backend):
         out = {
             "metric": HEADLINE_METRIC if args.config == "C4" else
             ("Bellman sweep (vertex, action) pairs/sec + ms/sweep" if kind == "bellman" else
+             "policy-evaluation sweep vertices/sec + ms/sweep" if kind == "policy" else
              "grid-cell Lyapunov checks/sec + ms/safe_set-update"),
             "value": units * args.steps / elapsed,
-            "unit": "checks/s" if kind == "lyapunov" else "(vertex, action) pairs/s",
+            "unit": "checks/s" if kind == "lyapunov" else
+            ("vertices/s" if kind == "policy" else "(vertex, action) pairs/s"),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -399,7 +422,8 @@ def run_rank(args, rank, world, local_rank, backend):
             out["end_to_end_ms"] = end_to_end_ms      # incl. bits->bytes and the bool[N] D2H
         out["roofline"] = roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world)
         out["roofline"]["kernel"] = obj._ctx.last_kernel()    # what the library launched (sl_last_kernel)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and kind != "policy":
+            # (the policy-evaluation line has no CPU leg of its own: C5's is the same oracle sweep)
             out["cpu_baseline"] = cpu_baseline(kind, case, min_cells=args.cpu_cells)
         print(json.dumps(out), flush=True)
     if grouped:
@@ -418,6 +442,16 @@ def _popcount(words):
 def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
     """Achieved rate of the dominant kernel against the roofline that bounds it."""
     is_gp = dyn.get("kind") == "gp"
+    if kind == "policy":
+        n = len(dyn["X"])
+        flops = 2.0 * n * d                      # the mean of the vertex's own action
+        achieved = flops * cells_per_launch / (avg_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "kernel": None, "kernel_ms": avg_ms, "flops_per_vertex": flops,
+                "note": "algorithmic flops = the posterior mean of each vertex's own action; the "
+                        "kernel computes the means of every distinct action of a 64-cell tile for all "
+                        "of its cells (one quarter-block GEMM per distinct action, DESIGN 4.4)"}
     if kind == "bellman":
         n = len(dyn["X"])
         flops = 2.0 * n * 9 * d                  # one FP64 GEMM [cells x n] . [n x A*D] (DESIGN 4.4)

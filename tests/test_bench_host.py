@@ -27,7 +27,7 @@ def test_args_and_workloads():
     for cfg in bench.CONFIGS:
         args = bench.parse_args(["--config", cfg, "--num-points", "6", "--n-gp", "20"])
         kind, label, case = bench.build_workload(args)
-        assert kind == ("bellman" if cfg == "C5" else "lyapunov")
+        assert kind == {"C5": "bellman", "C5-policy": "policy"}.get(cfg, "lyapunov")
         assert isinstance(label, str) and case["d"] in (1, 2, 4)
     # the headline: BASELINE.json's grid and GP sizes
     kind, label, case = bench.build_workload(bench.parse_args([]))
