@@ -12,7 +12,8 @@ All inputs are resident in HBM (the model is uploaded before the timed region); 
 ``--config`` selects the other BASELINE.json configurations (they are parity-test cases, not the
 headline): C1 (1-D, 1001 cells), C2 (pendulum 256^2, 512-pt GP), C3 (pendulum 2048^2, 2048-pt GP,
 LyapunovNetwork), C4-lin / C4-det (cart-pole 128^4 with linear / Euler dynamics, the HBM-bound
-cases) and C5 (cart-pole 64^4 x 9 actions: Bellman optimality sweeps, also run to convergence).
+cases), C5 (cart-pole 64^4 x 9 actions: Bellman optimality sweeps, also run to convergence) and
+C5-policy (the other sweep of that loop: evaluation of the greedy table policy).
 
 ``--gpus N``: one process per GPU.  Under torchrun (WORLD_SIZE set) this process is one rank;
 otherwise bench.py launches the N ranks itself (``torch.multiprocessing.spawn``), backend ``nccl``

@@ -112,6 +112,15 @@ def test_bench_other_lyapunov_configs(config, flags):
     assert out["roofline"]["bound"] == ("mfma" if config == "C2" else "hbm")
 
 
+def test_bench_c5_policy_line():
+    """--config C5-policy: the policy-evaluation sweep with the greedy table policy (on a 16-cell
+    last axis this is k_bellman_policy_mfma; the 64-cell shapes are tests/test_gpu_rl.py's)."""
+    out = _run("--config", "C5-policy", "--num-points", "10", "--n-gp", "128", "--steps", "3")
+    assert out["config"]["name"] == "C5-policy" and out["unit"] == "vertices/s" and out["value"] > 0
+    assert out["config"]["distinct_actions_per_row"] >= 1.0
+    assert "k_bellman" in out["roofline"]["kernel"] and "cpu_baseline" not in out
+
+
 def test_bench_c5_runs_to_convergence():
     out = _run("--config", "C5", "--num-points", "10", "--n-gp", "128", "--steps", "3",
                "--no-cpu-baseline", "--max-sweeps", "2500")
