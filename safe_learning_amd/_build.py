@@ -70,7 +70,10 @@ def _audit_bellman4(objdir, verbose):
         raise RuntimeError("sl_bellman4.hip failed its code audit:\n" + "\n".join(problems))
 
 
-def build(verbose=False, force=False):
+def build(verbose=False, force=False, run_audits=True, lib=None):
+    """``run_audits=False`` / ``lib=...``: development builds only (instrumented kernels whose listing the
+    audits do not describe, written next to the shipped library) - see tools/build_timing.py."""
+    LIB = lib or globals()["LIB"]
     csrc = os.path.join(HERE, "csrc")
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip"))]
     deps.append(os.path.join(ROOT, "include", "sl_hip.h"))
@@ -85,7 +88,7 @@ def build(verbose=False, force=False):
         flags.insert(0, "-Rpass-analysis=kernel-resource-usage")
     # one hipcc per translation unit, all at once, then one link.  Each unit has its own directory
     # (-save-temps=obj names the listing after the SOURCE file).
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if lib is None else "build_dev")
 
     def compile_cmd(stem, src, extra):
         os.makedirs(os.path.join(objdir, stem), exist_ok=True)
@@ -114,6 +117,8 @@ def build(verbose=False, force=False):
     for audit, src, macro, stems in ((_audit_gp4, "sl_gp4.hip", "SL_NO_GP4",
                                       ["sl_gp4_d%d" % dim for dim in (1, 2, 3, 4)]),
                                      (_audit_bellman4, "sl_bellman4.hip", "SL_NO_BELLMAN4", ["sl_bellman4"])):
+        if not run_audits:
+            continue
         if os.environ.get("SL_FORCE_AUDIT_FAILURE") == macro:       # exercised by the tests
             problem = "forced by SL_FORCE_AUDIT_FAILURE"
         else:
