@@ -70,9 +70,10 @@ def _audit_bellman4(objdir, verbose):
         raise RuntimeError("sl_bellman4.hip failed its code audit:\n" + "\n".join(problems))
 
 
-def build(verbose=False, force=False, run_audits=True, lib=None):
-    """``run_audits=False`` / ``lib=...``: development builds only (instrumented kernels whose listing the
-    audits do not describe, written next to the shipped library) - see tools/build_timing.py."""
+def build(verbose=False, force=False, run_audits=True, lib=None, only=None):
+    """``run_audits=False`` / ``lib=...`` / ``only=[stems]``: development builds only (instrumented
+    kernels whose listing the audits do not describe, written next to the shipped library; the
+    units not named in ``only`` are taken from the shipped build) - see tools/build_dev.py."""
     LIB = lib or globals()["LIB"]
     csrc = os.path.join(HERE, "csrc")
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip"))]
@@ -97,6 +98,8 @@ def build(verbose=False, force=False, run_audits=True, lib=None):
 
     jobs = []
     for stem, src, extra in UNITS:
+        if only is not None and stem not in only:
+            continue
         cmd = compile_cmd(stem, src, extra)
         if verbose:
             print(" ".join(cmd))
@@ -109,7 +112,8 @@ def build(verbose=False, force=False, run_audits=True, lib=None):
         failed = failed or proc.returncode != 0
     if failed:
         raise RuntimeError("hipcc failed")
-    objects = {stem: os.path.join(objdir, stem, stem + ".o") for stem, _, _ in UNITS}
+    objects = {stem: os.path.join(objdir if only is None or stem in only else os.path.join(HERE, "build"),
+                                  stem, stem + ".o") for stem, _, _ in UNITS}
     # The 4x4x4 kernels rely on properties of the generated code that only the audits can prove
     # (inline asm owns accumulator registers).  A toolchain that schedules or names things
     # differently must not make the package unbuildable: the kernel in question is compiled out
