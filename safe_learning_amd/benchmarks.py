@@ -9,7 +9,6 @@ are BASELINE.json's.
 """
 
 import numpy as np
-from scipy import signal
 
 from .functions import _cartpole_linearize, _pendulum_linearize
 from .utilities import dlqr

@@ -9,8 +9,6 @@ over gloo.
 
 import os
 
-import numpy as np
-
 _MASK63 = (1 << 63) - 1
 
 

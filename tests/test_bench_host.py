@@ -4,7 +4,6 @@ on small cases (the oracle is the thing timed there - allowed for bench.py's cpu
 import os
 import sys
 
-import numpy as np
 
 from conftest import ROOT
 

@@ -10,7 +10,6 @@
 Reference: lyapunov.py:407-606, reinforcement_learning.py:65-140, 213-279.
 """
 
-import os
 import sys
 
 import numpy as np

@@ -7,7 +7,6 @@ Everything goes through the C ABI (libslhip.so) via safe_learning_amd.  Bars:
  * safe_set and c_max equal to the oracle's sequential prefix rule.
 """
 
-import os
 
 import numpy as np
 import pytest

@@ -16,8 +16,7 @@ from numpy.testing import assert_allclose, assert_array_equal
 
 import cases
 import oracle
-from conftest import ROOT, GOLDEN_DIR
-from safe_learning_amd import _hip
+from conftest import ROOT
 from safe_learning_amd import functions as F
 from safe_learning_amd._model import ModelBuilder
 from safe_learning_amd.benchmarks import build_specs

@@ -24,7 +24,6 @@ from numpy.testing import assert_equal
 
 import oracle
 
-import cases
 from conftest import GOLDEN_DIR
 
 
