@@ -186,6 +186,41 @@ def audit_in_place(path, prefix=r"_Z1[017]k_bellman4(?:s|_policy)?I"):
                         if regs_of(prev.split(None, 1)[1].split(", ")[0]) & sources:
                             close.append("%s -> %s" % (prev, c))
                     slots += 1
+            # Direct global -> LDS loads (development build -DSL_B4S_DMA) are inline asm too: the
+            # compiler neither counts them nor waits for them.  In front of the loop's barrier there
+            # has to be an s_waitcnt vmcnt(N) with N <= the number of loads issued behind the last
+            # such copy (walking backwards from the barrier, around the loop's layout).
+            dma_problem = None
+            if any("global_load_lds" in c for c in code_lines):
+                barriers = [i for i, c in enumerate(code_lines) if c.startswith("s_barrier")]
+                if not barriers:
+                    dma_problem = "direct-to-LDS loads in a loop without a barrier"
+                for b in barriers:
+                    wait = None
+                    for back in range(1, 10):
+                        mm = re.match(r"s_waitcnt .*vmcnt\((\d+)\)", code_lines[b - back]) if b - back >= 0 else None
+                        if mm:
+                            wait, wait_at = int(mm.group(1)), b - back
+                            break
+                        if b - back >= 0 and code_lines[b - back].startswith(("v_mfma", "buffer_", "global_", "ds_")):
+                            break
+                    if wait is None:
+                        dma_problem = "no s_waitcnt vmcnt(N) in front of the barrier of a loop with direct-to-LDS loads"
+                        break
+                    order = list(range(wait_at - 1, -1, -1)) + list(range(len(code_lines) - 1, b, -1))
+                    younger = 0
+                    for i in order:
+                        c = code_lines[i]
+                        if "global_load_lds" in c:
+                            break
+                        if c.startswith(("buffer_load", "global_load")):
+                            younger += 1
+                    if wait > younger:
+                        dma_problem = ("s_waitcnt vmcnt(%d) in front of the barrier, but only %d loads behind "
+                                       "the last direct-to-LDS copy" % (wait, younger))
+                        break
+            if dma_problem:
+                problems.append("%s: %s" % (name, dma_problem))
             report.append("%s: %d MFMAs on %d accumulator registers in the chunk loop, %d out of "
                           "place, %d other instructions touch an accumulator, %d scratch accesses, "
                           "%d sources written within two slots of their MFMA"
