@@ -99,3 +99,45 @@ def test_shipped_listing_passes():
         pytest.skip("no build directory (the library was built elsewhere)")
     report, found = audit_gp4.audit_in_place(path)
     assert not found and len(report) >= 20
+
+
+# ---- audit(): k_gp_sweep4 owns a[0:255]; only its asm groups may name them -------------------
+GP_NAME = "_Z11k_gp_sweep4ILi4ELi1ELb1EEvTEST"
+
+
+def gp_listing(streams, extra, tmp_path):
+    lines = ["\t.text", GP_NAME + ":"]
+    for k, stream in enumerate(streams):
+        lines += [".LBB0_%d:" % (k + 1)] + stream + ["\ts_cbranch_scc1 .LBB0_%d" % (k + 1)]
+    lines += extra + ["\ts_endpgm", ""]
+    path = tmp_path / "gp.s"
+    path.write_text("\n".join(lines))
+    return str(path)
+
+
+def gp_stream(n=64, inside=()):
+    group = ["\t;;#ASMSTART"] + ["\tv_mfma_f64_4x4x4_4b_f64 a[0:1], v[2:3], v[4:5], a[0:1]"] * 8 + ["\t;;#ASMEND"]
+    return ["\tds_read_b128 v[4:7], v60"] + list(inside) + group * (n // 8)
+
+
+def test_gp4_audit_accepts_the_asm_groups(tmp_path):
+    report, found = audit_gp4.audit(gp_listing([gp_stream()] * 2, [], tmp_path), min_loops=2)
+    assert not found and "128 MFMAs" in report[0] and "in 2 MFMA loops" in report[0]
+
+
+@pytest.mark.parametrize("streams, extra, what", [
+    ([gp_stream()] * 2, ["\tv_accvgpr_read_b32 v9, a17"], "touches accumulator registers"),       # compiler AGPR use
+    ([gp_stream()] * 2, ["\tv_mfma_f64_4x4x4_4b_f64 a[8:9], v[2:3], v[4:5], a[8:9]"], "touches accumulator"),
+    ([gp_stream(inside=["\tscratch_load_dword v1, off, off"])] * 2, [], "scratch instructions inside the MFMA loops"),
+    ([gp_stream(inside=["\tv_readlane_b32 s4, v200, 3"] * 17)] * 2, [], "v_readlane / v_writelane in one MFMA stream"),
+    ([gp_stream()], [], "only 1 MFMA loops recognised"),
+    ([["\ts_nop 0"]] * 2, [], "no MFMA found"),
+])
+def test_gp4_audit_rejects(streams, extra, what, tmp_path):
+    found = audit_gp4.audit(gp_listing(streams, extra, tmp_path), min_loops=2)[1]
+    assert any(what in p for p in found), found
+
+
+def test_gp4_audit_allows_scratch_and_lane_reads_outside_the_streams(tmp_path):
+    extra = ["\tscratch_load_dword v1, off, off", "\tv_readlane_b32 s4, v200, 3"] * 40
+    assert not audit_gp4.audit(gp_listing([gp_stream()] * 2, extra, tmp_path), min_loops=2)[1]
