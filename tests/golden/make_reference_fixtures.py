@@ -86,8 +86,10 @@ class _Scope(object):
         return False
 
 
-def load_reference():
-    """-> the reference's ``functions`` module (GridWorld, _Triangulation usable)."""
+def load_reference(gpflow_module=None):
+    """-> the reference's ``functions`` module (GridWorld, _Triangulation usable).
+    ``gpflow_module``: what ``import gpflow`` resolves to instead of the refusing stand-in
+    (``numpy_gpflow.module()``, so that ``GPRCached`` inherits from a working ``GPR``)."""
     np.int = int
     tf = _StandInModule("tensorflow")
     tf.float64 = types.SimpleNamespace(as_numpy_dtype=np.float64)
@@ -95,9 +97,12 @@ def load_reference():
     tf.get_default_graph = lambda: graph                       # functions.py:40
     tf.variable_scope = lambda name: _Scope()                  # functions.py:44
     tf.make_template = lambda *args, **kwargs: None            # functions.py:49 (never called)
-    gpflow = _StandInModule("gpflow")
-    gpflow.gpr = _StandInModule("gpflow.gpr")
-    gpflow.gpr.GPR = type("GPR", (object,), {})                # base class of GPRCached (unused)
+    if gpflow_module is not None:
+        gpflow = gpflow_module
+    else:
+        gpflow = _StandInModule("gpflow")
+        gpflow.gpr = _StandInModule("gpflow.gpr")
+        gpflow.gpr.GPR = type("GPR", (object,), {})            # base class of GPRCached (unused)
     future = types.ModuleType("future")
     future_builtins = types.ModuleType("future.builtins")
     future_builtins.zip, future_builtins.range, future_builtins.object = zip, range, object

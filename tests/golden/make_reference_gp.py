@@ -1,0 +1,142 @@
+"""GP posteriors computed BY THE REFERENCE'S OWN GP CODE, at size (build container only).
+
+What runs here, unmodified, loaded from ``/root/reference``: ``functions.py`` ``GPRCached``
+(``__init__``, ``_compute_cache`` ``:395-410``: scaled kernel matrix + noise, Cholesky, triangular
+solve; ``update_cache``; ``build_predict`` ``:417-458``: scaled cross-kernel, triangular solve,
+mean, marginal variance, inverse scaling, tile), ``GaussianProcess`` (``__init__`` ``:482-498``,
+``build_evaluation`` ``:507-515``: ``beta * sqrt(var)``; ``add_data_point`` ``:525-546``),
+``FunctionStack`` (``:254-307``) and the ``concatenate_inputs`` decorator that joins states and
+actions (``utilities.py``).  gpflow 0.4.0 is absent: ``numpy_gpflow.py`` restates the RBF kernel,
+the mean functions and the parameter plumbing of that pinned version (and is itself checked by the
+reference's GP tests, see that file); TensorFlow is ``numpy_tf.py`` (Cholesky / triangular solves
+through LAPACK).
+
+Cases: n in {3, 130, 512, 1024} training points, p in {3, 5} inputs (pendulum / cart-pole state +
+action), the configurations C2 (512, p = 3) and C4 (1024, p = 5) of BASELINE.json among them; the
+``informed`` and ``tight`` hyper-parameters of the parity tests; ``scale != 1`` (the reference's
+internal scaling ``:402-405, 438-439, 455-456``), measurement noise 1e-6 x signal (cond(K) ~ 1e9),
+a zero mean function, a ``FunctionStack`` of one single-output GP per state dimension, and a model
+extended with ``add_data_point``.  Query points are grid cells with the closed-loop action of the
+case's policy (what the sweep kernels evaluate; the test addresses them by flat index), the
+training inputs themselves and points far outside the data.
+
+Output ``reference_gp_posterior.npz``: per case the hyper-parameters, ``X``, ``Y``, the query
+inputs, ``mean`` and ``bound = beta * sqrt(var)`` exactly as ``GaussianProcess.build_evaluation``
+returns them, and ``var`` from ``build_predict``.  Data only.
+
+    python tests/golden/make_reference_gp.py          (needs /root/reference)
+"""
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy_tf                                         # noqa: E402
+from tests.gp_cases import (reference_gp_case_list as case_list,        # noqa: E402
+                            reference_gp_build_case as build_case)
+
+OUT = os.path.join(HERE, "reference_gp_posterior.npz")
+
+
+def reference_gp_dynamics(case, ref, scale=1.0, zero_mean=False):
+    """The dynamics model of a GP case (``safe_learning_amd.benchmarks.make_case`` parameters) as
+    the REFERENCE'S objects: ``GaussianProcess(GPRCached(X, Y, RBF, Linear))`` or a
+    ``FunctionStack`` of single-output ones (``inverted_pendulum.ipynb:152-181``)."""
+    gpflow = sys.modules["gpflow"]
+    F = ref.functions
+    dyn, d = case["dynamics"], case["d"]
+
+    def model(Y, prior, lengthscales):
+        kern = gpflow.kernels.RBF(d + 1, variance=dyn["variance"], lengthscales=lengthscales, ARD=True)
+        if zero_mean:
+            mean = gpflow.mean_functions.Zero()
+        else:
+            mean = gpflow.mean_functions.Linear(np.ascontiguousarray(prior.T), np.zeros(len(prior)))
+        gp = F.GPRCached(dyn["X"], Y, kern, mean, scale=scale)
+        gp.likelihood.variance = dyn["noise_variance"]
+        gp.update_cache()                      # the notebooks set the noise after construction too
+        return F.GaussianProcess(gp, beta=dyn["beta"])
+
+    if case["stack"]:
+        return F.FunctionStack([model(dyn["Y"][:, [k]], dyn["prior"][[k], :], dyn["lengthscales"][k])
+                                for k in range(d)])
+    return model(dyn["Y"], dyn["prior"], dyn["lengthscales"])
+
+
+def evaluate(dynamics, inputs, d):
+    """``dynamics(states, actions)`` as the verification loop calls it (``lyapunov.py:436-437``)."""
+    mean, bound = dynamics(inputs[:, :d], inputs[:, d:])
+    return numpy_tf.evaluate([mean, bound], {}, {})
+
+
+def query_inputs(case, rng, cells):
+    """Grid cells (flat indices, for the sweep kernels) with their closed-loop actions, the
+    training inputs and far-away points."""
+    d = case["d"]
+    num_points = np.asarray(case["num_points"])
+    nindex = int(np.prod(num_points))
+    idx = np.sort(rng.choice(nindex, min(cells, nindex), replace=False))
+    limits = np.asarray(case["limits"], dtype=np.float64)
+    unit = (limits[:, 1] - limits[:, 0]) / (num_points - 1)
+    ijk = np.stack(np.unravel_index(idx, num_points), axis=1).astype(np.float64)
+    states = ijk * unit + limits[:, 0]                       # functions.py:728-731
+    K = np.asarray(case["K"])
+    actions = states[:, [0]] * K[:, 0]
+    for k in range(1, d):                                    # left to right, like the kernels
+        actions = actions + states[:, [k]] * K[:, k]
+    if case["saturate"] is not None:
+        actions = np.minimum(np.maximum(actions, case["saturate"][0]), case["saturate"][1])
+    X = case["dynamics"]["X"]
+    extra = np.vstack((X[: min(len(X), 64)], rng.uniform(-4.0, 4.0, (32, d + 1))))
+    return idx, np.hstack((states, actions)), extra
+
+
+def main():
+    ref = numpy_tf.load_reference(examples=False)
+    rng = np.random.default_rng(20260928)
+    arrays = {"_names": np.array([spec["name"] for spec in case_list()]),
+              "_numpy_version": np.array(np.__version__)}
+    for spec in case_list():
+        name = spec["name"]
+        case = build_case(spec)
+        d, dyn = case["d"], case["dynamics"]
+        dynamics = reference_gp_dynamics(case, ref, scale=spec.get("scale", 1.0),
+                                         zero_mean=spec.get("zero_mean", False))
+        if "add_points" in spec:
+            new_x = rng.uniform(-0.6, 0.6, (spec["add_points"], d + 1))
+            new_y = new_x @ dyn["prior"].T + rng.normal(0, 2e-3, (spec["add_points"], d))
+            for x, y in zip(new_x, new_y):
+                dynamics.add_data_point(x[None, :], y[None, :])
+            arrays[name + "/added_x"], arrays[name + "/added_y"] = new_x, new_y
+        idx, cell_inputs, extra = query_inputs(case, rng, spec["cells"])
+        mean_c, bound_c = evaluate(dynamics, cell_inputs, d)
+        mean_e, bound_e = evaluate(dynamics, extra, d)
+        heads = dynamics.functions if case["stack"] else [dynamics]
+        var = np.hstack([numpy_tf.evaluate(
+            h.gaussian_process.build_predict(numpy_tf.constant(np.vstack((cell_inputs, extra))))[1], {}, {})
+            for h in heads])
+        cond = max(float(np.linalg.cond(h.gaussian_process.cholesky.value)) ** 2 for h in heads)
+        arrays.update({name + "/X": dyn["X"], name + "/Y": dyn["Y"],
+                       name + "/variance": np.float64(dyn["variance"]),
+                       name + "/lengthscales": np.asarray(dyn["lengthscales"]),
+                       name + "/noise_variance": np.float64(dyn["noise_variance"]),
+                       name + "/prior": dyn["prior"], name + "/beta": np.float64(dyn["beta"]),
+                       name + "/cell_index": idx, name + "/cell_inputs": cell_inputs,
+                       name + "/cell_mean": mean_c, name + "/cell_bound": bound_c,
+                       name + "/extra_inputs": extra, name + "/extra_mean": mean_e,
+                       name + "/extra_bound": bound_e, name + "/var": var,
+                       name + "/cond": np.float64(cond)})
+        print("%-26s n %4d p %d D %d  cond(K) %.1e  bound %.2e .. %.2e" % (
+            name, len(heads[0].X), d + 1, mean_c.shape[1], cond, bound_c.min(), bound_c.max()))
+    np.savez_compressed(OUT, **arrays)
+    print("wrote %s (%d arrays, %.1f KiB)" % (OUT, len(arrays), os.path.getsize(OUT) / 1024.0))
+
+
+if __name__ == "__main__":
+    main()

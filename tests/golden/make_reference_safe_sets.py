@@ -13,12 +13,16 @@ What runs here, unmodified, loaded from ``/root/reference``:
   the reference's own objects;
 * ``examples/utilities.py``: ``InvertedPendulum`` and ``CartPole`` (the Euler models).
 
+* ``functions.py``'s GP classes (round 4): a GP dynamics model is the reference's
+  ``GaussianProcess(GPRCached(...))`` / ``FunctionStack`` (``:254-307, 357-546``: Cholesky cache,
+  ``build_predict``, ``beta sqrt(var)``, ``add_data_point`` with its cache rebuild) on top of
+  ``tests/golden/numpy_gpflow.py``, the restatement of the gpflow 0.4.0 pieces underneath (RBF
+  kernel, mean functions, parameter plumbing).  Until round 3 this leaf was the oracle's callable.
+
 What does NOT run is TensorFlow (absent from the image): ``tests/golden/numpy_tf.py`` answers the
 ops these files request with NumPy (elementwise IEEE-754 double arithmetic; ``matmul`` /
-``reduce_sum`` accumulate left to right - see that file for what this does and does not claim).
-And gpflow is absent: a GP dynamics model is the one leaf that is NOT a reference object; it is the
-oracle's ``GaussianProcess`` / ``FunctionStack`` callable (pinned by the reference's known-answer
-test) wrapped as a graph function.
+``reduce_sum`` accumulate left to right - see that file for what this does and does not claim;
+``tf.cholesky`` / ``tf.matrix_triangular_solve`` are LAPACK).
 
 ``tests/test_oracle_reference_safe_sets.py`` replays every scenario on ``oracle.Lyapunov`` with the
 oracle's own function classes and requires the safe set, ``c_max``, the value table, the
@@ -51,6 +55,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 import numpy_tf                                         # noqa: E402
+import make_reference_gp                                # noqa: E402
 
 OUT = os.path.join(HERE, "reference_safe_sets.npz")
 
@@ -59,11 +64,11 @@ OUT = os.path.join(HERE, "reference_safe_sets.npz")
 # The reference's own function classes as leaves
 # --------------------------------------------------------------------------------------
 
-def reference_specs(case, ref, oracle_dynamics):
+def reference_specs(case, ref):
     """(policy, dynamics, V, L_v) of a case (tests/cases.py parameters) built from the REFERENCE'S
     classes: ``functions.py`` ``LinearSystem`` / ``QuadraticFunction`` / ``Saturation`` /
-    ``Triangulation`` and ``examples/utilities.py`` ``InvertedPendulum`` / ``CartPole``.  Only a
-    GP model has no reference object here (gpflow is absent): it stays the oracle's callable."""
+    ``Triangulation`` / ``GaussianProcess(GPRCached)`` / ``FunctionStack`` and
+    ``examples/utilities.py`` ``InvertedPendulum`` / ``CartPole``."""
     F, tf = ref.functions, sys.modules["tensorflow"]
     d = case["d"]
     if "policy_table" in case:
@@ -83,7 +88,7 @@ def reference_specs(case, ref, oracle_dynamics):
         dynamics = ref.examples.CartPole(dyn["pendulum_mass"], dyn["cart_mass"], dyn["length"],
                                          dyn["rot_friction"], dyn["dt"], dyn["normalization"])
     else:
-        dynamics = numpy_tf.lazy_function(oracle_dynamics, d, uncertain=True)
+        dynamics = make_reference_gp.reference_gp_dynamics(case, ref)
     vspec = case.get("V", {"kind": "quadratic"})
     if vspec["kind"] == "quadratic":
         value = F.QuadraticFunction(case["P"])
@@ -293,8 +298,7 @@ def main():
     arrays, index = {}, []
     for scenario in scenarios():
         name, case = scenario["name"], scenario["case"]
-        _, oracle_dynamics, _, _ = cases.oracle_specs(case)
-        policy, dynamics, value, lv = reference_specs(case, ref, oracle_dynamics)
+        policy, dynamics, value, lv = reference_specs(case, ref)
         initial = None if scenario.get("no_initial_set") else cases.initial_safe_mask(case)
         config.gp_batch_size = scenario["batch"]
         grid = functions.GridWorld(case["limits"], case["num_points"])
@@ -303,7 +307,7 @@ def main():
         if scenario.get("unique"):
             assert len(np.unique(lyap.values)) == len(lyap.values), name
         boundary = lyapunov.smallest_boundary_value(value, grid)
-        records = replay(scenario, lyap, oracle_dynamics, lyapunov.get_safe_sample,
+        records = replay(scenario, lyap, dynamics, lyapunov.get_safe_sample,
                          lambda obj: obj.feed_dict[obj.c_max])
         arrays[name + "/values"] = lyap.values
         arrays[name + "/boundary"] = np.float64(boundary)
@@ -377,8 +381,7 @@ def check_live(count, seed):
         name, case = scenario["name"], scenario["case"]
         initial = cases.initial_safe_mask(case)
         # the reference's run
-        _, oracle_dynamics, _, _ = cases.oracle_specs(case)
-        policy, dynamics, value, lv = reference_specs(case, ref, oracle_dynamics)
+        policy, dynamics, value, lv = reference_specs(case, ref)
         ref.config.gp_batch_size = scenario["batch"]
         grid = ref.functions.GridWorld(case["limits"], case["num_points"])
         lyap = ref.lyapunov.Lyapunov(grid, value, dynamics, case["lf"], lv, case["tau"], policy,
@@ -386,7 +389,7 @@ def check_live(count, seed):
         if len(np.unique(lyap.values)) != len(lyap.values):
             print("%s: equal values on the grid, skipped (tie order is unpinned)" % name)
             continue
-        want = replay(scenario, lyap, oracle_dynamics, ref.lyapunov.get_safe_sample,
+        want = replay(scenario, lyap, dynamics, ref.lyapunov.get_safe_sample,
                       lambda obj: obj.feed_dict[obj.c_max])
         # the oracle's
         np_lyapunov.config.gp_batch_size = scenario["batch"]
@@ -398,6 +401,9 @@ def check_live(count, seed):
         assert np.array_equal(olyap.values, lyap.values), name
         for k, (a, b) in enumerate(zip(got, want)):
             for key in b:
+                if key == "bound" and case["dynamics"]["kind"] == "gp":     # a posterior std
+                    assert np.allclose(a[key], b[key], rtol=1e-10, atol=0), (name, k, key)
+                    continue
                 assert np.array_equal(a[key], b[key]), "%s step %d %s" % (name, k, key)
         compared += 1
         print("%-34s cells %5d batch %3d safe %s%s" % (

@@ -23,8 +23,9 @@ What this is and is not:
   no number in a fixture can come from an unimplemented stand-in.
 * The stand-in itself is checked by the reference's OWN test suite: ``run_reference_tests.py``
   collects ``/root/reference/safe_learning/tests`` on the reference's code behind this module -
-  35 of the 44 tests pass (``reference_test_results.json``), the other 9 are refused by name
-  (gpflow, ``tf.gradients``, the Xavier initialiser, an optimiser) or skipped (cvxpy).
+  39 of the 44 tests pass (``reference_test_results.json``; the four GP tests run on
+  ``numpy_gpflow.py``), the other 5 are refused by name (``tf.gradients``, the Xavier initialiser,
+  an optimiser) or skipped (cvxpy).
 
 NumPy-2 / Python-3 compatibility of the reference, applied by ``load_reference``:
 ``np.int`` -> ``int`` (``functions.py:597``), ``collections.Sequence`` (``lyapunov.py:5``),
@@ -40,6 +41,7 @@ import sys
 import types
 
 import numpy as np
+import scipy.linalg
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
@@ -360,7 +362,19 @@ def install(tf):
     tf.stop_gradient = lambda x: x
     tf.placeholder = lambda dt, shape=None, name="": Lazy(None, (), static(shape), name)
     tf.constant = constant
-    tf.eye = lambda n, dtype=None: constant(np.eye(n))
+    tf.eye = lambda n, dtype=None: Lazy(lambda k: np.eye(int(k)), (n,))
+    tf.shape = lambda x: Lazy(lambda v: np.array(np.shape(v)), (x,),
+                              None if shape_of(x) is None else (len(shape_of(x)),))
+    # functions.py:408-409, 441: LAPACK (dpotrf / dtrtrs) for TensorFlow's Eigen LLT / triangular
+    # solve - both backward-stable factorizations, results agree up to rounding x cond(K)
+    tf.cholesky = lambda a, name=None: Lazy(lambda v: scipy.linalg.cholesky(v, lower=True), (a,),
+                                            shape_of(a))
+    tf.matrix_triangular_solve = lambda a, b, lower=True, name=None: Lazy(
+        lambda u, v: scipy.linalg.solve_triangular(u, v, lower=lower), (a, b), shape_of(b))
+    tf.sqrt, tf.exp = unary(np.sqrt), unary(np.exp)
+    tf.expand_dims = lambda x, axis: Lazy(lambda v: np.expand_dims(v, axis), (x,))
+    tf.fill = lambda dims, value: Lazy(lambda d, v: np.full(tuple(int(k) for k in d), v), (dims, value))
+    tf.zeros = lambda dims, dtype=None: Lazy(lambda d: np.zeros(tuple(int(k) for k in d)), (dims,))
     tf.matmul, tf.reduce_sum, tf.norm = matmul, reduce_sum, norm
     tf.split, tf.concat, tf.tile, tf.unstack = split, concat, tile, unstack
     tf.stack = lambda xs, axis=0, name=None: (
@@ -378,6 +392,10 @@ def install(tf):
     tf.where = lambda c, a, b: Lazy(np.where, (c, a, b), shape_of(a))
     tf.cast = lambda x, dt: Lazy(lambda v: np.asarray(v).astype(dt.as_numpy_dtype), (x,), shape_of(x))
     tf.reshape = lambda x, shape: Lazy(lambda v: np.reshape(v, shape), (x,), static(shape))
+    plain_tile = tf.tile
+    tf.tile = lambda x, multiples: (plain_tile(x, multiples) if not any(isinstance(m, Lazy) for m in multiples)
+                                    else Lazy(lambda v, *m: np.tile(v, [int(k) for k in m]),
+                                              (x,) + tuple(multiples)))
     tf.linspace = lambda a, b, n: Lazy(lambda u, v, k: np.linspace(u, v, int(k)), (a, b, n), (None,))
     tf.meshgrid = lambda *xs, **kw: [Lazy(lambda *v, _k=k: np.meshgrid(*v, **kw)[_k], tuple(xs))
                                      for k in range(len(xs))]
@@ -412,9 +430,11 @@ def _load(module_name, path):
     return module
 
 
-def load_reference(examples=False):
+def load_reference(examples=False, gpflow=True):
     """-> namespace(functions, lyapunov, reinforcement_learning, examples, config): the
-    reference's modules, executed from ``/root/reference`` with this stand-in as ``tensorflow``."""
+    reference's modules, executed from ``/root/reference`` with this stand-in as ``tensorflow`` and
+    (``gpflow=True``) ``numpy_gpflow`` as ``gpflow``: the reference's ``GPRCached`` /
+    ``GaussianProcess`` are then usable (``functions.py:357-546``)."""
     collections.Sequence = collections.abc.Sequence                   # lyapunov.py:5
     for name in ("column_stack", "hstack"):
         plain = getattr(np, name)
@@ -422,7 +442,13 @@ def load_reference(examples=False):
             wrapped = (lambda f: lambda tup: f(tup if isinstance(tup, np.ndarray) else tuple(tup)))(plain)
             wrapped._accepts_iterators = True
             setattr(np, name, wrapped)
-    functions = ref_loader.load_reference()
+    gpflow_module = None
+    if gpflow:
+        sys.path.insert(0, HERE)
+        import numpy_gpflow
+        sys.path.remove(HERE)
+        gpflow_module = numpy_gpflow.module()
+    functions = ref_loader.load_reference(gpflow_module)
     tf = sys.modules["tensorflow"]
     install(tf)
     package = sys.modules["safe_learning"]

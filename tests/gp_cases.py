@@ -34,3 +34,82 @@ GP_CASES = [
     # ... and beyond it: the generation phase reads the training inputs from L2
     ("cartpole", dict(num_points=11, n_gp=2000, tau_scale=0.0, **INFORMED), None, 100),
 ]
+
+
+# ---- cases of the reference-run GP posterior fixture (tests/golden/make_reference_gp.py) --------
+# name, family, make_case kwargs; optional: scale (GPRCached's internal scaling), noise_ratio
+# (noise variance / signal variance), zero_mean, add_points (observations added one by one with
+# add_data_point), cells (grid cells queried).
+
+def reference_gp_case_list():
+    from safe_learning_amd.benchmarks import GP_VARIANTS, make_case
+    informed, tight = GP_VARIANTS["informed"], GP_VARIANTS["tight"]
+    out = []
+
+    def add(name, family, num_points, n_gp, hyper, cells=384, **extra):
+        kw = dict(num_points=num_points, n_gp=n_gp, tau_scale=0.01, **hyper)
+        kw.update({k: extra.pop(k) for k in ("stack", "seed") if k in extra})
+        out.append(dict(name=name, family=family, kwargs=kw, cells=cells, **extra))
+
+    add("pendulum_n3", "pendulum", 40, 3, tight)
+    add("pendulum_n130", "pendulum", 64, 130, informed)
+    add("pendulum_n130_scale", "pendulum", 64, 130, informed, scale=7.5)
+    add("pendulum_n512_C2", "pendulum", 256, 512, informed)
+    add("pendulum_n512_ill", "pendulum", 256, 512, informed, noise_ratio=1e-6)
+    add("pendulum_n1024_zero_mean", "pendulum", 48, 1024, informed, zero_mean=True)
+    add("cartpole_n3", "cartpole", 12, 3, tight)
+    add("cartpole_n130", "cartpole", 12, 130, tight)
+    add("cartpole_n130_stack", "cartpole", 12, 130, tight, stack=True)
+    add("cartpole_n512_scale", "cartpole", 14, 512, informed, scale=0.04)
+    add("cartpole_n1024_C4", "cartpole", 128, 1024, informed, cells=768)
+    add("cartpole_n1024_ill", "cartpole", 16, 1024, informed, noise_ratio=1e-6, seed=3)
+    add("cartpole_n1024_stack", "cartpole", 16, 1024, informed, stack=True)
+    add("pendulum_n130_added", "pendulum", 64, 130, informed, add_points=6)
+    return out
+
+
+def reference_gp_build_case(spec):
+    """make_case parameters of a case of ``tests/golden/reference_gp_posterior.npz``."""
+    from safe_learning_amd.benchmarks import make_case
+    case = make_case(spec["family"], **spec["kwargs"])
+    if "noise_ratio" in spec:
+        case["dynamics"]["noise_variance"] = float(case["dynamics"]["variance"] * spec["noise_ratio"])
+    return case
+
+
+def reference_gp_tolerance(cond):
+    """Relative tolerance of a posterior mean / confidence bound against the reference-run fixture.
+    The fixture solves with the Cholesky factor of ``K + noise I`` (``functions.py:408-409, 441``);
+    the oracle uses the same LAPACK calls but BLAS dot products in the kernel matrix, the engine
+    multiplies by an explicit inverse factor and sums on the matrix cores: rounding differences of
+    the kernel entries (1e-16) come back multiplied by up to cond(K) in ``a = L^-1 k_x`` and in the
+    difference ``sigma^2 - |a|^2``.  Measured: <= 0.4 eps cond(K) for the oracle; the bound below
+    leaves a factor 20 and never exceeds the north star's 1e-5 (cond(K) <= 5e8 in the fixture)."""
+    return 1e-13 + 8 * 2.2e-16 * cond
+
+
+def reference_gp_model(ns, spec, case, fixture):
+    """The dynamics model of a fixture case from the function classes of ``ns`` (the ``oracle``
+    package or ``safe_learning_amd``): same training data, hyper-parameters, mean function, scale,
+    and the observations the fixture added with ``add_data_point``."""
+    import numpy as np
+    name, d, dyn = spec["name"], case["d"], case["dynamics"]
+    assert np.array_equal(dyn["X"], fixture[name + "/X"]) and np.array_equal(dyn["Y"], fixture[name + "/Y"])
+    assert dyn["noise_variance"] == float(fixture[name + "/noise_variance"])
+
+    def head(Y, prior, lengthscales):
+        kern = ns.RBF(d + 1, dyn["variance"], lengthscales, ARD=True)
+        mean = None if spec.get("zero_mean") else ns.LinearSystem((prior,))
+        gp = ns.GPRCached(dyn["X"], Y, kern, mean, scale=spec.get("scale", 1.0),
+                          likelihood_variance=dyn["noise_variance"])
+        return ns.GaussianProcess(gp, dyn["beta"])
+
+    if case["stack"]:
+        model = ns.FunctionStack([head(dyn["Y"][:, [k]], dyn["prior"][[k], :], dyn["lengthscales"][k])
+                                  for k in range(d)])
+    else:
+        model = head(dyn["Y"], dyn["prior"], dyn["lengthscales"])
+    if "add_points" in spec:
+        for x, y in zip(fixture[name + "/added_x"], fixture[name + "/added_y"]):
+            model.add_data_point(x[None, :], y[None, :])
+    return model

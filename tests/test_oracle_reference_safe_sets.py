@@ -5,11 +5,12 @@
 ``update_values`` / ``threshold`` / ``v_decrease_bound`` (``lyapunov.py:176-606``),
 ``get_safe_sample`` (``:609-797``) and ``smallest_boundary_value`` (``:22-56``) executed unmodified
 on the reference's own ``functions.py`` / ``examples/utilities.py`` objects (policy, dynamics, V,
-L_v; only a GP model is the oracle's callable - gpflow is absent), with ``tests/golden/numpy_tf.py``
-answering the TensorFlow ops they request.  Here every scenario (parameters stored in the fixture)
+L_v; a GP model is the reference's ``GaussianProcess(GPRCached)`` on ``tests/golden/numpy_gpflow.py``
+since round 4), with ``tests/golden/numpy_tf.py`` answering the TensorFlow ops they request.  Here every scenario (parameters stored in the fixture)
 is replayed on ``oracle.Lyapunov`` through the same step driver: safe set, ``c_max``, refinement
 array after every ``update_safe_set`` call, the sample and its bound after every
-``get_safe_sample`` call, the value table and the boundary minimum - bit for bit.
+``get_safe_sample`` call, the value table and the boundary minimum - bit for bit (the bound of a
+sample under GP dynamics, a posterior standard deviation, to 1e-10).
 """
 
 import importlib.util
@@ -87,6 +88,11 @@ def test_safe_sets_equal_the_reference_run(entry, batch_size):
             want = FIXTURE["%s/step%d/%s" % (name, k, key)]
             if rtol and key == "c_max":
                 assert_allclose(got, want, rtol=rtol)
+            elif key == "bound" and case["dynamics"]["kind"] == "gp":
+                # the confidence bound of the chosen sample is a GP posterior standard deviation:
+                # the reference's GPRCached ran here with left-to-right dot products, the oracle
+                # uses BLAS (tests/gp_cases.py::reference_gp_tolerance; cond(K) < 1e6 here)
+                assert_allclose(got, want, rtol=1e-10, atol=0)
             else:
                 assert_equal(got, want, err_msg="%s step %d %s" % (name, k, key))
 
