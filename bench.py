@@ -423,6 +423,13 @@ def run_rank(args, rank, world, local_rank, backend):
             out["end_to_end_ms"] = end_to_end_ms      # incl. bits->bytes and the bool[N] D2H
         out["roofline"] = roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world)
         out["roofline"]["kernel"] = obj._ctx.last_kernel()    # what the library launched (sl_last_kernel)
+        # a build whose code audit failed compiles the 4x4x4 kernels out with only a warning
+        # (safe_learning_amd/_build.py): the headline lines must not silently run on the fallbacks
+        expected = {"C4": "k_gp_sweep4", "C3": "k_gp_sweep4", "C5": "k_bellman4"}.get(args.config)
+        forced = any(os.environ.get(k) for k in ("SL_GP_CFG", "SL_BELLMAN4", "SL_BELLMAN_MFMA"))
+        if expected and not forced and not out["roofline"]["kernel"].startswith(expected):
+            raise SystemExit("bench.py: %s ran on %r instead of %s* (library built without its "
+                             "4x4x4 kernels?)" % (args.config, out["roofline"]["kernel"], expected))
         if world == 1 and not args.no_cpu_baseline and kind != "policy":
             # (the policy-evaluation line has no CPU leg of its own: C5's is the same oracle sweep)
             out["cpu_baseline"] = cpu_baseline(kind, case, min_cells=args.cpu_cells)

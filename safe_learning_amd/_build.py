@@ -78,9 +78,14 @@ def build(verbose=False, force=False, run_audits=True, lib=None, only=None):
     csrc = os.path.join(HERE, "csrc")
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip"))]
     deps.append(os.path.join(ROOT, "include", "sl_hip.h"))
-    if not force and not _newer(LIB, deps):
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # the flag set is part of what the library is: a change of SL_GP4_R / SL_EXTRA_FLAGS / HIPCC
+    # rebuilds like a source edit does (the stamp travels with the library)
+    stamp_path = LIB + ".flags"
+    stamp = "GP4_R=%d\nEXTRA=%s\nHIPCC=%s\n" % (GP4_R, os.environ.get("SL_EXTRA_FLAGS", ""), hipcc)
+    stamp_ok = os.path.exists(stamp_path) and open(stamp_path).read() == stamp
+    if not force and stamp_ok and not _newer(LIB, deps):
+        return LIB
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
              "-fvisibility=hidden",           # exports = the SL_API declarations of include/sl_hip.h
              "-I" + os.path.join(ROOT, "include"), "-I" + csrc]
@@ -148,6 +153,9 @@ def build(verbose=False, force=False, run_audits=True, lib=None, only=None):
         sys.stderr.write(res.stdout)
     if res.returncode != 0:
         raise RuntimeError("hipcc link failed (exit %d)" % res.returncode)
+    if only is None:
+        with open(stamp_path, "w") as handle:
+            handle.write(stamp)
     return LIB
 
 

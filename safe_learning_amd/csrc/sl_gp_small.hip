@@ -258,7 +258,24 @@ __global__ __launch_bounds__(64 * gps::WAVES) void k_gp_small(
 // =============================================================================================
 // host side
 // =============================================================================================
-// models the kernel takes: every head with a padded capacity of at most 256 training points
+// LDS doubles of a launch without the factor's lower triangle: per head the scaled inputs and
+// alpha', plus the per-wavefront scratch of the check
+static size_t small_lds_doubles(sl_ctx* ctx, int p, int d) {
+    size_t small = 0;
+    for (int k = 0; k < ctx->h_gp.nheads; ++k) {
+        const SlGpHeadHost& h = ctx->gp_heads[k];
+        small += (size_t)((p * h.n_pad + 1) & ~1) + (size_t)((h.n_pad * h.dout + 1) & ~1);
+    }
+    return small + (size_t)gps::WAVES * 64 * (p + 1 + 2 * d);
+}
+
+static size_t lds_capacity(bool general) {
+    return 160 * 1024 - (general ? sizeof(SlTriLds<true>) : 0) - 256;
+}
+
+// models the kernel takes: every head with a padded capacity of at most 256 training points, and
+// the heads' inputs / alpha' / the check's scratch fit LDS (a 6-D stack of six 256-point heads
+// does not: it stays on k_gp_sweep)
 bool sl_gp_small_supports(sl_ctx* ctx, const SlDevModel& model) {
     const char* env = getenv("SL_GP_SMALL");
     if (env && env[0] == '0') return false;
@@ -267,7 +284,8 @@ bool sl_gp_small_supports(sl_ctx* ctx, const SlDevModel& model) {
         const SlGpHeadHost& h = ctx->gp_heads[k];
         if (!h.set || h.n_pad > 256 || h.n_pad % 16 || h.p != model.in_dim) return false;
     }
-    return true;
+    return sizeof(double) * small_lds_doubles(ctx, model.in_dim, model.m.grid.d)
+           <= lds_capacity(sl_model_is_general(model));
 }
 
 template <bool GENERAL, int DT, int MT>
@@ -285,7 +303,7 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
         tri += (size_t)tri_offset(h.n_pad / 16) * 128;
     }
     const size_t scratch = (size_t)WAVES * 64 * (p + 1 + 2 * d);
-    const size_t cap = 160 * 1024 - (GENERAL ? sizeof(SlTriLds<true>) : 0) - 256;
+    const size_t cap = lds_capacity(GENERAL);
     const bool alds = sizeof(double) * (small + tri + scratch) <= cap;
     const int head_doubles = (int)(small + (alds ? tri : 0));
     const size_t lds = sizeof(double) * ((size_t)head_doubles + scratch);

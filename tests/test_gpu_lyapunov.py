@@ -861,3 +861,56 @@ def test_row_kernel_is_bit_identical(sl, name, kw, monkeypatch):
     assert_array_equal(lyap.safe_set, olyap.safe_set)
     assert_array_equal(ref.safe_set, olyap.safe_set)
     assert lyap.c_max == olyap.c_max == ref.c_max
+
+
+def test_six_dimensional_stack_of_six_heads_falls_back_to_the_wide_kernel(sl):
+    """A 6-D FunctionStack of six single-output GPs with 250 training points each (padded capacity
+    256, p = 7): the heads' inputs and alpha' (98 KB) plus the check's scratch (82 KB) exceed the
+    160 KB of LDS k_gp_small needs them in, so the sweep must take k_gp_sweep instead of failing
+    (advisor finding, round 3) - and agree with the oracle."""
+    d, n_gp = 6, 250
+    rng = np.random.default_rng(5)
+    limits, num_points = [[-1.0, 1.0]] * d, [4] * d
+    A = np.eye(d) * 0.9 + 0.02 * rng.normal(size=(d, d))
+    B = 0.1 * rng.normal(size=(d, 1))
+    K = -0.2 * rng.normal(size=(1, d))
+    P = np.eye(d)
+    X = rng.uniform(-1, 1, (n_gp, d + 1))
+    prior = np.hstack((A, B))
+    Y = X @ prior.T + 1e-3 * np.sin(3 * X[:, :d]) + rng.normal(0, 2e-4, (n_gp, d))
+    models = {}
+    for ns in (sl, oracle):
+        heads = []
+        for k in range(d):
+            kern = ns.RBF(d + 1, 1e-6, np.full(d + 1, 1.0 + 0.1 * k), ARD=True)
+            gp = ns.GPRCached(X, Y[:, [k]], kern, ns.LinearSystem((prior[[k], :],)),
+                              likelihood_variance=4e-8)
+            heads.append(ns.GaussianProcess(gp, 2.0))
+        models[ns] = ns.FunctionStack(heads)
+    init = np.zeros(4 ** d, dtype=bool)
+    lyaps = {}
+    for ns in (sl, oracle):
+        grid = ns.GridWorld(limits, num_points)
+        lv = ns.AbsFunction(ns.LinearSystem((2 * P,)))
+        lyaps[ns] = ns.Lyapunov(grid, ns.QuadraticFunction(P), models[ns], 1.0, lv, 0.0,
+                                ns.Saturation(ns.LinearSystem((K,)), -1.0, 1.0), initial_set=init)
+    lyap, olyap = lyaps[sl], lyaps[oracle]
+    values, neg, rec = _engine_records(lyap)
+    assert lyap._ctx.last_kernel().startswith("k_gp_sweep<"), lyap._ctx.last_kernel()
+    ref_rec, ref_neg = _oracle_all(olyap)
+    assert_array_equal(values, olyap.values)
+    assert_allclose(rec[:, 2:2 + d], ref_rec[:, 2:2 + d], rtol=RTOL_GP, atol=1e-12)
+    assert_allclose(rec[:, 2 + d:], ref_rec[:, 2 + d:], rtol=1e-7, atol=1e-12)
+    assert_allclose(rec[:, :2], ref_rec[:, :2], rtol=1e-7, atol=1e-12)
+    _check_masks(neg, ref_neg, rec, ref_rec)
+    # four heads (1 + 1 + 2 + 2 outputs) of the same size still fit: the small kernel keeps them
+    def head(cols):
+        return sl.GaussianProcess(sl.GPRCached(X, Y[:, cols], sl.RBF(d + 1, 1e-6, np.ones(d + 1), ARD=True),
+                                               sl.LinearSystem((prior[cols, :],)),
+                                               likelihood_variance=4e-8), 2.0)
+    stack4 = sl.FunctionStack([head([0]), head([1]), head([2, 3]), head([4, 5])])
+    lyap4 = sl.Lyapunov(sl.GridWorld(limits, num_points), sl.QuadraticFunction(P), stack4, 1.0,
+                        sl.AbsFunction(sl.LinearSystem((2 * P,))), 0.0,
+                        sl.Saturation(sl.LinearSystem((K,)), -1.0, 1.0), initial_set=init)
+    lyap4.update_safe_set()
+    assert lyap4._ctx.last_kernel().startswith("k_gp_small<"), lyap4._ctx.last_kernel()
