@@ -38,3 +38,17 @@ def golden():
     import json
     with open(os.path.join(GOLDEN_DIR, "reference_known_answers.json")) as f:
         return json.load(f)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """What the table-lookup parity tests excluded (tests/exclusions.py), kept with the GPU logs."""
+    import json
+    try:
+        import exclusions
+    except ImportError:
+        return
+    if exclusions.LOG:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_exclusions.json"), "w") as handle:
+            json.dump(exclusions.LOG, handle, indent=1)

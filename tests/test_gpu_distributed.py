@@ -15,6 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import cases
+import exclusions
 import oracle
 from conftest import ROOT
 
@@ -105,6 +106,8 @@ def _worker(rank, world, port, results, backend="gloo"):
     for a, action in enumerate(actions):
         nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))
         ok_q[:, a] = ~test_gpu_rl.ambiguous_points(ovf, nxt[0] if isinstance(nxt, tuple) else nxt)
+    if not exclusions.within("two ranks: discrete_policy_optimization", ok_q, "successor"):
+        failures.append(("rl", "exclusions", float(1 - ok_q.mean())))
     top2 = np.sort(oq, axis=1)[:, -2:]
     tie = np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1])
     best, obest = rl.policy._host_parameters()[:, 0], orl.policy.parameters[:, 0]
@@ -116,6 +119,8 @@ def _worker(rank, world, port, results, backend="gloo"):
         nxt = orl.dynamics(x, orl.policy(x))
         nxt = nxt[0] if isinstance(nxt, tuple) else nxt
         ok = ~test_gpu_rl.ambiguous_points(orl.policy, x) & ~test_gpu_rl.ambiguous_points(ovf, nxt)
+        if not exclusions.within("two ranks: value_iteration sweep %d" % sweep, ok, "own vertices"):
+            failures.append(("rl", "exclusions", float(1 - ok.mean())))
         res = rl.value_iteration()
         orl.value_iteration()
         if not np.allclose(vf._host_parameters()[ok], ovf.parameters[ok], rtol=1e-9, atol=1e-12):
@@ -134,6 +139,8 @@ def _worker(rank, world, port, results, backend="gloo"):
     for action in actions:
         nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))
         ok &= ~test_gpu_rl.ambiguous_points(ovf, nxt[0] if isinstance(nxt, tuple) else nxt)
+    if not exclusions.within("two ranks: 4x4x4 action values", ok, "successor"):
+        failures.append(("rl", "exclusions", float(1 - ok.mean())))
     if q.shape != oq.shape or not np.allclose(q[ok], oq[ok], rtol=1e-9, atol=1e-12):
         failures.append(("rl", "4x4x4 action values"))
     # ... and the policy-evaluation sweep with the greedy table (k_bellman4_policy: six live rows
@@ -142,6 +149,8 @@ def _worker(rank, world, port, results, backend="gloo"):
     vf.parameters = ovf.parameters.copy()
     nxt = orl.dynamics(x, orl.policy(x))
     ok = ~test_gpu_rl.ambiguous_points(orl.policy, x) & ~test_gpu_rl.ambiguous_points(ovf, nxt[0])
+    if not exclusions.within("two ranks: 4x4x4 policy evaluation", ok, "own vertices"):
+        failures.append(("rl", "exclusions", float(1 - ok.mean())))
     rl.value_iteration()
     orl.value_iteration()
     if "k_bellman4_policy" not in rl._ctx.last_kernel():

