@@ -427,6 +427,7 @@ def run_rank(args, rank, world, local_rank, backend):
         # (safe_learning_amd/_build.py): the headline lines must not silently run on the fallbacks
         expected = {"C4": "k_gp_sweep4", "C3": "k_gp_sweep4", "C5": "k_bellman4"}.get(args.config)
         forced = any(os.environ.get(k) for k in ("SL_GP_CFG", "SL_BELLMAN4", "SL_BELLMAN_MFMA"))
+        forced = forced or args.num_points or args.n_gp      # other shapes may pick other kernels
         if expected and not forced and not out["roofline"]["kernel"].startswith(expected):
             raise SystemExit("bench.py: %s ran on %r instead of %s* (library built without its "
                              "4x4x4 kernels?)" % (args.config, out["roofline"]["kernel"], expected))

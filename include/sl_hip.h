@@ -222,6 +222,55 @@ SL_API int  sl_lyap_finalize(sl_ctx* ctx, int64_t lo, int64_t hi, const double* 
 SL_API int  sl_select_pass(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values, int which,
                     int byte, uint64_t prefix, uint64_t vbits_equal, uint64_t* d_hist);
 
+/* ---- the same rule with every decision read from DEVICE memory (no host round trip between the
+ * passes of one update_safe_set; the multi-GPU path of SURVEY.md 8e) ------------------------------ */
+
+/* *out = 1 when d_values may be NULL in sl_lyap_sweep AND in the three passes below: V is a
+ * QuadraticFunction (functions.py:1503-1539) on a grid of 1..4 dimensions whose np.linspace points
+ * (functions.py:612-638, the points Lyapunov.update_values evaluates V on, lyapunov.py:321) equal
+ * index_to_state (functions.py:728-731) bit for bit.  The ordering keys of lyapunov.py:512 are then
+ * recomputed from the cell index (8 cells of a grid row per thread, the prefix of the ordered sums
+ * shared) instead of read: the values array (2.1 GB at 128^4) need not exist. */
+SL_API int  sl_values_implicit(sl_ctx* ctx, int* out);
+
+/* d_out = fold of `count` result records that lie in device memory (e.g. every rank's record after
+ * an all-gather): lexmin of `fail`, lexmax of `last_safe` and `max_key`, sums of the counters -
+ * the reductions np.argsort + the batch loop of lyapunov.py:512-595 perform on one host. */
+SL_API int  sl_fold_results(sl_ctx* ctx, const sl_sweep_result* d_records, int count,
+                     sl_sweep_result* d_out);
+
+/* sl_lyap_finalize with key_star = d_folded->fail and key_keep = *d_keep (NULL: none) read by the
+ * kernel.  d_values may be NULL (sl_values_implicit).  d_result: ->fail is copied from d_folded,
+ * the other fields are this range's statistics (fold them across ranks with sl_fold_results). */
+SL_API int  sl_lyap_finalize_dev(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values,
+                          const uint64_t* d_init_bits, const uint64_t* d_prev_bits,
+                          const sl_sweep_result* d_folded, const sl_key* d_keep,
+                          uint64_t* d_safe_bits, sl_sweep_result* d_result);
+
+/* Radix select of the k-th smallest (V, index) key over all ranks (0-based; what
+ * values[order[k]] of lyapunov.py:512, 590-595 reads) with its state in device memory. */
+typedef struct sl_select_state {
+    uint64_t prefix;        /* digits found so far (of vbits, then of the index)                 */
+    int64_t  remaining;     /* rank among the keys that share the prefix                         */
+    sl_key   key;           /* the result once both phases are through; KEY_NONE if none         */
+    int64_t  rank;          /* the k the select was started with                                 */
+    int64_t  none;          /* 1: k >= n_total (no such key), every pass is a no-op              */
+    int64_t  pad[2];
+} sl_select_state;          /* 64 bytes */
+
+/* k >= 0: select that rank.  k < 0: rank = (d_folded->count_below / batch + 1) * batch, the first
+ * position behind the batch that holds the first failure (lyapunov.py:585-587: later batches keep
+ * their previous state).  n_total = cells of the whole grid. */
+SL_API int  sl_select_begin(sl_ctx* ctx, sl_select_state* d_state, int64_t k, int64_t batch,
+                     const sl_sweep_result* d_folded, int64_t n_total);
+/* Histogram of one byte (7 = most significant first) of the keys of [lo,hi) that match the state's
+ * prefix: which = 0 the vbits, which = 1 the index among cells with vbits == state->key.vbits.
+ * d_hist[256] is zeroed and filled; SUM it over the ranks, then call sl_select_digit. */
+SL_API int  sl_select_hist(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values, int which,
+                    int byte, const sl_select_state* d_state, uint64_t* d_hist);
+SL_API int  sl_select_digit(sl_ctx* ctx, int which, int byte, const uint64_t* d_hist,
+                     sl_select_state* d_state);
+
 /* Bit mask <-> byte mask helpers for the bool[N] safe_set of the reference (lyapunov.py:187). */
 SL_API int  sl_bits_to_bytes(sl_ctx* ctx, int64_t n, const uint64_t* d_bits, uint8_t* d_bytes);
 SL_API int  sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uint64_t* d_bits);

@@ -63,24 +63,6 @@ int rccl_fail(sl_ctx* ctx, const char* what, int rc) {
                    g_rccl.error_string ? g_rccl.error_string(rc) : "RCCL error");
 }
 
-// records[world] -> out: the reductions of lyapunov.py:512-606 over the shards
-__global__ void k_fold_records(const sl_sweep_result* __restrict__ records, int world,
-                               sl_sweep_result* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    sl_sweep_result r = records[0];
-    for (int k = 1; k < world; ++k) {
-        const sl_sweep_result o = records[k];
-        if (sl_key_less(o.fail.vbits, o.fail.index, r.fail.vbits, r.fail.index)) r.fail = o.fail;
-        if (sl_key_less(r.last_safe.vbits, r.last_safe.index, o.last_safe.vbits, o.last_safe.index))
-            r.last_safe = o.last_safe;
-        if (sl_key_less(r.max_key.vbits, r.max_key.index, o.max_key.vbits, o.max_key.index))
-            r.max_key = o.max_key;
-        r.count_below += o.count_below;
-        r.count_safe += o.count_safe;
-    }
-    *out = r;
-}
-
 }  // namespace
 
 extern "C" int sl_comm_unique_id(unsigned char* id_out) {
@@ -140,11 +122,8 @@ extern "C" int sl_allreduce_result(sl_ctx* ctx, sl_sweep_result* d_result) {
     rc = g_rccl.all_gather(d_result, ctx->d_comm_records, sizeof(sl_sweep_result), RCCL_UINT8,
                            static_cast<rccl_comm>(ctx->comm), ctx->stream);
     if (rc) return rccl_fail(ctx, "ncclAllGather", rc);
-    hipLaunchKernelGGL(k_fold_records, dim3(1), dim3(64), 0, ctx->stream,
-                       static_cast<const sl_sweep_result*>(ctx->d_comm_records), ctx->comm_world,
-                       d_result);
-    SL_HIP_CHECK(ctx, hipGetLastError());
-    return SL_OK;
+    return sl_fold_results(ctx, static_cast<const sl_sweep_result*>(ctx->d_comm_records),
+                           ctx->comm_world, d_result);
 }
 
 extern "C" int sl_allgather(sl_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes_per_rank) {

@@ -10,12 +10,15 @@ out of the comparison.  Two categories, measured on the oracle side (tools/exclu
 * ``successor`` - the value table read at successor states ``f(x, u)``, inside the grid or
   projected onto its boundary faces (``project=True``): measured 0 of 1e5 points in every test
   shape, 8 ... 87 % of them ON a boundary face.  Projected successors are therefore COMPARED, not
-  excluded; the bound is 2 %.
+  excluded; the bound is 2 %.  On the GPU suite (profiles/r04_parity_exclusions.json, 171 logged
+  comparisons): at most 0.23 %; the C5 sweep at 64^4 compares 2503 sampled vertices x 9 actions
+  with NONE excluded, 61 % of them having a successor on a boundary face.
 * ``own vertices`` - a piecewise-constant (greedy) policy table evaluated at its own vertices
   (``reinforcement_learning.py:98``: ``policy(states)`` at the grid points): every query sits on
   grid lines in all dimensions, the ``%`` wraps it into a corner of the unit cell shared by several
   simplices, and a noisy table makes them disagree: 19 ... 36 % of the vertices of the small random
-  test tables, 0 % for smooth tables.  Bound 45 % on the small random tables, 25 % at full size.
+  test tables (41 % on the 13 x 13 table of a reference-run scenario), 0 % for smooth tables, 2.0 %
+  for the greedy policy of C5 at 64^4.  Bound 45 % on the small random tables, 5 % at full size.
 
 Every call is logged; ``conftest.py`` writes the log to ``gpurun_out/parity_exclusions.json`` at
 the end of a GPU session.  ``SL_EXCLUSION_SOFT=1`` logs without asserting (to survey the rates).
@@ -26,7 +29,7 @@ import os
 import numpy as np
 
 LOG = []
-LIMITS = {"successor": 0.02, "own vertices": 0.45, "own vertices, full size": 0.25}
+LIMITS = {"successor": 0.02, "own vertices": 0.45, "own vertices, full size": 0.05}
 
 
 def on_boundary_face(tri, points):

@@ -394,7 +394,7 @@ def test_table_lyapunov_function(sl, lv_kind):
     ok = ~on_face
     import exclusions
     # the table's GRADIENT (L_v at the successor) is what is ambiguous on a face, not its value
-    exclusions.report("test_table_lyapunov_function[%s]" % lv_kind, ok, "successor", limit=0.5)
+    exclusions.report("test_table_lyapunov_function[%s]" % lv_kind, ok, "successor", limit=0.10)   # measured 4.1 %
     assert ok.sum() > 50
     assert_allclose(values, olyap.values, rtol=1e-12, atol=1e-14)
     assert np.all(rec[:, 1] == 0.0) and np.all(ref_rec[:, 1] == 0.0)
