@@ -74,7 +74,7 @@ def _audit_bellman4(objdir, verbose):
 def build(verbose=False, force=False, run_audits=True, lib=None, only=None):
     """``run_audits=False`` / ``lib=...`` / ``only=[stems]``: development builds only (instrumented
     kernels whose listing the audits do not describe, written next to the shipped library; the
-    units not named in ``only`` are taken from the shipped build) - see tools/build_dev.py."""
+    units not named in ``only`` are taken from the shipped build) - see tools/build_variant.sh."""
     LIB = lib or globals()["LIB"]
     csrc = os.path.join(HERE, "csrc")
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip"))]

@@ -186,7 +186,7 @@ def audit_in_place(path, prefix=r"_Z1[017]k_bellman4(?:s|_policy)?I"):
                         if regs_of(prev.split(None, 1)[1].split(", ")[0]) & sources:
                             close.append("%s -> %s" % (prev, c))
                     slots += 1
-            # Direct global -> LDS loads (development build -DSL_B4S_DMA) are inline asm too: the
+            # Direct global -> LDS loads (k_bellman4s' chunk copy) are inline asm too: the
             # compiler neither counts them nor waits for them.  In front of the loop's barrier there
             # has to be an s_waitcnt vmcnt(N) with N <= the number of loads issued behind the last
             # such copy (walking backwards from the barrier, around the loop's layout).
