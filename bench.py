@@ -310,6 +310,7 @@ def run_rank(args, rank, world, local_rank, backend):
         step()
     barrier()
     obj.sweep_events = []                         # HIP events around the dominant kernel
+    obj.finalize_events = []                      # ... and around the streaming pass (k_finalize_dev)
     dist_utils.start_timing()                     # device events around every collective
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -319,7 +320,9 @@ def run_rank(args, rank, world, local_rank, backend):
     elapsed = time.perf_counter() - t0
     collective_ms = dist_utils.stop_timing() / max(args.steps, 1)
     kernel_ms = [a.elapsed_time(b) for a, b in obj.sweep_events]
+    finalize_ms = [a.elapsed_time(b) for a, b in (getattr(obj, "finalize_events", None) or [])]
     obj.sweep_events = None
+    obj.finalize_events = None
     avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     per_rank = [elapsed, avg_ms, collective_ms, 1e3 * own_elapsed / max(args.steps, 1)]
     if grouped:
@@ -422,6 +425,15 @@ def run_rank(args, rank, world, local_rank, backend):
         if end_to_end_ms is not None:
             out["end_to_end_ms"] = end_to_end_ms      # incl. bits->bytes and the bool[N] D2H
         out["roofline"] = roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world)
+        if finalize_ms:
+            fin = float(np.mean(finalize_ms)) * len(finalize_ms) / max(args.steps, 1)   # per step
+            out["roofline"]["finalize_ms"] = fin
+            out["roofline"]["step_kernels_ms"] = avg_ms + fin
+            if out["roofline"]["bound"] == "hbm":
+                out["roofline"]["step_achieved"] = (out["roofline"]["bytes_per_check"] * cells_per_launch
+                                                    / ((avg_ms + fin) * 1e-3) / 1e9)
+                out["roofline"]["step_frac"] = out["roofline"]["step_achieved"] / HBM_PEAK_GBPS
+                out["roofline"]["values_implicit"] = bool(getattr(obj, "_values_implicit", False))
         out["roofline"]["kernel"] = obj._ctx.last_kernel()    # what the library launched (sl_last_kernel)
         # a build whose code audit failed compiles the 4x4x4 kernels out with only a warning
         # (safe_learning_amd/_build.py): the headline lines must not silently run on the fallbacks

@@ -226,7 +226,8 @@ SL_API int  sl_select_pass(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_
  * passes of one update_safe_set; the multi-GPU path of SURVEY.md 8e) ------------------------------ */
 
 /* *out = 1 when d_values may be NULL in sl_lyap_sweep AND in the three passes below: V is a
- * QuadraticFunction (functions.py:1503-1539) on a grid of 1..4 dimensions whose np.linspace points
+ * QuadraticFunction (functions.py:1503-1539) on a grid of 1..4 dimensions (last axis a multiple of 8
+ * cells) whose np.linspace points
  * (functions.py:612-638, the points Lyapunov.update_values evaluates V on, lyapunov.py:321) equal
  * index_to_state (functions.py:728-731) bit for bit.  The ordering keys of lyapunov.py:512 are then
  * recomputed from the cell index (8 cells of a grid row per thread, the prefix of the ordered sums
@@ -270,6 +271,89 @@ SL_API int  sl_select_hist(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_
                     int byte, const sl_select_state* d_state, uint64_t* d_hist);
 SL_API int  sl_select_digit(sl_ctx* ctx, int which, int byte, const uint64_t* d_hist,
                      sl_select_state* d_state);
+
+/* ---- the adaptive branch of update_safe_set (lyapunov.py:445-487, 540-582) -------------------------
+ * The reference walks the cells in ascending-V order in batches of config.gp_batch_size; a batch whose
+ * unsafe tail can be accepted through local refinement lets the loop go on, the first one that
+ * cannot ends it.  Every batch is judged on its own from per-cell rows in sorted order. */
+
+/* Stable ascending sort of n (key, value) pairs by key: eight 8-bit radix passes (np.argsort of
+ * lyapunov.py:512 with ties in input order).  Result in d_keys / d_vals; d_keys_tmp / d_vals_tmp [n]
+ * and d_counts [SL_SORT_COUNT_WORDS] are scratch. */
+#define SL_SORT_COUNT_WORDS (256 * 2048)
+SL_API int  sl_sort_pairs(sl_ctx* ctx, int64_t n, uint64_t* d_keys, int64_t* d_vals,
+                   uint64_t* d_keys_tmp, int64_t* d_vals_tmp, uint32_t* d_counts);
+/* Stable partition: d_perm = the positions 0..n-1 ordered by d_digits[position] (positions with
+ * equal digits keep their order); d_bucket_counts[256] = elements per digit. */
+SL_API int  sl_partition_by_digit(sl_ctx* ctx, int64_t n, const uint8_t* d_digits, int64_t* d_perm,
+                           int64_t* d_bucket_counts, uint32_t* d_counts);
+/* d_rows_out[r] = d_rows_in[d_perm[r]] for rows of `words` 8-byte words. */
+SL_API int  sl_gather_rows(sl_ctx* ctx, int64_t count, int words, const int64_t* d_perm,
+                    const int64_t* d_rows_in, int64_t* d_rows_out);
+
+/* One row of SL_ADAPTIVE_ROW_WORDS words per cell of [lo,hi): vbits(V), flat index, decrease and
+ * threshold(x, tau = 1) = -|L_v(x)|_1 (1 + L_f(x)) from the records of a sweep run with tau = 1
+ * (d_records: [hi-lo][record_stride], columns 0 and 1), the refinement N(x) and the flags the loop
+ * starts from: d_prior_bits = NULL (can_shrink: the initial set, lyapunov.py:498-505) or the
+ * previous safe set with d_prior_ref = the previous refinement (NULL: 1 on safe cells) (:506-510). */
+#define SL_ADAPTIVE_ROW_WORDS 6
+SL_API int  sl_adaptive_pack(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values,
+                      const double* d_records, int record_stride, const uint64_t* d_init_bits,
+                      const uint64_t* d_prior_bits, const int64_t* d_prior_ref, int64_t* d_rows);
+/* d_dest[i] = number of splitter keys (d_splitters[s].key, from sl_select_*) <= row i's key: the rank
+ * that owns the row's position in the sorted order. */
+SL_API int  sl_adaptive_dest(sl_ctx* ctx, int64_t count, const int64_t* d_rows,
+                      const sl_select_state* d_splitters, int nsplit, uint8_t* d_dest);
+/* keys[i] = vbits of row i, vals[i] = i: the input of sl_sort_pairs. */
+SL_API int  sl_adaptive_sort_keys(sl_ctx* ctx, int64_t m, const int64_t* d_rows, uint64_t* d_keys,
+                           int64_t* d_vals);
+/* Judge the batches of the m rows at sorted positions [pos0, pos0 + m) (pos0 a multiple of batch;
+ * d_order[q] = row of position pos0 + q): d_info[b] = {passes, bound, stop, refine_bound} as in
+ * lyapunov.py:537-582, *d_first_break = smallest global batch index that ends the loop (INT64_MAX:
+ * none; MIN it over the ranks). */
+SL_API int  sl_adaptive_analyse(sl_ctx* ctx, int64_t m, int64_t pos0, int64_t batch,
+                         const int64_t* d_rows, const int64_t* d_order, double tau,
+                         double safety_factor, int64_t max_refinement, int32_t* d_info,
+                         int64_t* d_first_break);
+/* d_out_rows[row] = {flat index, safe, refinement} after the loop ended in batch b_star. */
+SL_API int  sl_adaptive_apply(sl_ctx* ctx, int64_t m, int64_t pos0, int64_t batch,
+                       const int64_t* d_rows, const int64_t* d_order, const int32_t* d_info,
+                       double tau, double safety_factor, int64_t b_star, int64_t* d_out_rows);
+/* {index, safe, refinement} rows of cells of [lo,hi) -> this range's mask words and refinement
+ * array; the initial set is kept (lyapunov.py:601-606); *d_safe_count = bits set. */
+SL_API int  sl_adaptive_scatter(sl_ctx* ctx, int64_t lo, int64_t hi, int64_t m,
+                         const int64_t* d_out_rows, const uint64_t* d_init_bits,
+                         uint64_t* d_safe_bits, int64_t* d_refinement, int64_t* d_safe_count);
+
+/* ---- get_safe_sample / perturb_actions (lyapunov.py:609-797): the glue between the safe set and
+ * the point evaluations (sl_eval_points) ------------------------------------------------------------ */
+/* d_states[i] = index_to_state(d_indices[i]) on the model's grid (functions.py:714-731). */
+SL_API int  sl_index_to_state(sl_ctx* ctx, int64_t count, const int64_t* d_indices, double* d_states);
+/* Row i*nperturb + k = [state_i, clip(action_i + perturbation_k, limits)] (lyapunov.py:634-647);
+ * d_limits [m][2] may be NULL (no clipping). */
+SL_API int  sl_perturb_pairs(sl_ctx* ctx, int64_t count, int d, int m, const double* d_states,
+                      const double* d_actions, int nperturb, const double* d_perturbations,
+                      const double* d_limits, double* d_pairs);
+/* utilities.unique_rows (:496-516) orders rows by memcmp of their raw bytes: d_keys[q] = byte-swapped
+ * word `column` of row d_order[q] (NULL: q) - sort by it with sl_sort_pairs, last column first. */
+SL_API int  sl_rows_sort_key(sl_ctx* ctx, int64_t count, int words, int column, const int64_t* d_rows,
+                      const int64_t* d_order, uint64_t* d_keys);
+/* d_flags[q] = 1 when row d_order[q] equals row d_order[q-1] bit for bit (drop it). */
+SL_API int  sl_rows_duplicate_flags(sl_ctx* ctx, int64_t count, int words, const int64_t* d_rows,
+                             const int64_t* d_order, uint8_t* d_flags);
+/* bound_i = sum_j std_ij and inside_i = V(mean_i) + sum_j L_v(mean_i)_j std_ij < c_max
+ * (lyapunov.py:716-726); lv_cols = 1 or d. */
+SL_API int  sl_sample_bounds(sl_ctx* ctx, int64_t count, int d, int lv_cols, const double* d_std,
+                      const double* d_lv, const double* d_value, double c_max, double* d_bound,
+                      uint8_t* d_inside);
+/* d_inout[i] &= safe_set[state_to_index(point_i)] (lyapunov.py:762-766, functions.py:733-752);
+ * d_safe_bits = the mask words of the WHOLE grid. */
+SL_API int  sl_state_membership(sl_ctx* ctx, int64_t count, const double* d_points,
+                         const uint64_t* d_safe_bits, uint8_t* d_inout);
+/* d_out[0] = first index of the largest d_values[i] among rows with d_mask[i] != 0 (NULL: all), NaN
+ * counting as largest (np.argmax, lyapunov.py:783, 789), -1 if there is none; d_out[1] = rows seen. */
+SL_API int  sl_argmax_masked(sl_ctx* ctx, int64_t count, const double* d_values, const uint8_t* d_mask,
+                      int64_t* d_out);
 
 /* Bit mask <-> byte mask helpers for the bool[N] safe_set of the reference (lyapunov.py:187). */
 SL_API int  sl_bits_to_bytes(sl_ctx* ctx, int64_t n, const uint64_t* d_bits, uint8_t* d_bytes);

@@ -24,7 +24,8 @@ UNITS = [("sl_kernels", "sl_kernels.hip", []), ("sl_gp", "sl_gp.hip", []),
          ("sl_bellman", "sl_bellman.hip", []), ("sl_bellman4", "sl_bellman4.hip", ["-save-temps=obj"]),
          ("sl_nn", "sl_nn.hip", []), ("sl_comm", "sl_comm.hip", []),
          ("sl_gp_small", "sl_gp_small.hip", []), ("sl_det_rows", "sl_det_rows.hip", []),
-         ("sl_level", "sl_level.hip", [])]
+         ("sl_level", "sl_level.hip", []), ("sl_adaptive", "sl_adaptive.hip", []),
+         ("sl_sample", "sl_sample.hip", [])]
 UNITS += [("sl_gp4_d%d" % dim, "sl_gp4.hip", GP4_FLAGS + ["-DSL_GP4_DIM=%d" % dim]) for dim in (1, 2, 3, 4)]
 LIB = os.path.join(HERE, "libslhip.so")
 

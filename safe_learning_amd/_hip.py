@@ -83,12 +83,23 @@ class Key(C.Structure):
 # sl_sweep_result as int64 words (a torch int64[8] tensor backs it on the device)
 RESULT_WORDS = 8
 R_FAIL_V, R_FAIL_I, R_LAST_V, R_LAST_I, R_MAX_V, R_MAX_I, R_BELOW, R_SAFE = range(8)
+SORT_COUNT_WORDS = 256 * 2048          # uint32 scratch of sl_sort_pairs / sl_partition_by_digit
+ADAPTIVE_ROW_WORDS = 6                 # vbits, index, decrease, threshold(tau = 1), refinement, flags
+# sl_select_state as int64 words: prefix, remaining, key.vbits, key.index, rank, none, pad, pad
+SELECT_WORDS = 8
+S_PREFIX, S_REMAINING, S_KEY_V, S_KEY_I, S_RANK, S_NONE = range(6)
 
 EXPORTS = [
     "sl_version", "sl_ctx_create", "sl_ctx_destroy", "sl_last_error", "sl_ctx_synchronize",
     "sl_last_kernel",
     "sl_model_set", "sl_gp_set_head", "sl_gp_append_point", "sl_gp_configure", "sl_tri_set", "sl_tri_set_table",
     "sl_network_set", "sl_values", "sl_lyap_sweep", "sl_lyap_finalize", "sl_select_pass",
+    "sl_values_implicit", "sl_fold_results", "sl_lyap_finalize_dev", "sl_select_begin",
+    "sl_select_hist", "sl_select_digit",
+    "sl_sort_pairs", "sl_partition_by_digit", "sl_gather_rows", "sl_adaptive_pack", "sl_adaptive_dest",
+    "sl_adaptive_sort_keys", "sl_adaptive_analyse", "sl_adaptive_apply", "sl_adaptive_scatter",
+    "sl_index_to_state", "sl_perturb_pairs", "sl_rows_sort_key", "sl_rows_duplicate_flags",
+    "sl_sample_bounds", "sl_state_membership", "sl_argmax_masked",
     "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_eval_points",
     "sl_comm_unique_id", "sl_comm_init", "sl_comm_destroy", "sl_allreduce_result", "sl_allgather",
     "sl_allreduce_sum_u64", "sl_allreduce_max_f64",
@@ -139,6 +150,31 @@ def load_library():
                                      C.c_void_p, Key, Key, C.c_void_p, C.c_void_p]
     lib.sl_select_pass.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                    C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.sl_values_implicit.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.sl_fold_results.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.sl_lyap_finalize_dev.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sl_select_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
+    lib.sl_select_hist.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p]
+    lib.sl_select_digit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    vp, i64 = C.c_void_p, C.c_int64
+    lib.sl_sort_pairs.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    lib.sl_partition_by_digit.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.sl_gather_rows.argtypes = [vp, i64, C.c_int, vp, vp, vp]
+    lib.sl_adaptive_pack.argtypes = [vp, i64, i64, vp, vp, C.c_int, vp, vp, vp, vp]
+    lib.sl_adaptive_dest.argtypes = [vp, i64, vp, vp, C.c_int, vp]
+    lib.sl_adaptive_sort_keys.argtypes = [vp, i64, vp, vp, vp]
+    lib.sl_adaptive_analyse.argtypes = [vp, i64, i64, i64, vp, vp, C.c_double, C.c_double, i64, vp, vp]
+    lib.sl_adaptive_apply.argtypes = [vp, i64, i64, i64, vp, vp, vp, C.c_double, C.c_double, i64, vp]
+    lib.sl_adaptive_scatter.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp]
+    lib.sl_index_to_state.argtypes = [vp, i64, vp, vp]
+    lib.sl_perturb_pairs.argtypes = [vp, i64, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]
+    lib.sl_rows_sort_key.argtypes = [vp, i64, C.c_int, C.c_int, vp, vp, vp]
+    lib.sl_rows_duplicate_flags.argtypes = [vp, i64, C.c_int, vp, vp, vp]
+    lib.sl_sample_bounds.argtypes = [vp, i64, C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp]
+    lib.sl_state_membership.argtypes = [vp, i64, vp, vp, vp]
+    lib.sl_argmax_masked.argtypes = [vp, i64, vp, vp, vp]
     lib.sl_bits_to_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sl_bytes_to_bits.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sl_bellman_sweep.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, c_double_p,
@@ -291,6 +327,116 @@ class Context(object):
         self.check(self.lib.sl_select_pass(self.handle, lo, hi, _ptr(d_values), which, byte,
                                            C.c_uint64(prefix), C.c_uint64(vbits_equal),
                                            _ptr(d_hist)), "sl_select_pass")
+
+    # ---- the same passes with every decision read from device memory (sl_level.hip) -------
+    def values_implicit(self):
+        """True when ``d_values=None`` is allowed: quadratic V whose ordering keys the passes
+        recompute from the cell index (``sl_values_implicit``)."""
+        out = C.c_int(0)
+        self.check(self.lib.sl_values_implicit(self.handle, C.byref(out)), "sl_values_implicit")
+        return bool(out.value)
+
+    def fold_results(self, d_records, count, d_out):
+        self.check(self.lib.sl_fold_results(self.handle, _ptr(d_records), count, _ptr(d_out)),
+                   "sl_fold_results")
+
+    def lyap_finalize_dev(self, lo, hi, d_values, d_init_bits, d_prev_bits, d_folded, d_keep,
+                          d_safe_bits, d_result):
+        self.check(self.lib.sl_lyap_finalize_dev(self.handle, lo, hi, _ptr(d_values),
+                                                 _ptr(d_init_bits), _ptr(d_prev_bits), _ptr(d_folded),
+                                                 _ptr(d_keep), _ptr(d_safe_bits), _ptr(d_result)),
+                   "sl_lyap_finalize_dev")
+
+    def select_begin(self, d_state, k, batch, d_folded, n_total):
+        self.check(self.lib.sl_select_begin(self.handle, _ptr(d_state), k, batch, _ptr(d_folded),
+                                            n_total), "sl_select_begin")
+
+    def select_hist(self, lo, hi, d_values, which, byte, d_state, d_hist):
+        self.check(self.lib.sl_select_hist(self.handle, lo, hi, _ptr(d_values), which, byte,
+                                           _ptr(d_state), _ptr(d_hist)), "sl_select_hist")
+
+    def select_digit(self, which, byte, d_hist, d_state):
+        self.check(self.lib.sl_select_digit(self.handle, which, byte, _ptr(d_hist), _ptr(d_state)),
+                   "sl_select_digit")
+
+    # ---- sort / partition / the adaptive branch (sl_adaptive.hip) --------------------------
+    def sort_pairs(self, n, d_keys, d_vals, d_keys_tmp, d_vals_tmp, d_counts):
+        self.check(self.lib.sl_sort_pairs(self.handle, n, _ptr(d_keys), _ptr(d_vals), _ptr(d_keys_tmp),
+                                          _ptr(d_vals_tmp), _ptr(d_counts)), "sl_sort_pairs")
+
+    def partition_by_digit(self, n, d_digits, d_perm, d_bucket_counts, d_counts):
+        self.check(self.lib.sl_partition_by_digit(self.handle, n, _ptr(d_digits), _ptr(d_perm),
+                                                  _ptr(d_bucket_counts), _ptr(d_counts)),
+                   "sl_partition_by_digit")
+
+    def gather_rows(self, count, words, d_perm, d_rows_in, d_rows_out):
+        self.check(self.lib.sl_gather_rows(self.handle, count, words, _ptr(d_perm), _ptr(d_rows_in),
+                                           _ptr(d_rows_out)), "sl_gather_rows")
+
+    def adaptive_pack(self, lo, hi, d_values, d_records, stride, d_init_bits, d_prior_bits,
+                      d_prior_ref, d_rows):
+        self.check(self.lib.sl_adaptive_pack(self.handle, lo, hi, _ptr(d_values), _ptr(d_records), stride,
+                                             _ptr(d_init_bits), _ptr(d_prior_bits), _ptr(d_prior_ref),
+                                             _ptr(d_rows)), "sl_adaptive_pack")
+
+    def adaptive_dest(self, count, d_rows, d_splitters, nsplit, d_dest):
+        self.check(self.lib.sl_adaptive_dest(self.handle, count, _ptr(d_rows), _ptr(d_splitters), nsplit,
+                                             _ptr(d_dest)), "sl_adaptive_dest")
+
+    def adaptive_sort_keys(self, m, d_rows, d_keys, d_vals):
+        self.check(self.lib.sl_adaptive_sort_keys(self.handle, m, _ptr(d_rows), _ptr(d_keys),
+                                                  _ptr(d_vals)), "sl_adaptive_sort_keys")
+
+    def adaptive_analyse(self, m, pos0, batch, d_rows, d_order, tau, safety_factor, max_refinement,
+                         d_info, d_first_break):
+        self.check(self.lib.sl_adaptive_analyse(self.handle, m, pos0, batch, _ptr(d_rows), _ptr(d_order),
+                                                float(tau), float(safety_factor), int(max_refinement),
+                                                _ptr(d_info), _ptr(d_first_break)), "sl_adaptive_analyse")
+
+    def adaptive_apply(self, m, pos0, batch, d_rows, d_order, d_info, tau, safety_factor, b_star,
+                       d_out_rows):
+        self.check(self.lib.sl_adaptive_apply(self.handle, m, pos0, batch, _ptr(d_rows), _ptr(d_order),
+                                              _ptr(d_info), float(tau), float(safety_factor), int(b_star),
+                                              _ptr(d_out_rows)), "sl_adaptive_apply")
+
+    def adaptive_scatter(self, lo, hi, m, d_out_rows, d_init_bits, d_safe_bits, d_refinement,
+                         d_safe_count):
+        self.check(self.lib.sl_adaptive_scatter(self.handle, lo, hi, m, _ptr(d_out_rows),
+                                                _ptr(d_init_bits), _ptr(d_safe_bits), _ptr(d_refinement),
+                                                _ptr(d_safe_count)), "sl_adaptive_scatter")
+
+    # ---- get_safe_sample glue (sl_sample.hip) ----------------------------------------------
+    def index_to_state(self, count, d_indices, d_states):
+        self.check(self.lib.sl_index_to_state(self.handle, count, _ptr(d_indices), _ptr(d_states)),
+                   "sl_index_to_state")
+
+    def perturb_pairs(self, count, d, m, d_states, d_actions, nperturb, d_perturbations, d_limits,
+                      d_pairs):
+        self.check(self.lib.sl_perturb_pairs(self.handle, count, d, m, _ptr(d_states), _ptr(d_actions),
+                                             nperturb, _ptr(d_perturbations), _ptr(d_limits),
+                                             _ptr(d_pairs)), "sl_perturb_pairs")
+
+    def rows_sort_key(self, count, words, column, d_rows, d_order, d_keys):
+        self.check(self.lib.sl_rows_sort_key(self.handle, count, words, column, _ptr(d_rows),
+                                             _ptr(d_order), _ptr(d_keys)), "sl_rows_sort_key")
+
+    def rows_duplicate_flags(self, count, words, d_rows, d_order, d_flags):
+        self.check(self.lib.sl_rows_duplicate_flags(self.handle, count, words, _ptr(d_rows),
+                                                    _ptr(d_order), _ptr(d_flags)),
+                   "sl_rows_duplicate_flags")
+
+    def sample_bounds(self, count, d, lv_cols, d_std, d_lv, d_value, c_max, d_bound, d_inside):
+        self.check(self.lib.sl_sample_bounds(self.handle, count, d, lv_cols, _ptr(d_std), _ptr(d_lv),
+                                             _ptr(d_value), float(c_max), _ptr(d_bound),
+                                             _ptr(d_inside)), "sl_sample_bounds")
+
+    def state_membership(self, count, d_points, d_safe_bits, d_inout):
+        self.check(self.lib.sl_state_membership(self.handle, count, _ptr(d_points), _ptr(d_safe_bits),
+                                                _ptr(d_inout)), "sl_state_membership")
+
+    def argmax_masked(self, count, d_values, d_mask, d_out):
+        self.check(self.lib.sl_argmax_masked(self.handle, count, _ptr(d_values), _ptr(d_mask),
+                                             _ptr(d_out)), "sl_argmax_masked")
 
     def bits_to_bytes(self, n, d_bits, d_bytes):
         self.check(self.lib.sl_bits_to_bytes(self.handle, n, _ptr(d_bits), _ptr(d_bytes)),

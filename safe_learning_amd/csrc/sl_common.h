@@ -340,6 +340,14 @@ __device__ __forceinline__ SlCellCheck sl_cell_check(const SlDevModel& M, int d,
     return r;
 }
 
+// blocks of SL_BLOCK threads that walk `ncells` items with a grid stride
+static inline int sl_grid_blocks(int64_t ncells) {
+    int64_t b = (ncells + SL_BLOCK - 1) / SL_BLOCK;
+    if (b > SL_MAX_GRID) b = SL_MAX_GRID;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
 // kernel-variant id of a model: 0 = generic, 1..4 = (d, 1)
 static inline int sl_dim_variant_of(const SlDevModel& M) {
     if (M.m.policy.m == 1 && M.m.grid.d >= 1 && M.m.grid.d <= 4) return M.m.grid.d;

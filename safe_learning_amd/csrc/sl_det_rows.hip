@@ -115,10 +115,11 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_rows(
         const double one_plus_lf = 1.0 + lip.lf_const;                               // lyapunov.py:287
 
         // ---- the 8 cells -----------------------------------------------------------------------
+        const int last0 = (int)ijk[L];
         unsigned neg8 = 0u;
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            const double tl = (double)(ijk[L] + c) * M.m.grid.unit_maxes[L];
+            const double tl = (double)(last0 + c) * M.m.grid.unit_maxes[L];       // v_cvt_f64_i32
             const double xl = tl + M.m.grid.offset[L];
             x[L] = xl;
             // policy: u = (prefix) + x_L K_L, saturated                              functions.py:349-354
@@ -171,7 +172,12 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_rows(
             const bool negative = (decrease < threshold) && valid;
             neg8 |= negative ? (1u << c) : 0u;
             const bool ok = negative || ((init8 >> c) & 1u);
-            if (valid && !ok) sl_key_min(best_v, best_i, sl_vbits(values ? v8[c] : vx), i0 + c);
+            // cells are visited in ascending index order (inside a thread and from one iteration
+            // to the next): a strict "<" on the value bits keeps the lexicographic minimum
+            if (valid && !ok) {
+                const uint64_t vb = sl_vbits(values ? v8[c] : vx);
+                if (vb < best_v || best_i == INT64_MAX) { best_v = vb; best_i = i0 + c; }   // (a NaN key is all ones)
+            }
         }
         neg_bytes[(i0 - lo) >> 3] = (uint8_t)neg8;
     }

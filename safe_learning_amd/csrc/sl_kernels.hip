@@ -322,13 +322,6 @@ static int sl_check_ready(sl_ctx* ctx, const char* who) {
     return SL_OK;
 }
 
-static inline int sl_grid_blocks(int64_t ncells) {
-    int64_t b = (ncells + SL_BLOCK - 1) / SL_BLOCK;
-    if (b > SL_MAX_GRID) b = SL_MAX_GRID;
-    if (b < 1) b = 1;
-    return (int)b;
-}
-
 // =============================================================================================
 // kernel-variant dispatch: fixed (state, action) dimensions fold every per-dimension predicate
 // =============================================================================================

@@ -31,7 +31,7 @@ struct RowValues {
     int64_t ijk[SL_D];
 
     __device__ __forceinline__ void point(const SlDevModel& M, int k) {
-        const double t = (double)ijk[k] * M.m.grid.unit_maxes[k];                    // functions.py:731
+        const double t = (double)(int)ijk[k] * M.m.grid.unit_maxes[k];               // functions.py:731
         const double s = t + M.m.grid.offset[k];
         x[k] = (ijk[k] == M.m.grid.num_points[k] - 1) ? M.m.grid.upper[k] : s;       // np.linspace
     }
@@ -64,7 +64,9 @@ struct RowValues {
         return M.m.value.negate ? (vx * -1.0) : vx;
     }
 
-    // V of cells i0 .. i0 + 7 (cells at or beyond `hi` are left undefined)
+    // V of cells i0 .. i0 + 7.  DT > 0: the eight cells lie in ONE row of the last axis (the host
+    // admits the implicit mode only for rows of whole bytes, sl_values_implicit), so the row is
+    // unravelled once and there is no carry.
     __device__ __forceinline__ void eight(const SlDevModel& M, const double* __restrict__ values,
                                           int64_t lo, int64_t hi, int64_t i0, double* v8) {
         if (DT == 0) {
@@ -73,15 +75,23 @@ struct RowValues {
             return;
         }
         start_row(M, i0);
+        const int first = (int)ijk[L];
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            if (c > 0) {
-                if (++ijk[L] == M.m.grid.num_points[L]) start_row(M, i0 + c);   // the row ended
-            }
+            ijk[L] = first + c;
             v8[c] = cell(M);
         }
     }
 };
+
+// sl_vbits (order-preserving float64 -> uint64, -0 = +0, NaN last) in eight instructions
+__device__ __forceinline__ uint64_t vbits_fast(double v) {
+    const double z = v + 0.0;                             // -0 -> +0 (round to nearest); NaN stays
+    union { double d; uint64_t u; } c;
+    c.d = z;
+    const uint64_t flip = (uint64_t)((int64_t)c.u >> 63) | 0x8000000000000000ull;
+    return (z != z) ? ~0ull : (c.u ^ flip);
+}
 
 template <int DT>
 __device__ __forceinline__ void constants_to_vgprs(SlDevModel& M) {
@@ -127,18 +137,23 @@ __global__ __launch_bounds__(SL_BLOCK) void k_finalize_dev(
         double v8[CPT];
         row.eight(M, values, lo, hi, i0, v8);
         unsigned safe8 = 0u;
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
+        auto one = [&](int c) {
             const int64_t idx = i0 + c;
-            if (idx < hi) {
-                const uint64_t vb = sl_vbits(v8[c]);
-                const bool below = sl_key_less(vb, idx, star.vbits, star.index);
-                const bool kept = ((prev8 >> c) & 1u) && !sl_key_less(vb, idx, keep.vbits, keep.index);
-                const bool safe = below || kept || ((init8 >> c) & 1u);
-                safe8 |= safe ? (1u << c) : 0u;
-                if (below) { ++n_below; sl_key_max(ls_v, ls_i, vb, idx); }
-                sl_key_max(mx_v, mx_i, vb, idx);
-            }
+            const uint64_t vb = vbits_fast(v8[c]);
+            const bool below = sl_key_less(vb, idx, star.vbits, star.index);
+            const bool kept = ((prev8 >> c) & 1u) && !sl_key_less(vb, idx, keep.vbits, keep.index);
+            const bool safe = below || kept || ((init8 >> c) & 1u);
+            safe8 |= safe ? (1u << c) : 0u;
+            // indices ascend inside a thread (and a thread's cells lie behind those of its
+            // earlier iterations): ">=" on the value bits alone keeps the lexicographic max
+            if (below) { ++n_below; if (vb >= ls_v) { ls_v = vb; ls_i = idx; } }
+            if (vb >= mx_v) { mx_v = vb; mx_i = idx; }
+        };
+        if (i0 + CPT <= hi) {                               // whole bytes: no per-cell range test
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) one(c);
+        } else {
+            for (int c = 0; c < CPT; ++c) if (i0 + c < hi) one(c);
         }
         safe_bytes[(i0 - lo) >> 3] = (uint8_t)safe8;
         n_safe += __popc(safe8);
@@ -252,18 +267,21 @@ __global__ __launch_bounds__(SL_BLOCK) void k_select_hist(
         if (i0 >= hi) continue;
         double v8[CPT];
         row.eight(M, values, lo, hi, i0, v8);
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
+        auto one = [&](int c) {
             const int64_t idx = i0 + c;
-            if (idx < hi) {
-                const uint64_t vb = sl_vbits(v8[c]);
-                uint64_t key;
-                bool take;
-                if (which == 0) { key = vb; take = true; }
-                else { key = (uint64_t)idx; take = (vb == vbits_equal); }
-                take = take && ((key & himask) == (prefix & himask));
-                if (take) atomicAdd(&lh[(key >> shift) & 0xff], 1u);
-            }
+            const uint64_t vb = vbits_fast(v8[c]);
+            uint64_t key;
+            bool take;
+            if (which == 0) { key = vb; take = true; }
+            else { key = (uint64_t)idx; take = (vb == vbits_equal); }
+            take = take && ((key & himask) == (prefix & himask));
+            if (take) atomicAdd(&lh[(key >> shift) & 0xff], 1u);
+        };
+        if (i0 + CPT <= hi) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) one(c);
+        } else {
+            for (int c = 0; c < CPT; ++c) if (i0 + c < hi) one(c);
         }
     }
     __syncthreads();
@@ -322,8 +340,9 @@ int blocks_for(sl_ctx* ctx, int64_t cells) {
 }  // namespace
 
 // May the passes of this file (and the sweep) be called with d_values = NULL?  Yes for a quadratic
-// V on a grid of 1..4 dimensions whose points by the np.linspace rule (last point = the upper limit)
-// equal index_to_state bit for bit - then the sweep's own V(x) IS the ordering key.
+// V on a grid of 1..4 dimensions with a last axis of whole bytes (a multiple of 8 cells) whose
+// points by the np.linspace rule (last point = the upper limit) equal index_to_state bit for bit -
+// then the sweep's own V(x) IS the ordering key.
 extern "C" int sl_values_implicit(sl_ctx* ctx, int* out) {
     if (!ctx || !out) return sl_fail(ctx, SL_ERR_INVALID, "sl_values_implicit: NULL argument");
     *out = 0;
@@ -331,6 +350,7 @@ extern "C" int sl_values_implicit(sl_ctx* ctx, int* out) {
     const SlDevModel& M = ctx->h_model;
     const int d = M.m.grid.d;
     if (M.m.value.kind != SL_V_QUADRATIC || d < 1 || d > 4) return SL_OK;
+    if (M.m.grid.num_points[d - 1] % CPT) return SL_OK;           // a thread's 8 cells share a row
     for (int k = 0; k < d; ++k) {
         volatile double t = (double)(M.m.grid.num_points[k] - 1) * M.m.grid.unit_maxes[k];
         volatile double s = t + M.m.grid.offset[k];

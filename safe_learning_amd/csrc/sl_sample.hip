@@ -1,0 +1,250 @@
+// sl_sample.hip - the glue of get_safe_sample / perturb_actions (lyapunov.py:609-797) as kernels:
+// states of the safe cells, the perturbed and clipped state-action candidates, their duplicate
+// removal in the byte-wise order of utilities.unique_rows (:496-516), the confidence bound and the
+// level-set test of a candidate, membership of its successor in the safe set and the arg-max.
+// (The GP posterior, V and L_v at the candidates come from sl_eval_points; the safe cells are
+// compacted with sl_partition_by_digit, rows are ordered with sl_sort_pairs.)
+#include "sl_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(SL_BLOCK) void k_index_to_state(const SlDevModel M, int64_t count,
+                                                             const int64_t* __restrict__ indices,
+                                                             double* __restrict__ states) {
+    const int d = M.m.grid.d;
+    for (int64_t i = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * SL_BLOCK) {
+        double x[SL_P];
+        sl_index_to_state(M.m.grid, M.gf, d, indices[i], x);           // functions.py:714-731
+        for (int k = 0; k < d; ++k) states[i * d + k] = x[k];
+    }
+}
+
+// row (i, k) = [state_i, clip(action_i + perturbation_k)]                          lyapunov.py:634-647
+__global__ __launch_bounds__(SL_BLOCK) void k_perturb_pairs(
+    int64_t count, int d, int m, const double* __restrict__ states, const double* __restrict__ actions,
+    int nperturb, const double* __restrict__ perturbations, const double* __restrict__ limits,
+    double* __restrict__ pairs) {
+    const int64_t total = count * nperturb;
+    const int w = d + m;
+    for (int64_t r = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; r < total;
+         r += (int64_t)gridDim.x * SL_BLOCK) {
+        const int64_t i = r / nperturb;
+        const int k = (int)(r - i * nperturb);
+        for (int c = 0; c < d; ++c) pairs[r * w + c] = states[i * d + c];
+        for (int a = 0; a < m; ++a) {
+            double u = actions[i * m + a] + perturbations[k * m + a];
+            if (limits) {                                                      // np.clip: min(max(u, lo), hi)
+                const double lo = limits[2 * a], hi = limits[2 * a + 1];
+                u = u < lo ? lo : u;
+                u = u > hi ? hi : u;
+            }
+            pairs[r * w + d + a] = u;
+        }
+    }
+}
+
+// memcmp order of a little-endian float64 = unsigned order of its byte-swapped bits
+__global__ __launch_bounds__(SL_BLOCK) void k_rows_sort_key(int64_t count, int words, int column,
+                                                            const int64_t* __restrict__ rows,
+                                                            const int64_t* __restrict__ order,
+                                                            uint64_t* __restrict__ keys) {
+    for (int64_t q = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; q < count;
+         q += (int64_t)gridDim.x * SL_BLOCK) {
+        const int64_t r = order ? order[q] : q;
+        keys[q] = __builtin_bswap64((uint64_t)rows[r * words + column]);
+    }
+}
+
+// flags[q] = 1 when the q-th row (in `order`) repeats the one before it, bit for bit
+__global__ __launch_bounds__(SL_BLOCK) void k_rows_duplicate_flags(int64_t count, int words,
+                                                                   const int64_t* __restrict__ rows,
+                                                                   const int64_t* __restrict__ order,
+                                                                   uint8_t* __restrict__ flags) {
+    for (int64_t q = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; q < count;
+         q += (int64_t)gridDim.x * SL_BLOCK) {
+        bool same = q > 0;
+        if (same) {
+            const int64_t a = order[q], b = order[q - 1];
+            for (int w = 0; w < words; ++w) same = same && rows[a * words + w] == rows[b * words + w];
+        }
+        flags[q] = same ? 1 : 0;
+    }
+}
+
+// bound = sum_j std_j; inside = V(mean) + sum_j L_v(mean)_j std_j < c_max               lyapunov.py:716-726
+__global__ __launch_bounds__(SL_BLOCK) void k_sample_bounds(
+    int64_t count, int d, int lv_cols, const double* __restrict__ std, const double* __restrict__ lv,
+    const double* __restrict__ value, double c_max, double* __restrict__ bound,
+    uint8_t* __restrict__ inside) {
+    for (int64_t i = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * SL_BLOCK) {
+        double b = std[i * d], e = lv[i * lv_cols] * std[i * d];
+        for (int k = 1; k < d; ++k) {                      // left to right like the oracle
+            b = b + std[i * d + k];
+            const double t = lv[i * lv_cols + (lv_cols > 1 ? k : 0)] * std[i * d + k];
+            e = e + t;
+        }
+        bound[i] = b;
+        inside[i] = (value[i] + e) < c_max ? 1 : 0;
+    }
+}
+
+// out[i] &= safe_set[state_to_index(point_i)]                          lyapunov.py:762-766, functions.py:733-752
+__global__ __launch_bounds__(SL_BLOCK) void k_state_membership(const SlDevModel M, int64_t count,
+                                                               const double* __restrict__ points,
+                                                               const uint64_t* __restrict__ safe_bits,
+                                                               uint8_t* __restrict__ inout) {
+    const int d = M.m.grid.d;
+    for (int64_t i = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * SL_BLOCK) {
+        int64_t flat = 0;
+        for (int k = 0; k < d; ++k) {
+            double x = points[i * d + k];
+            const double lo = M.m.grid.offset[k], hi = M.m.grid.upper[k];
+            x = x < lo ? lo : x;                                               // np.clip
+            x = x > hi ? hi : x;
+            const double inv = 1.0 / M.m.grid.unit_maxes[k];
+            const double s = (x - lo) * inv;
+            const int64_t ijk = (int64_t)rint(s);                              // np.rint: half to even
+            flat = flat * M.m.grid.num_points[k] + ijk;
+        }
+        const bool safe = (safe_bits[flat >> 6] >> (flat & 63)) & 1ull;
+        inout[i] = (inout[i] && safe) ? 1 : 0;
+    }
+}
+
+// first index of the largest value among the rows with mask != 0 (np.argmax: NaN counts as largest)
+__global__ __launch_bounds__(SL_BLOCK) void k_argmax_masked(int64_t count, const double* __restrict__ values,
+                                                            const uint8_t* __restrict__ mask,
+                                                            int64_t* __restrict__ out) {
+    __shared__ double sv[SL_BLOCK];
+    __shared__ int64_t si[SL_BLOCK];
+    __shared__ int64_t sn[SL_BLOCK];
+    double best = 0.0;
+    int64_t at = -1, n = 0;
+    auto better = [](double a, int64_t ia, double b, int64_t ib) {          // (a, ia) beats (b, ib)
+        if (ib < 0) return true;
+        const bool an = a != a, bn = b != b;
+        if (an != bn) return an;
+        if (!an && a != b) return a > b;
+        return ia < ib;
+    };
+    for (int64_t i = threadIdx.x; i < count; i += SL_BLOCK) {
+        if (mask && !mask[i]) continue;
+        ++n;
+        if (better(values[i], i, best, at)) { best = values[i]; at = i; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = at; sn[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = SL_BLOCK / 2; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) {
+            const int o = threadIdx.x + off;
+            if (si[o] >= 0 && better(sv[o], si[o], sv[threadIdx.x], si[threadIdx.x])) {
+                sv[threadIdx.x] = sv[o]; si[threadIdx.x] = si[o];
+            }
+            sn[threadIdx.x] += sn[o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = si[0]; out[1] = sn[0]; }
+}
+
+int check_model(sl_ctx* ctx, const char* who) {
+    if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "%s: NULL context", who);
+    if (!ctx->model_set) return sl_fail(ctx, SL_ERR_INVALID, "%s: call sl_model_set first", who);
+    return SL_OK;
+}
+
+}  // namespace
+
+extern "C" int sl_index_to_state(sl_ctx* ctx, int64_t count, const int64_t* d_indices, double* d_states) {
+    int rc = check_model(ctx, "sl_index_to_state");
+    if (rc) return rc;
+    if (count < 0 || (count && (!d_indices || !d_states)))
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_index_to_state: bad argument");
+    if (count == 0) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_index_to_state, dim3(sl_grid_blocks(count)), dim3(SL_BLOCK), 0, ctx->stream,
+                       ctx->h_model, count, d_indices, d_states);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+extern "C" int sl_perturb_pairs(sl_ctx* ctx, int64_t count, int d, int m, const double* d_states,
+                                const double* d_actions, int nperturb, const double* d_perturbations,
+                                const double* d_limits, double* d_pairs) {
+    if (!ctx || count < 0 || d < 1 || m < 1 || nperturb < 1 || !d_perturbations ||
+        (count && (!d_states || !d_actions || !d_pairs)))
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_perturb_pairs: bad argument");
+    if (count == 0) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_perturb_pairs, dim3(sl_grid_blocks(count * nperturb)), dim3(SL_BLOCK), 0,
+                       ctx->stream, count, d, m, d_states, d_actions, nperturb, d_perturbations, d_limits,
+                       d_pairs);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+extern "C" int sl_rows_sort_key(sl_ctx* ctx, int64_t count, int words, int column, const int64_t* d_rows,
+                                const int64_t* d_order, uint64_t* d_keys) {
+    if (!ctx || count < 0 || words < 1 || column < 0 || column >= words || (count && (!d_rows || !d_keys)))
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_rows_sort_key: bad argument");
+    if (count == 0) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_rows_sort_key, dim3(sl_grid_blocks(count)), dim3(SL_BLOCK), 0, ctx->stream, count,
+                       words, column, d_rows, d_order, d_keys);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+extern "C" int sl_rows_duplicate_flags(sl_ctx* ctx, int64_t count, int words, const int64_t* d_rows,
+                                       const int64_t* d_order, uint8_t* d_flags) {
+    if (!ctx || count < 0 || words < 1 || (count && (!d_rows || !d_order || !d_flags)))
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_rows_duplicate_flags: bad argument");
+    if (count == 0) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_rows_duplicate_flags, dim3(sl_grid_blocks(count)), dim3(SL_BLOCK), 0, ctx->stream,
+                       count, words, d_rows, d_order, d_flags);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+extern "C" int sl_sample_bounds(sl_ctx* ctx, int64_t count, int d, int lv_cols, const double* d_std,
+                                const double* d_lv, const double* d_value, double c_max, double* d_bound,
+                                uint8_t* d_inside) {
+    if (!ctx || count < 0 || d < 1 || (lv_cols != 1 && lv_cols != d) ||
+        (count && (!d_std || !d_lv || !d_value || !d_bound || !d_inside)))
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_sample_bounds: bad argument");
+    if (count == 0) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_sample_bounds, dim3(sl_grid_blocks(count)), dim3(SL_BLOCK), 0, ctx->stream, count,
+                       d, lv_cols, d_std, d_lv, d_value, c_max, d_bound, d_inside);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+extern "C" int sl_state_membership(sl_ctx* ctx, int64_t count, const double* d_points,
+                                   const uint64_t* d_safe_bits, uint8_t* d_inout) {
+    int rc = check_model(ctx, "sl_state_membership");
+    if (rc) return rc;
+    if (count < 0 || !d_safe_bits || (count && (!d_points || !d_inout)))
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_state_membership: bad argument");
+    if (count == 0) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_state_membership, dim3(sl_grid_blocks(count)), dim3(SL_BLOCK), 0, ctx->stream,
+                       ctx->h_model, count, d_points, d_safe_bits, d_inout);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+extern "C" int sl_argmax_masked(sl_ctx* ctx, int64_t count, const double* d_values, const uint8_t* d_mask,
+                                int64_t* d_out) {
+    if (!ctx || count < 0 || !d_out || (count && !d_values))
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_argmax_masked: bad argument");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_argmax_masked, dim3(1), dim3(SL_BLOCK), 0, ctx->stream, count, d_values, d_mask,
+                       d_out);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}

@@ -99,24 +99,20 @@ class _timed(object):
         return False
 
 
-def gather_words(tensor):
-    """Every rank's copy of a small packed int64 record as ONE host array ``[world, len]``.
-
-    This is the only communication pattern of ``update_safe_set``'s reductions: the kernels leave
-    their per-shard result (failing key, last safe key, largest key, counters: 64 bytes) in
-    device memory, one all-gather moves the packed records device to device (RCCL over xGMI) and
-    one copy brings all of them to the host, where the lexicographic (unsigned 64-bit) comparisons
-    are exact.  No per-scalar round trips."""
-    import torch
+def gather_records(tensor):
+    """Every rank's packed 64-byte record in DEVICE memory -> ``(records, world)``: one
+    ``all_gather_into_tensor`` (RCCL over xGMI), nothing copied to the host - the fold and the
+    kernels that consume the folded record run on the device (``sl_fold_results``)."""
     if not is_distributed():
-        return tensor.detach().cpu().numpy().reshape(1, -1)
+        return tensor, 1
+    import torch
     import torch.distributed as dist
     world = dist.get_world_size()
     flat = tensor.detach().reshape(-1).contiguous()
     out = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
     with _timed(flat):
         dist.all_gather_into_tensor(out, flat)
-    return out.cpu().numpy().reshape(world, -1)
+    return out, world
 
 
 def u64(word):
@@ -131,6 +127,36 @@ def allreduce_sum_(tensor):
         with _timed(tensor):
             dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor
+
+
+def allreduce_min_(tensor):
+    if is_distributed():
+        import torch.distributed as dist
+        with _timed(tensor):
+            dist.all_reduce(tensor, op=dist.ReduceOp.MIN)
+    return tensor
+
+
+def exchange_rows(rows, send_counts, recv_counts=None):
+    """All-to-all of the rows of a 2-D tensor: the first ``send_counts[0]`` rows go to rank 0, the
+    next ``send_counts[1]`` to rank 1, ...; returns ``(received rows, rows received per rank)`` in
+    source-rank order.  ``recv_counts``: known from an earlier exchange in the other direction,
+    otherwise the counts are exchanged first (one small all-to-all)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    assert len(send_counts) == world and sum(send_counts) == len(rows)
+    if recv_counts is None:
+        theirs = torch.empty(world, dtype=torch.int64, device=rows.device)
+        mine = torch.tensor(send_counts, dtype=torch.int64, device=rows.device)
+        with _timed(mine):
+            dist.all_to_all_single(theirs, mine)
+        recv_counts = [int(v) for v in theirs.cpu()]
+    out = torch.empty((sum(recv_counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    with _timed(rows):
+        dist.all_to_all_single(out, rows.contiguous(), output_split_sizes=recv_counts,
+                               input_split_sizes=list(send_counts))
+    return out, recv_counts
 
 
 def allreduce_max_(tensor):

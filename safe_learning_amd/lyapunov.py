@@ -101,11 +101,16 @@ class Lyapunov(object):
         # so that the gathers are ONE all_gather_into_tensor of equal pieces without a pad copy
         per = max(self._bounds[1] - self._bounds[0], 1)
         cap, wcap = (per, -(-per // 64)) if self._collective else (max(count, 1), max(self._nwords, 1))
-        self._d_values = torch.zeros(cap, dtype=torch.float64, device=dev)
+        self._values_capacity = cap
+        self._d_values_buffer = None    # V of this rank's shard: allocated when something reads it
+        self._values_stale = True
+        self._values_implicit = False   # quadratic V: the passes recompute it from the cell index
         self._d_init = torch.zeros(wcap, dtype=torch.int64, device=dev)
         self._d_neg = torch.zeros(wcap, dtype=torch.int64, device=dev)
         self._d_safe = torch.zeros(wcap, dtype=torch.int64, device=dev)
         self._d_result = torch.zeros(_hip.RESULT_WORDS, dtype=torch.int64, device=dev)
+        self._d_folded = torch.zeros(_hip.RESULT_WORDS, dtype=torch.int64, device=dev)
+        self._d_select = torch.zeros(_hip.SELECT_WORDS, dtype=torch.int64, device=dev)
         self._d_hist = torch.zeros(256, dtype=torch.int64, device=dev)
         self._values_host = None
         self._d_values_full = None      # all shards of V: gathered on demand (gather_values)
@@ -130,7 +135,42 @@ class Lyapunov(object):
         self._builder.upload(self.policy, self.dynamics, self.lyapunov_function,
                              self._lipschitz_lyapunov, self._lipschitz_dynamics, self.tau)
 
+    @property
+    def _d_values(self):
+        """V on this rank's shard as a device tensor (``sl_values``), computed when first read:
+        with a quadratic V the sweep and the streaming passes recompute the ordering keys from the
+        cell index (``sl_values_implicit``) and the 8 bytes per cell are neither written nor read."""
+        import torch
+        if self._d_values_buffer is None:
+            self._d_values_buffer = torch.zeros(self._values_capacity, dtype=torch.float64,
+                                                device=self._ctx.torch_device)
+            self._values_stale = True
+        if self._values_stale:
+            self._upload_model()
+            self._ctx.values(self._lo, self._hi, self._d_values_buffer)
+            self._values_stale = False
+        return self._d_values_buffer
+
+    def _values_arg(self):
+        """What the passes get as ``d_values``: None when the keys are recomputed in the kernels."""
+        return None if self._values_implicit else self._d_values
+
     # ---- reference attribute surface -----------------------------------------------------
+    @property
+    def lyapunov_function(self):
+        return self._lyapunov_function
+
+    @lyapunov_function.setter
+    def lyapunov_function(self, fun):
+        # In the reference ``values`` keeps the OLD function's numbers until update_values() is
+        # called (lyapunov.py:305-322).  If the kernels currently recompute the keys from the
+        # model, write them down with the old function before the model changes.
+        old = getattr(self, '_lyapunov_function', None)
+        if old is not None and fun is not old and getattr(self, '_values_implicit', False):
+            self._d_values
+            self._values_implicit = False
+        self._lyapunov_function = fun
+
     @property
     def initial_safe_set(self):
         return self._initial_safe_set
@@ -247,19 +287,6 @@ class Lyapunov(object):
             self._safe_dev_valid = False
         return self._safe_host
 
-    def _safe_bytes_device(self):
-        """The safe set as ``uint8[nindex]`` on the device (no host copy): the mask words every
-        rank holds after ``update_safe_set``, or the host array if the caller edited it."""
-        import torch
-        n = self.discretization.nindex
-        dev = self._ctx.torch_device
-        if self._safe_host_valid and not self._safe_dev_valid:
-            return torch.from_numpy(self._safe_host.view(np.uint8)).to(dev)
-        words = self._d_safe_full if self._d_safe_full is not None else self._d_safe
-        d_bytes = torch.empty(max(-(-n // 8) * 8, 8), dtype=torch.uint8, device=dev)
-        self._ctx.bits_to_bytes(n, words, d_bytes)
-        return d_bytes[:n]
-
     @safe_set.setter
     def safe_set(self, value):
         self._safe_host[:] = value
@@ -271,7 +298,11 @@ class Lyapunov(object):
         """Refinement N(x) per cell (``lyapunov.py:220-225``): the array kept by the adaptive
         branch, otherwise 1 on safe cells and 0 elsewhere (``:531, 586, 601-606``)."""
         if self._refinement_host is None and getattr(self, '_refinement_dev', None) is not None:
-            self._refinement_host = self._refinement_dev.cpu().numpy().astype(int)
+            # every rank keeps the refinement of its own cells; reading the attribute gathers the
+            # shards (collective with more than one rank, like ``values``)
+            sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
+            full = dist_utils.allgather_concat(self._refinement_dev, sizes)
+            self._refinement_host = full.cpu().numpy().astype(int)
         if self._refinement_host is not None:
             return self._refinement_host
         return self.safe_set.astype(int)
@@ -293,7 +324,7 @@ class Lyapunov(object):
             self._upload_model()
             self._refresh_init_bits()
             d_neg = torch.zeros_like(self._d_neg)
-            self._ctx.lyap_sweep(self._lo, self._hi, self._d_init, self._d_values, d_neg,
+            self._ctx.lyap_sweep(self._lo, self._hi, self._d_init, self._values_arg(), d_neg,
                                  self._d_result)
         finally:
             self.policy = own_policy
@@ -346,12 +377,23 @@ class Lyapunov(object):
         self._init_object = init
 
     # ---- reference methods ---------------------------------------------------------------
-    def update_values(self):
-        """Recompute V on the grid (``lyapunov.py:305-322``)."""
+    def update_values(self, gather=False):
+        """Recompute V on the grid (``lyapunov.py:305-322``).
+
+        With a quadratic V nothing is computed here: the kernels recompute the ordering keys of
+        ``lyapunov.py:512`` from the cell index and the array is materialised when ``values`` is
+        read.  ``gather=True`` (sharded grids): gather all shards now, collectively, so that a
+        later read of ``values`` on ONE rank only is a local read (the lazy gather behind the
+        attribute is a collective and must otherwise be reached by every rank)."""
         self._upload_model()
-        self._ctx.values(self._lo, self._hi, self._d_values)
+        self._values_implicit = self._ctx.values_implicit()
+        self._values_stale = True
+        if not self._values_implicit:
+            self._d_values                   # computes this rank's shard now
         self._values_host = None
         self._d_values_full = None       # shards only; ``values`` / ``gather_values`` gather lazily
+        if gather:
+            self.gather_values()
 
     def update_safe_set(self, can_shrink=True, max_refinement=1, safety_factor=1.,
                         parallel_iterations=1):
@@ -369,7 +411,7 @@ class Lyapunov(object):
         engine = _HipShardEngine(self)
         stats = {}
         self.c_max = prefix_rule(engine, self.discretization.nindex, int(config.gp_batch_size),
-                                 can_shrink, self._ctx.torch_device, stats)
+                                 can_shrink, stats)
         self.safe_count = stats['safe']       # cells in the safe set (all ranks), no mask copy
         self._safe_host_valid = False
         self._safe_dev_valid = True
@@ -380,163 +422,57 @@ class Lyapunov(object):
                 self._d_safe, -(-self.discretization.nindex // 64), out=self._safe_full_buffer())
 
 
-    def _threshold_base_device(self):
-        """``-|L_v(x)|_1 (1 + L_f(x))`` at every grid cell as a device tensor (the refined
-        threshold of the adaptive branch is this times ``tau / N(x)``): ``threshold(x, tau=1)``
-        with the same operation order, ``L_v`` from the point-evaluation kernels."""
-        import torch
-        from . import _evaluate
-        n = self.discretization.nindex
-        dev = self._ctx.torch_device
-        lvs, lfs = self._lipschitz_lyapunov, self._lipschitz_dynamics
-        states = None
-        if not (np.isscalar(lvs) and np.isscalar(lfs)):
-            states = _index_to_state_device(self.discretization,
-                                            torch.arange(n, dtype=torch.int64, device=dev))
-        if np.isscalar(lvs):
-            lv = torch.full((n,), float(lvs), dtype=torch.float64, device=dev)
-        else:
-            lv = _evaluate.value(self.lyapunov_function, states, lvs)[1]
-            if lv.shape[1] > 1:
-                acc = lv[:, 0].abs()
-                for k in range(1, lv.shape[1]):
-                    acc = acc + lv[:, k].abs()
-                lv = acc
-            else:
-                lv = lv[:, 0]
-        if np.isscalar(lfs):
-            lf = float(lfs)
-        else:
-            rows = torch.from_numpy(np.asarray(lfs.fun.matrix, dtype=np.float64)).to(dev)
-            acc = None
-            for r in range(rows.shape[0]):
-                t = states[:, 0] * rows[r, 0]
-                for k in range(1, states.shape[1]):
-                    t = t + states[:, k] * rows[r, k]
-                acc = t.abs() if acc is None else acc + t.abs()
-            lf = lfs.constant + acc
-        return (-lv) * (1. + lf) * 1.0
-
     def _update_safe_set_adaptive(self, can_shrink, max_refinement, safety_factor):
         """Adaptive discretisation (``lyapunov.py:445-487, 540-582``), bug-compatible: as written
         in the reference the refined check compares the decrease of every cell of the candidate
         run with each cell's refined threshold ``threshold(x, tau / N(x))`` (the refined points
         themselves are never evaluated), see DESIGN.md.
 
-        Everything of grid size stays on the GPU: the per-cell quantities come from one sweep of
-        this rank's shard, the ascending-V order from a stable device sort (no host ``argsort``),
-        and the batch loop of the reference runs over device slices with a few scalar read-backs
-        per batch; it ends at the first batch that cannot be refined, like the reference's."""
-        import torch
-        n, d = self.discretization.nindex, self.discretization.ndim
-        dev = self._ctx.torch_device
-        batch = int(config.gp_batch_size)
-        safety_factor = max(float(safety_factor), 1.)
+        All of it runs in HIP kernels on sharded data (``adaptive_rule``): one sweep of this rank's
+        cells, a device radix sort of the ``(V, index)`` keys instead of the host ``argsort``, every
+        batch of the reference's loop judged in parallel, rows exchanged between the owner of a cell
+        and the owner of its sorted position with two all-to-alls; no rank holds anything of grid
+        size but its own shard."""
         self._upload_model()
         self._refresh_init_bits()
-        lo, hi = self._lo, self._hi
-        count = hi - lo
-        sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
-        records = torch.empty((max(count, 1), 2 + 2 * d), dtype=torch.float64, device=dev)
-        self._ctx.lyap_sweep(lo, hi, self._d_init, self._d_values, self._d_neg, self._d_result, records)
-        decrease = dist_utils.allgather_concat(records[:count, 0].contiguous(), sizes)
-        threshold = dist_utils.allgather_concat(records[:count, 1].contiguous(), sizes)
-        d_bytes = torch.empty(max(-(-count // 8) * 8, 8), dtype=torch.uint8, device=dev)
-        self._ctx.bits_to_bytes(count, self._d_neg, d_bytes)
-        negative = dist_utils.allgather_concat(d_bytes[:count], sizes).to(torch.bool)
-        values = self.gather_values()
-        base = self._threshold_base_device()
-        init_mask = torch.zeros(n, dtype=torch.bool, device=dev)
-        if self._initial_safe_set is not None:
-            init = np.asarray(self._initial_safe_set)
-            if init.dtype == bool and init.shape == (n,):
-                init_mask = torch.from_numpy(init).to(dev)
-            else:
-                init_mask[torch.from_numpy(np.atleast_1d(init).astype(np.int64)).to(dev)] = True
-
-        if can_shrink:
-            safe_src = init_mask.clone()
-            refine_src = init_mask.to(torch.int64)
-        else:
-            safe_src = self._safe_bytes_device().to(torch.bool).clone()
-            refine_src = self._refinement_device().clone()
-        order = torch.sort(values, stable=True).indices          # ascending (V, flat index)
-        safe_sorted, refinement = safe_src[order], refine_src[order]
-        ratio = safety_factor * threshold / decrease
-        n_req_all = torch.ceil(torch.clamp(torch.where(torch.isnan(ratio), torch.zeros_like(ratio),
-                                                       ratio), min=0.))
-        n_req_all = torch.clamp(n_req_all, max=float(1 << 40)).to(torch.int64)   # inf -> "too many"
-
-        start = bound = refine_bound = 0
-        for start in range(0, n, batch):
-            idx = order[start:start + batch]
-            safe_b, ref_b = safe_sorted[start:start + batch], refinement[start:start + batch]
-            neg_b = negative[idx]
-            safe_b |= neg_b
-            ref_b[neg_b] = 1
-            unsafe = torch.nonzero(~safe_b, as_tuple=False)
-            bound, refine_bound = (int(unsafe[0]) if len(unsafe) else 0), 0
-            if not len(unsafe):
-                continue
-            ref_b[bound:] = n_req_all[idx[bound:]]
-            ref_b[neg_b | init_mask[idx]] = 1
-            checkable = ((ref_b >= 1) & (ref_b <= max_refinement))[bound:]
-            stop = len(checkable) if bool(checkable.all()) else int(torch.argmin(checkable.to(torch.uint8)))
-            if stop > 0:
-                run = idx[bound:bound + stop]
-                run_dec = decrease[run]
-                refined_thr = base[run] * (self.tau / ref_b[bound:bound + stop].to(torch.float64))
-                worst = float(run_dec.max()) if not bool(torch.isnan(run_dec).any()) else float('inf')
-                refined_safe = worst < refined_thr
-                refine_bound = stop if bool(refined_safe.all()) else int(torch.argmin(refined_safe.to(torch.uint8)))
-                safe_b[bound:bound + refine_bound] = True
-            if stop < len(checkable) or refine_bound < stop:
-                safe_b[bound + refine_bound:] = False
-                ref_b[bound + refine_bound:] = 0
-                break
-
-        self.c_max = float(values[order[start + bound + refine_bound - 1]])
-        safe = torch.zeros(n, dtype=torch.bool, device=dev)
-        safe[order[safe_sorted]] = True
-        refine = torch.zeros(n, dtype=torch.int64, device=dev)
-        refine[order] = refinement
-        safe |= init_mask
-        refine[init_mask] = 1
-        self._refinement_dev = refine
+        if not can_shrink and not self._safe_dev_valid:          # lyapunov.py:507-510
+            self._upload_mask(self._safe_host, self._d_safe)
+        engine = _HipAdaptiveEngine(self, can_shrink)
+        stats = {}
+        self.c_max = adaptive_rule(engine, self.discretization.nindex, int(config.gp_batch_size),
+                                   max_refinement, max(float(safety_factor), 1.), stats)
+        self.safe_count = stats['safe']
+        self._refinement_dev = engine.refinement        # this rank's shard, int64
         self._refinement_host = None
-        self.safe_count = int(safe.sum())
-        # the mask goes straight into this rank's bit words (and the gathered copy)
-        full_bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
-        self._ctx.bytes_to_bits(n, safe.to(torch.uint8).contiguous(), full_bits)
-        nwords = (count + 63) // 64
-        self._d_safe[:nwords] = full_bits[lo // 64:lo // 64 + nwords]
-        self._d_safe_full = full_bits if self._collective else None
         self._safe_host_valid = False
         self._safe_dev_valid = True
+        if self._collective:
+            self._d_safe_full = dist_utils.allgather_equal(
+                self._d_safe, -(-self.discretization.nindex // 64), out=self._safe_full_buffer())
 
-    def _refinement_device(self):
-        """Refinement N(x) per cell as a device tensor (int64[nindex])."""
+    def _refinement_shard(self):
+        """Refinement N(x) of this rank's cells as a device tensor (int64), or None when it is
+        simply 1 on safe cells (no adaptive update yet)."""
         import torch
+        dev = self._ctx.torch_device
         if getattr(self, '_refinement_dev', None) is not None:
             return self._refinement_dev
         if self._refinement_host is not None:
-            return torch.from_numpy(np.asarray(self._refinement_host, dtype=np.int64)).to(
-                self._ctx.torch_device)
-        return self._safe_bytes_device().to(torch.int64)
+            return torch.from_numpy(np.ascontiguousarray(
+                np.asarray(self._refinement_host, dtype=np.int64)[self._lo:self._hi])).to(dev)
+        return None
 
 
 class _HipShardEngine(object):
-    """This rank's shard of the grid as the prefix rule sees it (all work in HIP kernels).
-
-    ``sweep`` / ``finalize`` return the kernels' packed result record (``sl_sweep_result``, eight
-    int64 words) as a DEVICE tensor; ``prefix_rule`` gathers the records of all ranks at once."""
+    """This rank's shard of the grid as the prefix rule sees it (all work in HIP kernels, every
+    intermediate result - records, folded records, the radix-select state - in device memory)."""
 
     def __init__(self, lyap):
         self.lyap = lyap
         self.prior = None
 
     def sweep(self, can_shrink):
-        """Decrease check of every cell; words R_FAIL_V / R_FAIL_I hold the local lexmin failing
+        """Decrease check of every cell; the record's ``fail`` is the local lexmin failing
         ``(vbits, index)``."""
         ly = self.lyap
         self.prior = ly._d_init if can_shrink else ly._d_safe.clone()     # lyapunov.py:500-510
@@ -545,83 +481,98 @@ class _HipShardEngine(object):
             import torch
             start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
-        ly._ctx.lyap_sweep(ly._lo, ly._hi, self.prior, ly._d_values, ly._d_neg, ly._d_result)
+        ly._ctx.lyap_sweep(ly._lo, ly._hi, self.prior, ly._values_arg(), ly._d_neg, ly._d_result)
         if events is not None:
             stop.record()
             events.append((start, stop))
         return ly._d_result
 
-    def finalize(self, star, keep, use_prior):
-        """``safe = init | key < star | (prior & key >= keep)``; words R_BELOW, R_LAST_*, R_MAX_*
-        hold the local statistics."""
+    def fold(self, records, count):
+        """``count`` gathered records (device) -> one: lexmin / lexmax of the keys, sums of the
+        counters (``sl_fold_results``)."""
         ly = self.lyap
-        ly._ctx.lyap_finalize(ly._lo, ly._hi, ly._d_values, ly._d_init,
-                              self.prior if use_prior else None, star, keep, ly._d_safe,
-                              ly._d_result)
+        ly._ctx.fold_results(records, count, ly._d_folded)
+        return ly._d_folded
+
+    def finalize(self, folded, keep_state, use_prior):
+        """``safe = init | key < key* | (prior & key >= key_keep)`` with ``key*`` = the folded
+        record's ``fail`` and ``key_keep`` = the select state's key, both read by the kernel."""
+        ly = self.lyap
+        events = getattr(ly, 'finalize_events', None)
+        if events is not None:
+            import torch
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+        keep = None if keep_state is None else keep_state[_hip.S_KEY_V:_hip.S_KEY_V + 2]
+        ly._ctx.lyap_finalize_dev(ly._lo, ly._hi, ly._values_arg(), ly._d_init,
+                                  self.prior if use_prior else None, folded, keep, ly._d_safe,
+                                  ly._d_result)
+        if events is not None:
+            stop.record()
+            events.append((start, stop))
         return ly._d_result
 
-    def select_hist(self, which, byte, prefix, vbits_equal):
-        """Local 256-bin histogram of one radix-select pass (int64[256])."""
+    def select_begin(self, k, batch, folded, n):
         ly = self.lyap
-        ly._d_hist.zero_()
-        ly._ctx.select_pass(ly._lo, ly._hi, ly._d_values, which, byte, prefix, vbits_equal,
-                            ly._d_hist)
+        ly._ctx.select_begin(ly._d_select, k, batch, folded, n)
+        return ly._d_select
+
+    def select_hist(self, which, byte, state):
+        """Local 256-bin histogram of one radix-select pass (int64[256], device)."""
+        ly = self.lyap
+        ly._ctx.select_hist(ly._lo, ly._hi, ly._values_arg(), which, byte, state, ly._d_hist)
         return ly._d_hist
 
+    def select_digit(self, which, byte, hist, state):
+        self.lyap._ctx.select_digit(which, byte, hist, state)
 
-def select_kth(engine, k, device):
-    """``(vbits, index)`` of the k-th smallest key (0-based) over all shards: two 8-pass radix
-    selects (value bytes, then index bytes among equal values), one 2 KiB SUM all-reduce each."""
-    def run(which, vbits_equal, rank_in):
-        prefix, remaining = 0, rank_in
+
+def select_kth(engine, k, batch, folded, n):
+    """Select state (device) holding the k-th smallest ``(vbits, index)`` key (0-based) over all
+    shards; ``k < 0``: ``k = (count_below // batch + 1) * batch`` taken from the folded record on
+    the device.  Two 8-pass radix selects (value bytes, then index bytes among equal values), one
+    2 KiB SUM all-reduce each, no host round trip: digits and prefixes stay on the device."""
+    state = engine.select_begin(k, batch, folded, n)
+    for which in (0, 1):
         for byte in range(7, -1, -1):
-            hist = engine.select_hist(which, byte, prefix, vbits_equal)
-            hist = dist_utils.allreduce_sum_(hist)
-            hist = hist.cpu().numpy() if hasattr(hist, 'cpu') else np.asarray(hist)
-            cum = np.cumsum(hist)
-            digit = int(np.searchsorted(cum, remaining, side='right'))
-            if digit > 0:
-                remaining -= int(cum[digit - 1])
-            prefix |= digit << (8 * byte)
-        return prefix, remaining
-
-    vbits, rank_among_equal = run(0, 0, k)
-    index, _ = run(1, vbits, rank_among_equal)
-    return vbits, index
+            hist = dist_utils.allreduce_sum_(engine.select_hist(which, byte, state))
+            engine.select_digit(which, byte, hist, state)
+    return state
 
 
-def _reduce_key(rows, col_v, col_i, largest):
-    keys = [(dist_utils.u64(r[col_v]), int(r[col_i])) for r in rows]
-    return max(keys) if largest else min(keys)
+def _host_words(tensor):
+    return [int(v) for v in tensor.detach().cpu().numpy().reshape(-1)]
 
 
-def prefix_rule(engine, n, batch, can_shrink, device, stats=None):
+def prefix_rule(engine, n, batch, can_shrink, stats=None):
     """The safe-set rule of ``lyapunov.py:512-606`` over sharded cells; returns ``c_max``.
 
     ``engine`` owns one contiguous shard (the HIP engine in production, a NumPy stand-in in the
-    CPU tests of the multi-rank path).  Communication: ONE all-gather of the packed 64-byte result
-    record after the sweep and ONE after the streaming pass (``distributed.gather_words``), each
-    followed by one copy to the host; only ``can_shrink=False`` or the no-failure ``c_max`` quirk
-    add sixteen 2 KiB SUM all-reduces of radix-select histograms.
-    """
-    rows = dist_utils.gather_words(engine.sweep(can_shrink))
-    star = _reduce_key(rows, _hip.R_FAIL_V, _hip.R_FAIL_I, largest=False)
-    rows = dist_utils.gather_words(engine.finalize(star, _KEY_NONE, use_prior=False))
-    below = int(sum(int(r[_hip.R_BELOW]) for r in rows))
-    last_safe = _reduce_key(rows, _hip.R_LAST_V, _hip.R_LAST_I, largest=True)
-    max_key = _reduce_key(rows, _hip.R_MAX_V, _hip.R_MAX_I, largest=True)
+    CPU tests of the multi-rank path).  One sequence of launches and collectives: sweep ->
+    all-gather of the 64-byte records -> fold (device) -> streaming pass that reads ``key*`` from
+    the folded record -> all-gather -> fold -> ONE 64-byte copy to the host.  ``can_shrink=False``
+    or the no-failure ``c_max`` quirk add a device-resident radix select (sixteen 2 KiB SUM
+    all-reduces) and one more copy."""
+    folded = engine.fold(*dist_utils.gather_records(engine.sweep(can_shrink)))
+    folded = engine.fold(*dist_utils.gather_records(engine.finalize(folded, None, use_prior=False)))
+    row = _host_words(folded)
+    star = (dist_utils.u64(row[_hip.R_FAIL_V]), row[_hip.R_FAIL_I])
+    below = row[_hip.R_BELOW]
+    last_safe = (dist_utils.u64(row[_hip.R_LAST_V]), row[_hip.R_LAST_I])
+    max_key = (dist_utils.u64(row[_hip.R_MAX_V]), row[_hip.R_MAX_I])
+    safe = row[_hip.R_SAFE]
     failed = star != _KEY_NONE
 
     if failed and not can_shrink:
         # cells after the batch that contains the first failure keep their previous state
-        # (lyapunov.py:585-587 never touches later batches)
-        end = (below // batch + 1) * batch
-        keep = select_kth(engine, end, device) if end < n else _KEY_NONE
-        record = engine.finalize(star, keep, use_prior=True)
+        # (lyapunov.py:585-587 never touches later batches): key_keep = the key at sorted position
+        # (below // batch + 1) * batch, computed AND consumed on the device
+        keep = select_kth(engine, -1, batch, folded, n)
+        folded = engine.fold(*dist_utils.gather_records(engine.finalize(folded, keep, use_prior=True)))
         if stats is not None:
-            rows = dist_utils.gather_words(record)
+            safe = _host_words(folded)[_hip.R_SAFE]
     if stats is not None:
-        stats['safe'] = int(sum(int(r[_hip.R_SAFE]) for r in rows))
+        stats['safe'] = safe
         stats['below'] = below
 
     # c_max = values[order[max_index]], max_index as in lyapunov.py:590
@@ -629,8 +580,163 @@ def prefix_rule(engine, n, batch, can_shrink, device, stats=None):
         c_key = last_safe if below > 0 else max_key
     else:
         last_batch_start = ((n - 1) // batch) * batch
-        c_key = select_kth(engine, last_batch_start - 1, device) if last_batch_start > 0 else max_key
+        if last_batch_start > 0:
+            state = _host_words(select_kth(engine, last_batch_start - 1, batch, folded, n))
+            c_key = (dist_utils.u64(state[_hip.S_KEY_V]), state[_hip.S_KEY_I])
+        else:
+            c_key = max_key
     return vbits_to_float(c_key[0])
+
+
+class _HipAdaptiveEngine(object):
+    """This rank's part of the adaptive branch: HIP kernels on device buffers (``sl_adaptive.hip``)."""
+
+    def __init__(self, lyap, can_shrink):
+        import torch
+        self.lyap, self.can_shrink = lyap, can_shrink
+        self.dev = lyap._ctx.torch_device
+        self.torch = torch
+        self.counts = torch.zeros(_hip.SORT_COUNT_WORDS, dtype=torch.int32, device=self.dev)
+        self.refinement = None
+
+    def _empty(self, *shape, dtype=None):
+        return self.torch.empty(shape, dtype=dtype or self.torch.int64, device=self.dev)
+
+    def pack(self):
+        """One row per cell of the shard: ``[vbits(V), index, decrease, threshold(tau=1), N, flags]``
+        from one sweep with ``tau = 1`` (``threshold(x, tau') = threshold(x, 1) tau'`` exactly)."""
+        ly, torch = self.lyap, self.torch
+        d = ly.discretization.ndim
+        count = ly._hi - ly._lo
+        records = torch.empty((max(count, 1), 2 + 2 * d), dtype=torch.float64, device=self.dev)
+        scratch_bits = torch.empty_like(ly._d_neg)
+        values = ly._d_values                  # (materialises V with the model as it is)
+        ly._builder.upload(ly.policy, ly.dynamics, ly.lyapunov_function, ly._lipschitz_lyapunov,
+                           ly._lipschitz_dynamics, 1.0)
+        try:
+            ly._ctx.lyap_sweep(ly._lo, ly._hi, ly._d_init, values, scratch_bits, ly._d_result, records)
+        finally:
+            ly._upload_model()
+        rows = self._empty(max(count, 1), _hip.ADAPTIVE_ROW_WORDS)
+        prior_bits = None if self.can_shrink else ly._d_safe
+        prior_ref = None if self.can_shrink else ly._refinement_shard()
+        ly._ctx.adaptive_pack(ly._lo, ly._hi, values, records, 2 + 2 * d, ly._d_init,
+                              prior_bits, prior_ref, rows)
+        return rows[:count]
+
+    def splitters(self, positions, n):
+        """Keys at the given sorted positions (device select states, one row each)."""
+        ly = self.lyap
+        shard = _HipShardEngine(ly)
+        states = self._empty(max(len(positions), 1), _hip.SELECT_WORDS)
+        for r, k in enumerate(positions):
+            states[r].copy_(select_kth(shard, k, 1, ly._d_folded, n))
+        return states[:len(positions)]
+
+    def partition(self, rows, splitters):
+        """Rows ordered by the rank that owns their sorted position -> ``(rows, counts per rank)``."""
+        ly = self.lyap
+        count = len(rows)
+        dest = self._empty(max(count, 1), dtype=self.torch.uint8)
+        ly._ctx.adaptive_dest(count, rows, splitters, len(splitters), dest)
+        perm = self._empty(max(count, 1))
+        buckets = self._empty(256)
+        ly._ctx.partition_by_digit(count, dest, perm, buckets, self.counts)
+        out = self._empty(max(count, 1), _hip.ADAPTIVE_ROW_WORDS)
+        ly._ctx.gather_rows(count, _hip.ADAPTIVE_ROW_WORDS, perm, rows, out)
+        return out[:count], buckets
+
+    def sort(self, rows):
+        """``order[q]`` = row at this rank's q-th sorted position, and the sorted value bits."""
+        ly = self.lyap
+        m = len(rows)
+        keys, vals = self._empty(max(m, 1)), self._empty(max(m, 1))
+        ly._ctx.adaptive_sort_keys(m, rows, keys, vals)
+        ly._ctx.sort_pairs(m, keys, vals, self._empty(max(m, 1)), self._empty(max(m, 1)), self.counts)
+        return vals[:m], keys[:m]
+
+    def analyse(self, rows, order, pos0, batch, max_refinement, safety_factor):
+        ly = self.lyap
+        m = len(rows)
+        info = self._empty(max(-(-m // batch), 1), 4, dtype=self.torch.int32)
+        first_break = self._empty(1)
+        ly._ctx.adaptive_analyse(m, pos0, batch, rows, order, ly.tau, safety_factor, max_refinement,
+                                 info, first_break)
+        return info, first_break
+
+    def apply(self, rows, order, info, pos0, batch, b_star, safety_factor):
+        ly = self.lyap
+        m = len(rows)
+        out = self._empty(max(m, 1), 3)
+        ly._ctx.adaptive_apply(m, pos0, batch, rows, order, info, ly.tau, safety_factor, b_star, out)
+        return out[:m]
+
+    def scatter(self, out_rows):
+        """Returned rows -> the shard's mask words and refinement array; -> safe cells (device)."""
+        ly = self.lyap
+        count = ly._hi - ly._lo
+        self.refinement = self.torch.zeros(max(count, 1), dtype=self.torch.int64, device=self.dev)[:count]
+        safe_count = self._empty(1)
+        ly._ctx.adaptive_scatter(ly._lo, ly._hi, len(out_rows), out_rows, ly._d_init, ly._d_safe,
+                                 self.refinement, safe_count)
+        return safe_count
+
+
+def _order_int(vbits):
+    """uint64 value bits -> int64 with the same order (for MAX all-reduces of int64 tensors)."""
+    v = (int(vbits) & _U64_MAX) ^ (1 << 63)
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def adaptive_rule(engine, n, batch, max_refinement, safety_factor, stats=None):
+    """The adaptive branch of ``lyapunov.py:540-582`` over sharded cells; returns ``c_max``.
+
+    ``engine`` (HIP in production, NumPy in the CPU tests of the multi-rank path) provides the
+    primitives; this function is the exchange: rank r owns the sorted positions ``[r per, (r+1) per)``
+    (``per`` a whole number of batches), rows travel there and back with one all-to-all each, the
+    first batch that ends the loop is a MIN all-reduce, ``c_max`` two small all-reduces."""
+    import torch
+    rank, world = dist_utils.rank_and_world()
+    per = max(-(-(-(-n // world)) // batch) * batch, batch)
+    pos0 = rank * per
+    rows = engine.pack()
+    send_counts = None
+    if world > 1:
+        splitters = engine.splitters([r * per for r in range(1, world)], n)
+        rows, buckets = engine.partition(rows, splitters)
+        send_counts = [int(v) for v in buckets[:world].cpu()]
+        rows, recv_counts = dist_utils.exchange_rows(rows, send_counts)
+    m = len(rows)
+    order, sorted_bits = engine.sort(rows)
+    info, first_break = engine.analyse(rows, order, pos0, batch, max_refinement, safety_factor)
+    b_star = int(dist_utils.allreduce_min_(first_break)[0])
+    out = engine.apply(rows, order, info, pos0, batch, b_star, safety_factor)
+    if world > 1:
+        out, _ = dist_utils.exchange_rows(out, recv_counts, send_counts)
+    safe = dist_utils.allreduce_sum_(engine.scatter(out))
+
+    # c_max = values[order[i + bound + refine_bound - 1]], i = start of the last batch the loop
+    # touched (lyapunov.py:590): its owner publishes bound and refine_bound, then the owner of that
+    # sorted position publishes the value bits (position -1 reads the LARGEST value, as in NumPy)
+    nbatches = -(-n // batch)
+    b_last = b_star if b_star < nbatches else nbatches - 1
+    mine = pos0 <= b_last * batch < pos0 + m
+    pair = torch.zeros(2, dtype=torch.int64, device=first_break.device)
+    if mine:
+        pair += info[b_last - pos0 // batch][[1, 3]].to(torch.int64)
+    pair = dist_utils.allreduce_sum_(pair).cpu()
+    position = b_last * batch + int(pair[0]) + int(pair[1]) - 1
+    word = torch.full((1,), -(1 << 63), dtype=torch.int64, device=first_break.device)
+    if position < 0:
+        if m:
+            word[0] = _order_int(int(sorted_bits[m - 1]))
+    elif pos0 <= position < pos0 + m:
+        word[0] = _order_int(int(sorted_bits[position - pos0]))
+    word = int(dist_utils.allreduce_max_(word)[0])
+    if stats is not None:
+        stats['safe'] = int(safe[0])
+        stats['b_star'] = b_star
+    return vbits_to_float((word & _U64_MAX) ^ (1 << 63))
 
 
 class _CMaxView(dict):
@@ -669,64 +775,107 @@ def perturb_actions(states, actions, perturbations, limits=None):
     return pairs
 
 
-def _index_to_state_device(grid, idx):
-    """``GridWorld.index_to_state`` (functions.py:714-731) for a device tensor of flat indices."""
+def _safe_words_device(lyapunov):
+    """Mask words of the WHOLE grid on the device (every rank holds them after ``update_safe_set``;
+    a host array the caller edited is packed first)."""
     import torch
-    dev = idx.device
-    rem, cols = idx, []
-    for n in reversed([int(v) for v in grid.num_points]):
-        cols.append(rem % n)
-        rem = torch.div(rem, n, rounding_mode='floor')
-    ijk = torch.stack(cols[::-1], dim=1).to(torch.float64)
-    unit = torch.from_numpy(np.asarray(grid.unit_maxes, dtype=np.float64)).to(dev)
-    offset = torch.from_numpy(np.asarray(grid.offset, dtype=np.float64)).to(dev)
-    return ijk * unit + offset                                   # multiply, then add
+    n = lyapunov.discretization.nindex
+    dev = lyapunov._ctx.torch_device
+    if lyapunov._safe_host_valid and not lyapunov._safe_dev_valid:
+        d_bytes = torch.from_numpy(lyapunov._safe_host.view(np.uint8)).to(dev)
+        words = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+        lyapunov._ctx.bytes_to_bits(n, d_bytes, words)
+        return words
+    return lyapunov._d_safe_full if lyapunov._d_safe_full is not None else lyapunov._d_safe
 
 
-def _state_to_index_device(grid, states):
-    """``GridWorld.state_to_index`` (functions.py:733-752) on the device (round half to even)."""
-    import torch
-    dev = states.device
-    lo = torch.from_numpy(np.asarray(grid.limits[:, 0], dtype=np.float64)).to(dev)
-    hi = torch.from_numpy(np.asarray(grid.limits[:, 1], dtype=np.float64)).to(dev)
-    inv = torch.from_numpy(1. / np.asarray(grid.unit_maxes, dtype=np.float64)).to(dev)
-    offset = torch.from_numpy(np.asarray(grid.offset, dtype=np.float64)).to(dev)
-    ijk = torch.round((torch.minimum(torch.maximum(states, lo), hi) - offset) * inv).to(torch.int64)
-    flat = torch.zeros(len(states), dtype=torch.int64, device=dev)
-    for k, n in enumerate(int(v) for v in grid.num_points):
-        flat = flat * n + ijk[:, k]
-    return flat
+class _SampleKernels(object):
+    """Device steps of ``get_safe_sample`` (``sl_sample.hip``, ``sl_partition_by_digit``,
+    ``sl_sort_pairs``) on the engine context of a Lyapunov object."""
 
+    def __init__(self, lyapunov):
+        import torch
+        self.torch, self.ctx, self.dev = torch, lyapunov._ctx, lyapunov._ctx.torch_device
+        self.counts = torch.zeros(_hip.SORT_COUNT_WORDS, dtype=torch.int32, device=self.dev)
 
-def _unique_rows_device(rows):
-    """Unique rows in the byte-wise order of ``safe_learning/utilities.py:496-516`` (memcmp of the
-    raw float64 bytes) on the device."""
-    import torch
-    n, k = rows.shape
-    as_bytes = rows.contiguous().view(torch.uint8).reshape(n, 8 * k)
-    return torch.unique(as_bytes, dim=0).contiguous().view(torch.float64).reshape(-1, k)
+    def _empty(self, *shape, dtype=None):
+        return self.torch.empty(shape, dtype=dtype or self.torch.int64, device=self.dev)
+
+    def safe_indices(self, words, n):
+        """Flat indices of the set bits, ascending (``np.where(safe_set)``, lyapunov.py:729)."""
+        d_bytes = self._empty(max(-(-n // 8) * 8, 8), dtype=self.torch.uint8)
+        self.ctx.bits_to_bytes(n, words, d_bytes)
+        perm, buckets = self._empty(n), self._empty(256)
+        self.ctx.partition_by_digit(n, d_bytes, perm, buckets, self.counts)   # unsafe cells first
+        count = int(buckets[1])
+        return perm[n - count:]
+
+    def take(self, rows, picks):
+        """``rows[picks]`` for a 1-D or 2-D int64 / float64 tensor (``sl_gather_rows``)."""
+        words = 1 if rows.dim() == 1 else rows.shape[1]
+        out = self.torch.empty((len(picks),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=self.dev)
+        self.ctx.gather_rows(len(picks), words, picks, rows.contiguous(), out)
+        return out
+
+    def states(self, indices):
+        d = self._d
+        out = self._empty(max(len(indices), 1), d, dtype=self.torch.float64)[:len(indices)]
+        self.ctx.index_to_state(len(indices), indices.contiguous(), out)
+        return out
+
+    def pairs(self, states, actions, perturbations, limits):
+        """``perturb_actions`` (lyapunov.py:609-651): every state with every perturbed, clipped
+        action; with limits, duplicate rows dropped in the byte-wise order of ``unique_rows``."""
+        torch = self.torch
+        pert = torch.from_numpy(np.ascontiguousarray(np.atleast_2d(perturbations), dtype=np.float64)).to(self.dev)
+        lim = None
+        if limits is not None:
+            lim = torch.from_numpy(np.ascontiguousarray(limits, dtype=np.float64)).to(self.dev)
+        count, d, m = len(states), states.shape[1], actions.shape[1]
+        total, width = count * len(pert), d + m
+        rows = self._empty(max(total, 1), width, dtype=torch.float64)[:total]
+        self.ctx.perturb_pairs(count, d, m, states.contiguous(), actions.contiguous(), len(pert), pert,
+                               lim, rows)
+        if limits is None or total == 0:
+            return rows
+        # np.unique of the rows viewed as raw bytes: stable radix sorts, last column first
+        order = torch.arange(total, dtype=torch.int64, device=self.dev)
+        keys, tmp_k, tmp_v = self._empty(total), self._empty(total), self._empty(total)
+        for column in range(width - 1, -1, -1):
+            self.ctx.rows_sort_key(total, width, column, rows, order, keys)
+            self.ctx.sort_pairs(total, keys, order, tmp_k, tmp_v, self.counts)
+        flags = self._empty(total, dtype=torch.uint8)
+        self.ctx.rows_duplicate_flags(total, width, rows, order, flags)
+        perm, buckets = self._empty(total), self._empty(256)
+        self.ctx.partition_by_digit(total, flags, perm, buckets, self.counts)     # first of each group first
+        keep = self.take(order, perm[:int(buckets[0])])
+        return self.take(rows, keep)
 
 
 def get_safe_sample(lyapunov, perturbations=None, limits=None, positive=False,
                     num_samples=None, actions=None):
     """Most uncertain safe state-action pair for the next measurement (``lyapunov.py:657-797``).
 
-    Everything that scales with the safe set stays on the GPU: the safe cells come from the
-    device mask, their states / perturbed actions / duplicate removal are tensor operations, the
-    GP posterior, ``V`` and ``L_v`` at the candidates come from the HIP kernels (explicit-point
-    mode), the membership test ``safe_set[state_to_index(mean)]`` and the arg-max run on the
-    device.  Only the winning row travels to the host.  Returns ``(state_action[1, d+m], bound)``."""
+    Everything that scales with the safe set runs in HIP kernels on the device: the safe cells are
+    compacted from the bit mask (stable partition), their states / perturbed and clipped actions /
+    duplicate removal (radix sorts in ``unique_rows``' byte order) are ``sl_sample.hip`` kernels,
+    the GP posterior, ``V`` and ``L_v`` at the candidates come from the explicit-point entry, the
+    membership test ``safe_set[state_to_index(mean)]`` and the arg-max are kernels too.  Only the
+    winning row travels to the host.  Returns ``(state_action[1, d+m], bound)``."""
     import warnings
     import torch
     from . import _evaluate
     grid = lyapunov.discretization
-    d = grid.ndim
-    safe_bytes = lyapunov._safe_bytes_device()                   # uint8[nindex] on the device
-    safe_idx = torch.nonzero(safe_bytes, as_tuple=False).reshape(-1)
+    d, n = grid.ndim, grid.nindex
+    lyapunov._upload_model()                 # the kernels below read the grid of the engine's model
+    kernels = _SampleKernels(lyapunov)
+    kernels._d = d
+    words = _safe_words_device(lyapunov)
+    safe_idx = kernels.safe_indices(words, n)
     if num_samples is not None and len(safe_idx) > num_samples:
         pick = np.random.choice(len(safe_idx), num_samples, replace=True)     # the reference's draw
-        safe_idx = safe_idx[torch.from_numpy(pick).to(safe_idx.device)]
-    safe_states = _index_to_state_device(grid, safe_idx)
+        safe_idx = kernels.take(safe_idx, torch.from_numpy(pick.astype(np.int64)).to(safe_idx.device))
+    safe_states = kernels.states(safe_idx)
     safe_actions = None
     if perturbations is None:
         host_states = safe_states.cpu().numpy()
@@ -734,48 +883,36 @@ def get_safe_sample(lyapunov, perturbations=None, limits=None, positive=False,
         state_actions = torch.from_numpy(np.column_stack([m.ravel() for m in mesh])).to(safe_states.device)
     else:
         safe_actions = _evaluate.policy(lyapunov.policy, safe_states)
-        state_actions = _perturb_actions_device(safe_states, safe_actions, perturbations, limits)
+        state_actions = kernels.pairs(safe_states, safe_actions, perturbations, limits)
 
     def evaluate(pairs):
+        count = len(pairs)
         mean, std = _evaluate.dynamics(lyapunov.dynamics, pairs[:, :d].contiguous(),
                                        pairs[:, d:].contiguous())
         value, lv = _evaluate.value(lyapunov.lyapunov_function, mean.contiguous(),
                                     lyapunov._lipschitz_lyapunov)
-        bound = std[:, [0]].clone()
-        scaled = lv * std
-        error = scaled[:, [0]].clone()
-        for k in range(1, std.shape[1]):                         # left to right like the oracle
-            bound = bound + std[:, [k]]
-            error = error + scaled[:, [k]]
-        return mean, bound, ((value + error) < lyapunov.c_max)[:, 0]
+        bound = torch.empty(max(count, 1), dtype=torch.float64, device=pairs.device)[:count]
+        inside = torch.empty(max(count, 1), dtype=torch.uint8, device=pairs.device)[:count]
+        lyapunov._ctx.sample_bounds(count, d, lv.shape[1], std.contiguous(), lv.contiguous(),
+                                    value.contiguous(), lyapunov.c_max, bound, inside)
+        return mean.contiguous(), bound, inside
+
+    def best_of(bound, mask):
+        out = torch.empty(2, dtype=torch.int64, device=bound.device)
+        lyapunov._ctx.argmax_masked(len(bound), bound, mask, out)
+        index, seen = (int(v) for v in out.cpu())
+        return index, seen
 
     mean, bound, maps_inside = evaluate(state_actions)
     if not positive:
-        maps_inside &= safe_bytes[_state_to_index_device(grid, mean)].to(torch.bool)
-    if not bool(maps_inside.any()):
+        lyapunov._ctx.state_membership(len(mean), mean, words, maps_inside)
+    best, seen = best_of(bound, maps_inside)
+    if seen == 0:
         warnings.warn("No safe state-action pairs found! Using backup policy ...", RuntimeWarning)
-        state_actions = _perturb_actions_device(safe_states, safe_actions, np.array([[0.]]), limits)
+        state_actions = kernels.pairs(safe_states, safe_actions, np.array([[0.]]), limits)
         _, bound, _ = evaluate(state_actions)
-        best = int(torch.argmax(bound[:, 0]))
-        return state_actions[[best]].cpu().numpy(), float(bound[best, 0])
-    candidates = state_actions[maps_inside]
-    bound = bound[maps_inside]
-    best = int(torch.argmax(bound[:, 0]))
-    return candidates[[best]].cpu().numpy(), float(bound[best, 0])
-
-
-def _perturb_actions_device(states, actions, perturbations, limits):
-    """``perturb_actions`` (``lyapunov.py:609-651``) on device tensors."""
-    import torch
-    dev = states.device
-    pert = torch.from_numpy(np.atleast_2d(np.asarray(perturbations, dtype=np.float64))).to(dev)
-    count, state_dim = len(pert), states.shape[1]
-    acts = actions.repeat_interleave(count, dim=0) + pert.repeat(len(states), 1)
-    if limits is not None:
-        lim = torch.from_numpy(np.asarray(limits, dtype=np.float64)).to(dev)
-        acts = torch.minimum(torch.maximum(acts, lim[:, 0]), lim[:, 1])
-    pairs = torch.cat((states.repeat_interleave(count, dim=0), acts), dim=1)
-    return _unique_rows_device(pairs) if limits is not None else pairs
+        best, _ = best_of(bound, None)
+    return state_actions[[best]].cpu().numpy(), float(bound[best])
 
 
 def get_lyapunov_region(lyapunov, discretization, init_node):

@@ -531,22 +531,96 @@ def test_ties_in_values(sl, small_batches):
 
 
 def test_select_kth(sl):
+    """The device-resident radix select (sl_select_begin / _hist / _digit) on explicit values with
+    ties, NaNs and signed zeros; k given by the caller, k derived on the device from a folded
+    record (the batch behind the first failure, lyapunov.py:585-587), and k beyond the grid."""
     import torch
+    from safe_learning_amd import _hip
     from safe_learning_amd.benchmarks import build_lyapunov
+    from safe_learning_amd.distributed import u64
     case = cases.make_case("pendulum", num_points=37, dynamics="linear")
     lyap = build_lyapunov(case)
     rng = np.random.default_rng(5)
-    vals = rng.normal(size=lyap.discretization.nindex).round(1)          # many ties
+    n = lyap.discretization.nindex
+    vals = rng.normal(size=n).round(1)          # many ties
     vals[rng.choice(len(vals), 10)] = np.nan
     vals[rng.choice(len(vals), 10)] = -0.0
+    lyap._values_implicit = False
     lyap._d_values.copy_(torch.from_numpy(vals))
     order = np.argsort(vals, kind="stable")
     from safe_learning_amd.lyapunov import vbits_to_float, select_kth, _HipShardEngine
+    engine = _HipShardEngine(lyap)
+
+    def key_of(state):
+        words = state.cpu().numpy()
+        return u64(words[_hip.S_KEY_V]), int(words[_hip.S_KEY_I]), int(words[_hip.S_NONE])
+
     for k in [0, 1, 17, 500, len(vals) // 2, len(vals) - 11, len(vals) - 1]:
-        vbits, index = select_kth(_HipShardEngine(lyap), k, lyap._ctx.torch_device)
-        assert index == order[k]
+        vbits, index, none = key_of(select_kth(engine, k, 1, lyap._d_folded, n))
+        assert index == order[k] and not none
         got, ref = vbits_to_float(vbits), vals[order[k]]
         assert (np.isnan(got) and np.isnan(ref)) or got == ref
+    # k from the device: (count_below // batch + 1) * batch
+    record = torch.zeros(_hip.RESULT_WORDS, dtype=torch.int64, device=lyap._ctx.torch_device)
+    for below, batch in ((0, 7), (123, 50), (n - 30, 100), (n - 1, 10), (n, 13)):
+        record[_hip.R_BELOW] = below
+        k = (below // batch + 1) * batch
+        vbits, index, none = key_of(select_kth(engine, -1, batch, record, n))
+        if k >= n:
+            assert none and vbits == (1 << 64) - 1 and index == (1 << 63) - 1
+        else:
+            assert not none and index == order[k]
+
+
+def test_implicit_values_are_bit_identical(sl, small_batches):
+    """Quadratic V: the sweep and the streaming passes recompute the ordering keys from the cell
+    index (sl_values_implicit; 8 cells of a grid row per thread) instead of reading the values
+    array.  Masks, safe sets, c_max, counters and the radix select must be bit for bit those of the
+    explicit path, for can_shrink on and off, on grids with and without whole bytes per row."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    shapes = [("1d", dict(num_points=1000)), ("pendulum", dict(num_points=[17, 43], dynamics="linear", tau_scale=0.02)),
+              ("pendulum", dict(num_points=64, dynamics="analytic", tau_scale=0.01)),
+              ("cartpole", dict(num_points=[5, 6, 7, 16], dynamics="linear", tau_scale=0.01)),
+              ("cartpole", dict(num_points=9, n_gp=60, tau_scale=0.0))]
+    for name, kw in shapes:
+        case = cases.make_case(name, **kw)
+        implicit, explicit = build_lyapunov(case), build_lyapunov(case)
+        # rows of whole bytes: a thread's 8 cells share the row prefix (else V stays explicit)
+        expected = case["num_points"][-1] % 8 == 0
+        assert implicit._values_implicit == expected
+        assert implicit._d_values_buffer is None or not expected
+        explicit._values_implicit = False
+        olyap = cases.oracle_lyapunov(case)
+        rng = np.random.default_rng(1)
+        for step, shrink in enumerate((True, False, False, True)):
+            if step == 1:                          # hand-marked cells beyond the level set
+                extra = rng.choice(implicit.discretization.nindex, 40, replace=False)
+                for ly in (implicit, explicit, olyap):
+                    ly.safe_set[extra] = True
+                    ly.tau = case["tau"] * 3 if case["tau"] else 0.0
+            for ly in (implicit, explicit, olyap):
+                ly.update_safe_set(can_shrink=shrink)
+            assert implicit._d_values_buffer is None or not expected       # never materialised
+            assert_array_equal(implicit.safe_set, explicit.safe_set)
+            assert implicit.c_max == explicit.c_max and implicit.safe_count == explicit.safe_count
+            if case["dynamics"]["kind"] != "gp":
+                assert_array_equal(implicit.safe_set, olyap.safe_set)
+                assert implicit.c_max == olyap.c_max
+        # reading the attribute materialises the very numbers the kernels used
+        assert_array_equal(implicit.values, olyap.values)
+    # a grid whose last np.linspace point is not index_to_state's: the keys stay explicit
+    case = cases.make_case("pendulum", num_points=[17, 43], dynamics="linear")
+    case["limits"] = [[-1.0, 1.03], [-0.97, 1.0]]
+    grid = sl.GridWorld(case["limits"], case["num_points"])
+    exact = all((n - 1) * u + o == hi for n, u, o, (_, hi) in
+                zip(grid.num_points, grid.unit_maxes, grid.offset, grid.limits))
+    lyap = build_lyapunov(case)
+    assert lyap._values_implicit == exact
+    olyap = cases.oracle_lyapunov(case)
+    lyap.update_safe_set()
+    olyap.update_safe_set()
+    assert_array_equal(lyap.safe_set, olyap.safe_set)
+    assert lyap.c_max == olyap.c_max
 
 
 def test_bits_bytes_roundtrip(sl):
