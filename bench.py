@@ -491,8 +491,15 @@ def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if world == 1 and args.config == "C4" and not args.num_points and not args.n_gp:
-                traffic, source = pmc["bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 " \
-                    "FETCH_SIZE x2 + WRITE_SIZE of this command, separate passes; not this run)"
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import pmc_traffic
+                if pmc.get("source_sha256") == pmc_traffic.kernel_source_sha():
+                    traffic, source = pmc["bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 " \
+                        "FETCH_SIZE x2 + WRITE_SIZE of this command on this version of sl_gp4.hip, " \
+                        "separate passes, tools/profile_r04.sh; not this run)"
+                else:
+                    source = "profiles/pmc_traffic.json was measured on another version of sl_gp4.hip: " \
+                        "re-run tools/profile_r04.sh"
         except (OSError, ValueError, KeyError):
             pass
         return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,

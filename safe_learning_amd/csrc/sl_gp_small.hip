@@ -31,7 +31,10 @@ typedef double sl_d4 __attribute__((ext_vector_type(4)));
 typedef double sl_d2 __attribute__((ext_vector_type(2)));
 
 namespace gps {
-constexpr int WAVES = 8;          // wavefronts per workgroup
+// wavefronts per workgroup: 8 (two per SIMD), or 12 - three per SIMD, which caps the kernel at 168
+// registers (a handful of spills in the table check of the general flavour) and hides more of the
+// latency of its table look-ups; taken when the per-wavefront scratch of 12 wavefronts still fits LDS
+constexpr int WAVES_MIN = 8, WAVES_MID = 10, WAVES_MAX = 12;
 constexpr int PRB = 8;            // row blocks (of 16 rows) per pass: 128 rows
 // fragment pairs (1 KiB each: two slabs of 4 training points x 16 rows) of the lower triangle in
 // front of row block I: row block i needs the slab pairs 0 .. 2 i + 1
@@ -39,8 +42,8 @@ __host__ __device__ constexpr int tri_offset(int I) { return I * (I + 1); }
 }  // namespace gps
 
 // ALDS: the A fragments are read from the workgroup's LDS copy (else from L2).
-template <bool GENERAL, int DT, int MT, bool ALDS>
-__global__ __launch_bounds__(64 * gps::WAVES) void k_gp_small(
+template <bool GENERAL, int DT, int MT, bool ALDS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_gp_small(
     const SlDevModel M, const SlGpDev gp, SlAux aux_arg, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
@@ -266,7 +269,7 @@ static size_t small_lds_doubles(sl_ctx* ctx, int p, int d) {
         const SlGpHeadHost& h = ctx->gp_heads[k];
         small += (size_t)((p * h.n_pad + 1) & ~1) + (size_t)((h.n_pad * h.dout + 1) & ~1);
     }
-    return small + (size_t)gps::WAVES * 64 * (p + 1 + 2 * d);
+    return small + (size_t)gps::WAVES_MIN * 64 * (p + 1 + 2 * d);
 }
 
 static size_t lds_capacity(bool general) {
@@ -302,32 +305,47 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
         small += (size_t)((p * h.n_pad + 1) & ~1) + (size_t)((h.n_pad * h.dout + 1) & ~1);
         tri += (size_t)tri_offset(h.n_pad / 16) * 128;
     }
-    const size_t scratch = (size_t)WAVES * 64 * (p + 1 + 2 * d);
     const size_t cap = lds_capacity(GENERAL);
-    const bool alds = sizeof(double) * (small + tri + scratch) <= cap;
+    auto scratch_of = [&](int waves) { return (size_t)waves * 64 * (p + 1 + 2 * d); };
+    auto fits = [&](int waves, bool with_tri) {
+        return sizeof(double) * (small + (with_tri ? tri : 0) + scratch_of(waves)) <= cap;
+    };
+    // the factor in LDS matters most, then the third wavefront per SIMD
+    const char* wenv = getenv("SL_GP_SMALL_WAVES");
+    const int wmax = wenv ? atoi(wenv) : WAVES_MAX;
+    int waves = WAVES_MIN;
+    bool alds = fits(WAVES_MIN, true);
+    // (the runtime-dimension instantiations need all 256 registers: two wavefronts per SIMD)
+    if (DT > 0 && wmax >= WAVES_MAX && fits(WAVES_MAX, alds)) waves = WAVES_MAX;
+    else if (DT > 0 && wmax >= WAVES_MID && fits(WAVES_MID, alds)) waves = WAVES_MID;   // (five per two SIMDs)
+    const size_t scratch = scratch_of(waves);
     const int head_doubles = (int)(small + (alds ? tri : 0));
     const size_t lds = sizeof(double) * ((size_t)head_doubles + scratch);
     if (lds > cap)
         return sl_fail(ctx, SL_ERR_UNSUPPORTED, "k_gp_small: %zu bytes of LDS needed", lds);
-    int64_t blocks = (ntiles + WAVES - 1) / WAVES;
+    int64_t blocks = (ntiles + waves - 1) / waves;
     if (blocks > ctx->num_cu) blocks = ctx->num_cu;
     if (blocks < 1) blocks = 1;
     *nblocks = (int)blocks;
     SlAux aux{ctx->d_tri, ctx->d_net};
-#define SL_GPS_GO(ALDS_)                                                                           \
+#define SL_GPS_GO(ALDS_, W_)                                                                       \
     do {                                                                                           \
-        auto kern = k_gp_small<GENERAL, DT, MT, ALDS_>;                                            \
+        auto kern = k_gp_small<GENERAL, DT, MT, ALDS_, W_>;                                        \
         SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), lds, ctx->stream, model, \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * W_), lds, ctx->stream, model,   \
                            ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,      \
                            ctx->d_partials, d_dbg, head_doubles, d_points);                     \
     } while (0)
-    if (alds) SL_GPS_GO(true); else SL_GPS_GO(false);
+    if constexpr (DT > 0) {
+        if (waves == WAVES_MAX) { if (alds) SL_GPS_GO(true, WAVES_MAX); else SL_GPS_GO(false, WAVES_MAX); }
+        if (waves == WAVES_MID) { if (alds) SL_GPS_GO(true, WAVES_MID); else SL_GPS_GO(false, WAVES_MID); }
+    }
+    if (waves == WAVES_MIN) { if (alds) SL_GPS_GO(true, WAVES_MIN); else SL_GPS_GO(false, WAVES_MIN); }
 #undef SL_GPS_GO
     SL_HIP_CHECK(ctx, hipGetLastError());
-    sl_note_kernel(ctx, false, "k_gp_small<general=%d, d=%d, m=%d, Linv in %s> (%d head(s))", (int)GENERAL, DT,
-                   MT, alds ? "LDS" : "L2", ctx->h_gp.nheads);
+    sl_note_kernel(ctx, false, "k_gp_small<general=%d, d=%d, m=%d, Linv in %s, %d wavefronts> (%d head(s))",
+                   (int)GENERAL, DT, MT, alds ? "LDS" : "L2", waves, ctx->h_gp.nheads);
     return SL_OK;
 }
 

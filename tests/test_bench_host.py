@@ -48,3 +48,16 @@ def test_reference_faithful_leg_small():
     assert done >= 1600 and seconds > 0
     model, blas, threads = bench._cpu_info()
     assert isinstance(model, str) and isinstance(blas, str) and threads >= 1
+
+
+def test_traffic_measurement_belongs_to_the_shipped_kernel():
+    """roofline.traffic is read from profiles/pmc_traffic.json (separate rocprofv3 counter passes,
+    tools/profile_r04.sh): the file records the sha256 of sl_gp4.hip it was measured on, and a kernel
+    edit without a new measurement fails here (bench.py then reports traffic = null)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as handle:
+        pmc = json.load(handle)
+    assert pmc["source_sha256"] == pmc_traffic.kernel_source_sha()
+    assert pmc["bytes_per_launch"] > 2.2e9            # at least the algorithmic bytes

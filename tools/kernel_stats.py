@@ -10,7 +10,7 @@ def main():
     print("|---|---|---|---|---|")
     for name, calls, total, avg, pct in cur.execute(
             "select name, total_calls, total_duration, average, percentage from top_kernels"):
-        print("| `%s` | %d | %.3f | %.3f | %.3f |" % (name.split("(")[0], calls, total / 1e3, avg / 1e3, pct))
+        print("| `%s` | %d | %.3f | %.3f | %.3f |" % (name.replace("(anonymous namespace)::", "").split("(")[0], calls, total / 1e3, avg / 1e3, pct))
 
 
 if __name__ == "__main__":

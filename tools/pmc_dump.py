@@ -13,7 +13,7 @@ def main():
         for name, counter, total, ndisp in rows:
             if sub in name:
                 print("%-28s %-14.6g dispatches=%d  %s" % (counter, total / max(ndisp, 1), ndisp,
-                                                          name.split("(")[0][:60]))
+                                                          name.replace("(anonymous namespace)::", "").split("(")[0][:60]))
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@ profiles/pmc_traffic.json, which bench.py reports as roofline.traffic.
 
 Corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE
 are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x, so it is doubled."""
+import hashlib
 import json
 import os
 import sqlite3
@@ -26,6 +27,14 @@ def per_dispatch(db, counter, kernel_substr):
     raise SystemExit("kernel %s not found in %s" % (kernel_substr, db))
 
 
+def kernel_source_sha():
+    """sha256 of the kernel's source: bench.py and tests/test_bench_host.py refuse a measurement
+    that was taken on another version of sl_gp4.hip."""
+    path = os.path.join(ROOT, "safe_learning_amd", "csrc", "sl_gp4.hip")
+    with open(path, "rb") as handle:
+        return hashlib.sha256(handle.read()).hexdigest()
+
+
 def main():
     fetch_db, write_db = sys.argv[1], sys.argv[2]
     workload = sys.argv[3] if len(sys.argv) > 3 else "cartpole 128^4, 1024-point GP"
@@ -34,10 +43,11 @@ def main():
     out = {"workload": workload, "kernel": kname.split("(")[0],
            "fetch_size_kib_reported": fetch_kib, "write_size_kib_reported": write_kib,
            "bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0,
+           "source_sha256": kernel_source_sha(),
            "note": "L2<->fabric bytes per launch of the GP sweep kernel: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                    "(KiB units, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes): L2 misses "
                    "of the inverse Cholesky factor's fragments served by the Infinity Cache (an upper bound "
-                   "of the HBM reads) + mask words and set-up scratch; profiles/r03_summary.md."}
+                   "of the HBM reads) + mask words and set-up scratch; profiles/r04_summary.md."}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(out)
