@@ -34,7 +34,9 @@ namespace gps {
 // wavefronts per workgroup: 8 (two per SIMD), or 12 - three per SIMD, which caps the kernel at 168
 // registers (a handful of spills in the table check of the general flavour) and hides more of the
 // latency of its table look-ups; taken when the per-wavefront scratch of 12 wavefronts still fits LDS
-constexpr int WAVES_MIN = 8, WAVES_MID = 10, WAVES_MAX = 12;
+constexpr int WAVES_MIN = 8, WAVES_MAX = 12;
+// (a 10-wavefront workgroup - what fits beside a factor in LDS - measured SLOWER than 8 on the
+// single-head table sweep: 2.31 against 2.22 ms, profiles/r04_configs.jsonl vs r04_gp_small_waves_ab.txt)
 constexpr int PRB = 8;            // row blocks (of 16 rows) per pass: 128 rows
 // fragment pairs (1 KiB each: two slabs of 4 training points x 16 rows) of the lower triangle in
 // front of row block I: row block i needs the slab pairs 0 .. 2 i + 1
@@ -317,7 +319,6 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
     bool alds = fits(WAVES_MIN, true);
     // (the runtime-dimension instantiations need all 256 registers: two wavefronts per SIMD)
     if (DT > 0 && wmax >= WAVES_MAX && fits(WAVES_MAX, alds)) waves = WAVES_MAX;
-    else if (DT > 0 && wmax >= WAVES_MID && fits(WAVES_MID, alds)) waves = WAVES_MID;   // (five per two SIMDs)
     const size_t scratch = scratch_of(waves);
     const int head_doubles = (int)(small + (alds ? tri : 0));
     const size_t lds = sizeof(double) * ((size_t)head_doubles + scratch);
@@ -339,7 +340,6 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
     } while (0)
     if constexpr (DT > 0) {
         if (waves == WAVES_MAX) { if (alds) SL_GPS_GO(true, WAVES_MAX); else SL_GPS_GO(false, WAVES_MAX); }
-        if (waves == WAVES_MID) { if (alds) SL_GPS_GO(true, WAVES_MID); else SL_GPS_GO(false, WAVES_MID); }
     }
     if (waves == WAVES_MIN) { if (alds) SL_GPS_GO(true, WAVES_MIN); else SL_GPS_GO(false, WAVES_MIN); }
 #undef SL_GPS_GO

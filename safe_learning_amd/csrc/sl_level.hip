@@ -20,78 +20,10 @@
 
 namespace {
 
-constexpr int CPT = 8;        // cells per thread: one byte of every bit mask
+constexpr int CPT = SL_ROW_CELLS;        // cells per thread: one byte of every bit mask
 
-// ---- V of 8 consecutive cells ---------------------------------------------------------------
-// DT = 0: read from `values`; DT = 1..4: quadratic V of a DT-dimensional grid from the index
-template <int DT>
-struct RowValues {
-    static constexpr int D = DT > 0 ? DT : 1, L = D - 1;
-    double lin_pre[D], x[D];
-    int64_t ijk[SL_D];
-
-    __device__ __forceinline__ void point(const SlDevModel& M, int k) {
-        const double t = (double)(int)ijk[k] * M.m.grid.unit_maxes[k];               // functions.py:731
-        const double s = t + M.m.grid.offset[k];
-        x[k] = (ijk[k] == M.m.grid.num_points[k] - 1) ? M.m.grid.upper[k] : s;       // np.linspace
-    }
-
-    __device__ __forceinline__ void start_row(const SlDevModel& M, int64_t idx) {
-        sl_unravel(M.m.grid, M.gf, D, idx, ijk);
-#pragma unroll
-        for (int k = 0; k < L; ++k) point(M, k);
-        if (L > 0) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                double b = x[0] * M.m.value.matrix[0][j];
-#pragma unroll
-                for (int k = 1; k < L; ++k) { const double t = x[k] * M.m.value.matrix[k][j]; b = b + t; }
-                lin_pre[j] = b;
-            }
-        }
-    }
-
-    __device__ __forceinline__ double cell(const SlDevModel& M) {
-        point(M, L);
-        double vx = 0.0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const double tc = x[L] * M.m.value.matrix[L][j];
-            const double lin = L > 0 ? lin_pre[j] + tc : tc;
-            const double q = lin * x[j];
-            vx = (j == 0) ? q : (vx + q);
-        }
-        return M.m.value.negate ? (vx * -1.0) : vx;
-    }
-
-    // V of cells i0 .. i0 + 7.  DT > 0: the eight cells lie in ONE row of the last axis (the host
-    // admits the implicit mode only for rows of whole bytes, sl_values_implicit), so the row is
-    // unravelled once and there is no carry.
-    __device__ __forceinline__ void eight(const SlDevModel& M, const double* __restrict__ values,
-                                          int64_t lo, int64_t hi, int64_t i0, double* v8) {
-        if (DT == 0) {
-#pragma unroll
-            for (int c = 0; c < CPT; ++c) v8[c] = (i0 + c < hi) ? values[i0 + c - lo] : 0.0;
-            return;
-        }
-        start_row(M, i0);
-        const int first = (int)ijk[L];
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            ijk[L] = first + c;
-            v8[c] = cell(M);
-        }
-    }
-};
-
-// sl_vbits (order-preserving float64 -> uint64, -0 = +0, NaN last) in eight instructions
-__device__ __forceinline__ uint64_t vbits_fast(double v) {
-    const double z = v + 0.0;                             // -0 -> +0 (round to nearest); NaN stays
-    union { double d; uint64_t u; } c;
-    c.d = z;
-    const uint64_t flip = (uint64_t)((int64_t)c.u >> 63) | 0x8000000000000000ull;
-    return (z != z) ? ~0ull : (c.u ^ flip);
-}
+// (the V of 8 consecutive cells and the fast key map live in sl_model.h - SlRowValues, sl_vbits_fast -
+// so that the CPU suite compiles and checks the very same code)
 
 template <int DT>
 __device__ __forceinline__ void constants_to_vgprs(SlDevModel& M) {
@@ -127,7 +59,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_finalize_dev(
     uint64_t ls_v = 0ull, mx_v = 0ull;
     int64_t ls_i = -1, mx_i = -1;
     int64_t n_below = 0, n_safe = 0;
-    RowValues<DT> row;
+    SlRowValues<DT> row;
     const int64_t span = (int64_t)SL_BLOCK * CPT;
     for (int64_t base = lo + (int64_t)blockIdx.x * span; base < hi; base += (int64_t)gridDim.x * span) {
         const int64_t i0 = base + (int64_t)threadIdx.x * CPT;
@@ -139,7 +71,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_finalize_dev(
         unsigned safe8 = 0u;
         auto one = [&](int c) {
             const int64_t idx = i0 + c;
-            const uint64_t vb = vbits_fast(v8[c]);
+            const uint64_t vb = sl_vbits_fast(v8[c]);
             const bool below = sl_key_less(vb, idx, star.vbits, star.index);
             const bool kept = ((prev8 >> c) & 1u) && !sl_key_less(vb, idx, keep.vbits, keep.index);
             const bool safe = below || kept || ((init8 >> c) & 1u);
@@ -260,7 +192,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_select_hist(
     const uint64_t prefix = state->prefix, vbits_equal = state->key.vbits;
     const int shift = byte * 8;
     const uint64_t himask = (byte == 7) ? 0ull : (~0ull << (shift + 8));
-    RowValues<DT> row;
+    SlRowValues<DT> row;
     const int64_t span = (int64_t)SL_BLOCK * CPT;
     for (int64_t base = lo + (int64_t)blockIdx.x * span; base < hi; base += (int64_t)gridDim.x * span) {
         const int64_t i0 = base + (int64_t)threadIdx.x * CPT;
@@ -269,7 +201,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_select_hist(
         row.eight(M, values, lo, hi, i0, v8);
         auto one = [&](int c) {
             const int64_t idx = i0 + c;
-            const uint64_t vb = vbits_fast(v8[c]);
+            const uint64_t vb = sl_vbits_fast(v8[c]);
             uint64_t key;
             bool take;
             if (which == 0) { key = vb; take = true; }
@@ -347,15 +279,7 @@ extern "C" int sl_values_implicit(sl_ctx* ctx, int* out) {
     if (!ctx || !out) return sl_fail(ctx, SL_ERR_INVALID, "sl_values_implicit: NULL argument");
     *out = 0;
     if (!ctx->model_set) return SL_OK;
-    const SlDevModel& M = ctx->h_model;
-    const int d = M.m.grid.d;
-    if (M.m.value.kind != SL_V_QUADRATIC || d < 1 || d > 4) return SL_OK;
-    if (M.m.grid.num_points[d - 1] % CPT) return SL_OK;           // a thread's 8 cells share a row
-    for (int k = 0; k < d; ++k) {
-        volatile double t = (double)(M.m.grid.num_points[k] - 1) * M.m.grid.unit_maxes[k];
-        volatile double s = t + M.m.grid.offset[k];
-        if (s != M.m.grid.upper[k]) return SL_OK;
-    }
+    if (!sl_values_implicit_ok(ctx->h_model.m)) return SL_OK;
     *out = 1;
     return SL_OK;
 }

@@ -1116,3 +1116,95 @@ SL_HD double sl_vbits_to_double(uint64_t b) {
 SL_HD bool sl_key_less(uint64_t va, int64_t ia, uint64_t vb, int64_t ib) {
     return (va < vb) || (va == vb && ia < ib);
 }
+
+// =============================================================================================
+// V of 8 consecutive cells of a grid row, recomputed from the flat index (sl_level.hip)
+// =============================================================================================
+#define SL_ROW_CELLS 8
+
+// May the ordering keys V(all_points[i]) (lyapunov.py:305-322, 512) be recomputed from the cell
+// index instead of read?  Quadratic V, 1..4 dimensions, a last axis of whole bytes of the bit masks
+// (a thread's 8 cells share a row), and np.linspace points (last point = the upper limit,
+// functions.py:612-638) that equal index_to_state (functions.py:728-731) bit for bit.
+SL_HD bool sl_values_implicit_ok(const sl_model_desc& m) {
+    const int d = m.grid.d;
+    if (m.value.kind != SL_V_QUADRATIC || d < 1 || d > 4) return false;
+    if (m.grid.num_points[d - 1] % SL_ROW_CELLS) return false;
+    for (int k = 0; k < d; ++k) {
+        volatile double t = (double)(m.grid.num_points[k] - 1) * m.grid.unit_maxes[k];
+        volatile double s = t + m.grid.offset[k];
+        if (s != m.grid.upper[k]) return false;
+    }
+    return true;
+}
+
+// sl_vbits (order-preserving float64 -> uint64, -0 = +0, NaN last) in eight instructions
+SL_HD uint64_t sl_vbits_fast(double v) {
+    const double z = v + 0.0;                             // -0 -> +0 (round to nearest); NaN stays
+    union { double d; uint64_t u; } c;
+    c.d = z;
+    const uint64_t flip = (uint64_t)((int64_t)c.u >> 63) | 0x8000000000000000ull;
+    return (z != z) ? ~0ull : (c.u ^ flip);
+}
+
+// DT = 0: read from `values`; DT = 1..4: quadratic V of a DT-dimensional grid from the index - the
+// ordered sums of functions.py:1534-1539 with the prefix over the leading coordinates shared by the
+// row (the same numbers, rounding included, as sl_quadratic on sl_index_to_grid_point)
+template <int DT>
+struct SlRowValues {
+    static constexpr int D = DT > 0 ? DT : 1, L = D - 1;
+    double lin_pre[D], x[D];
+    int64_t ijk[SL_D];
+
+    SL_HD void point(const SlDevModel& M, int k) {
+        const double t = (double)(int)ijk[k] * M.m.grid.unit_maxes[k];               // functions.py:731
+        const double s = t + M.m.grid.offset[k];
+        x[k] = (ijk[k] == M.m.grid.num_points[k] - 1) ? M.m.grid.upper[k] : s;       // np.linspace
+    }
+
+    SL_HD void start_row(const SlDevModel& M, int64_t idx) {
+        sl_unravel(M.m.grid, M.gf, D, idx, ijk);
+#pragma unroll
+        for (int k = 0; k < L; ++k) point(M, k);
+        if (L > 0) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double b = x[0] * M.m.value.matrix[0][j];
+#pragma unroll
+                for (int k = 1; k < L; ++k) { const double t = x[k] * M.m.value.matrix[k][j]; b = b + t; }
+                lin_pre[j] = b;
+            }
+        }
+    }
+
+    SL_HD double cell(const SlDevModel& M) {
+        point(M, L);
+        double vx = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const double tc = x[L] * M.m.value.matrix[L][j];
+            const double lin = L > 0 ? lin_pre[j] + tc : tc;
+            const double q = lin * x[j];
+            vx = (j == 0) ? q : (vx + q);
+        }
+        return M.m.value.negate ? (vx * -1.0) : vx;
+    }
+
+    // V of cells i0 .. i0 + 7.  DT > 0: the eight cells lie in ONE row of the last axis
+    // (sl_values_implicit_ok), so the row is unravelled once and there is no carry.
+    SL_HD void eight(const SlDevModel& M, const double* values, int64_t lo, int64_t hi, int64_t i0,
+                     double* v8) {
+        if (DT == 0) {
+#pragma unroll
+            for (int c = 0; c < SL_ROW_CELLS; ++c) v8[c] = (i0 + c < hi) ? values[i0 + c - lo] : 0.0;
+            return;
+        }
+        start_row(M, i0);
+        const int first = (int)ijk[L];
+#pragma unroll
+        for (int c = 0; c < SL_ROW_CELLS; ++c) {
+            ijk[L] = first + c;
+            v8[c] = cell(M);
+        }
+    }
+};

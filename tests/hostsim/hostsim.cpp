@@ -154,6 +154,34 @@ double hs_exp_nonpos(double x) { return sl_exp_nonpos(x); }
 void hs_sincos(double x, double* s, double* c) { sl_sincos(x, s, c); }
 
 uint64_t hs_vbits(double v) { return sl_vbits(v); }
+uint64_t hs_vbits_fast(double v) { return sl_vbits_fast(v); }
+int hs_values_implicit_ok(const sl_model_desc* desc) { return sl_values_implicit_ok(*desc) ? 1 : 0; }
+
+// the ordering keys as the streaming passes recompute them (sl_level.hip: SlRowValues<D>::eight, a
+// thread's 8 cells of a row) and as k_values writes them (sl_quadratic on the np.linspace points)
+int hs_row_values(const sl_model_desc* desc, int64_t n, double* rows, double* points) {
+    SlDevModel M;
+    make_model(desc, &M);
+    const int d = M.m.grid.d;
+    if (n % SL_ROW_CELLS) return -1;
+    for (int64_t i0 = 0; i0 < n; i0 += SL_ROW_CELLS) {
+        double v8[SL_ROW_CELLS];
+        switch (d) {
+            case 1: { SlRowValues<1> r; r.eight(M, nullptr, 0, n, i0, v8); break; }
+            case 2: { SlRowValues<2> r; r.eight(M, nullptr, 0, n, i0, v8); break; }
+            case 3: { SlRowValues<3> r; r.eight(M, nullptr, 0, n, i0, v8); break; }
+            case 4: { SlRowValues<4> r; r.eight(M, nullptr, 0, n, i0, v8); break; }
+            default: return -2;
+        }
+        for (int c = 0; c < SL_ROW_CELLS; ++c) rows[i0 + c] = v8[c];
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        double x[SL_P];
+        sl_index_to_grid_point(M.m.grid, M.gf, d, i, x);
+        points[i] = sl_quadratic(M.m.value, d, x);
+    }
+    return 0;
+}
 double hs_vbits_to_double(uint64_t b) { return sl_vbits_to_double(b); }
 
 }  // extern "C"

@@ -340,3 +340,64 @@ def test_sincos(hostsim):
     err = np.abs(got - ref)
     # (absolute floor: at multiples of pi/2 the reduced argument carries the 1e-32 of the 3-piece pi/2)
     assert np.all(err <= 2 * np.spacing(np.maximum(np.abs(ref), 1e-300)) + 1e-30)
+
+
+# ---- round 4: the ordering keys recomputed in the streaming passes (sl_level.hip) ---------------------
+@pytest.mark.parametrize("name,kw,limits", [
+    ("1d", dict(num_points=1000), None),
+    ("pendulum", dict(num_points=[17, 40], dynamics="linear"), None),
+    ("pendulum", dict(num_points=[9, 24], dynamics="linear"), [[-1.0, 1.0], [-0.5, 0.75]]),
+    ("cartpole", dict(num_points=[5, 6, 7, 16], dynamics="linear"), None),
+    ("cartpole", dict(num_points=8, dynamics="linear"), None),
+    ("cartpole", dict(num_points=[3, 4, 5, 24], dynamics="linear"), [[-1, 1], [-2, 2], [-0.5, 0.5], [-4, 4]]),
+])
+def test_row_values_equal_the_value_pass_bit_for_bit(hostsim, name, kw, limits):
+    """SlRowValues (8 cells of a grid row per thread, the prefix of the ordered sums shared) against
+    sl_quadratic on the np.linspace points (what k_values writes) and against the oracle's values."""
+    case = cases.make_case(name, **kw)
+    if limits is not None:
+        case["limits"] = [[float(a), float(b)] for a, b in limits]
+    grid, desc = _describe(case)
+    assert hostsim.hs_values_implicit_ok(C.byref(desc)) == 1
+    n = grid.nindex
+    rows, points = np.zeros(n), np.zeros(n)
+    assert hostsim.hs_row_values(C.byref(desc), C.c_int64(n), rows.ctypes.data_as(C.c_void_p),
+                                 points.ctypes.data_as(C.c_void_p)) == 0
+    assert_array_equal(rows, points)
+    olyap = cases.oracle_lyapunov(case)
+    assert_array_equal(rows, olyap.values)
+    # a negated quadratic (-V as in the reinforcement-learning notebooks)
+    desc.value.negate = 1
+    assert hostsim.hs_row_values(C.byref(desc), C.c_int64(n), rows.ctypes.data_as(C.c_void_p),
+                                 points.ctypes.data_as(C.c_void_p)) == 0
+    assert_array_equal(rows, points)
+    assert_array_equal(rows, -olyap.values)
+
+
+def test_values_stay_explicit_where_the_index_points_differ(hostsim):
+    """np.linspace pins the last point of an axis to the upper limit; where index * unit + offset
+    rounds to something else (or the last axis is not whole bytes, or V is a table) the passes read V."""
+    case = cases.make_case("pendulum", num_points=[17, 40], dynamics="linear")
+    case["limits"] = [[-1.0, 1.03], [-0.97, 1.0]]
+    grid, desc = _describe(case)
+    exact = all((int(n) - 1) * u + o == hi for n, u, o, (_, hi) in
+                zip(grid.num_points, grid.unit_maxes, grid.offset, grid.limits))
+    assert hostsim.hs_values_implicit_ok(C.byref(desc)) == int(exact) == 0
+    _, desc = _describe(cases.make_case("pendulum", num_points=[17, 43], dynamics="linear"))
+    assert hostsim.hs_values_implicit_ok(C.byref(desc)) == 0            # 43 cells per row
+    from safe_learning_amd import _hip
+    _, desc = _describe(cases.make_case("pendulum", num_points=[17, 40], dynamics="linear"))
+    assert hostsim.hs_values_implicit_ok(C.byref(desc)) == 1
+    desc.value.kind = _hip.V_TRI
+    assert hostsim.hs_values_implicit_ok(C.byref(desc)) == 0            # a table V is read
+
+
+def test_fast_key_map_equals_the_reference_map(hostsim):
+    hostsim.hs_vbits_fast.restype = C.c_uint64
+    hostsim.hs_vbits_fast.argtypes = [C.c_double]
+    rng = np.random.default_rng(0)
+    samples = np.concatenate([rng.normal(size=2000) * 10.0 ** rng.integers(-300, 300, 2000),
+                              [0.0, -0.0, np.inf, -np.inf, np.nan, -np.nan, 5e-324, -5e-324,
+                               np.finfo(float).max, np.finfo(float).min]])
+    for v in samples:
+        assert hostsim.hs_vbits_fast(float(v)) == hostsim.hs_vbits(float(v)), v
