@@ -18,7 +18,7 @@ ROOT = os.path.dirname(HERE)
 # translation units: (object stem, source, extra flags).  sl_gp4.hip is compiled once per state
 # dimension (its unrolled MFMA streams make one instantiation a minute of compile time; the four
 # jobs run side by side).
-GP4_R = int(os.environ.get("SL_GP4_R", "4"))     # row blocks per wavefront of k_gp_sweep4 (sl_gp4.hip)
+GP4_R = 4                                        # row blocks per wavefront of k_gp_sweep4 (sl_gp4.hip)
 GP4_FLAGS = ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0", "-save-temps=obj", "-DSL_GP4_R=%d" % GP4_R]
 UNITS = [("sl_kernels", "sl_kernels.hip", []), ("sl_gp", "sl_gp.hip", []),
          ("sl_bellman", "sl_bellman.hip", []), ("sl_bellman4", "sl_bellman4.hip", ["-save-temps=obj"]),

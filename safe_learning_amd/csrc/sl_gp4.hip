@@ -9,15 +9,13 @@
 //    tile takes four instructions: the A fragment (rows) stays, the k_x fragment (cells) is read
 //    from LDS rotated by 0/4/8/12 lanes per row of 16.
 //  * FP64 VALU work shares that pipe (measured: no overlap with FP64 MFMAs, own wave or partner).
-//    Two shapes of a workgroup (SL_GP4_R, build time):
-//      R = 4 (shipped): four wavefronts with 256 registers each - 4 row blocks x 4 cell blocks x
-//        4 rotations = 64 FP64 accumulators per lane in a[0:127] - 256-row panels and 79 KB of LDS,
-//        so that TWO workgroups share a CU and cover each other's non-MFMA phases (generation,
-//        barrier, per-tile prologue and epilogue); training inputs and alpha' come from L2.
-//      R = 8 (round 2): one wavefront per SIMD with the whole 512-register file (128
-//        accumulators in a[0:255], 512-row panels: 24 instead of 40 chunk generations per tile,
-//        half the operand traffic per MFMA); its non-MFMA phases can ride in the MFMA stream as
-//        "fillers" (struct Fill).  2 % slower than R = 4 (profiles/r03_summary.md).
+//    The workgroup: four wavefronts with 256 registers each - 4 row blocks x 4 cell blocks x
+//    4 rotations = 64 FP64 accumulators per lane in a[0:127] - 256-row panels and 79 KB of LDS,
+//    so that TWO workgroups share a CU and cover each other's non-MFMA phases (generation,
+//    barrier, per-tile prologue and epilogue); training inputs and alpha' come from L2.
+//    (Round 2's shape - one wavefront per SIMD with the whole 512-register file, 512-row panels,
+//    24 instead of 40 chunk generations per tile, its non-MFMA phases riding in the MFMA stream as
+//    "fillers" - measured 2 % slower, profiles/r03_summary.md, and left the source in round 4.)
 //  * The accumulators sit at FIXED accumulator registers and are only touched by inline-asm MFMA
 //    groups.  With C++ accumulator variables every branch around the MFMAs (the lower triangle
 //    makes the set of active row blocks chunk dependent) costs phi copies, out-of-place MFMAs and
@@ -56,18 +54,15 @@ typedef unsigned sl_u4 __attribute__((ext_vector_type(4)));
 
 namespace gp4 {
 
-// SL_GP4_R row blocks per wavefront.  8: one wavefront per SIMD with all 512 registers (128 FP64
-// accumulators, 512-row panels).  4: 256 registers (64 accumulators, 256-row panels) and at most
-// 80 KB of LDS per workgroup, so that TWO workgroups share a CU: they work on different tiles at
-// their own pace, and whatever one of them does outside its MFMA stream (k_x generation, the
-// barrier, the per-tile prologue and epilogue) runs under the other one's MFMAs.
+// R row blocks per wavefront: 256 registers (64 accumulators, 256-row panels) and at most 80 KB of
+// LDS per workgroup, so that TWO workgroups share a CU: they work on different tiles at their own
+// pace, and whatever one of them does outside its MFMA stream (k_x generation, the barrier, the
+// per-tile prologue and epilogue) runs under the other one's MFMAs.
 #ifndef SL_GP4_R
 #define SL_GP4_R 4
 #endif
 constexpr int R = SL_GP4_R, CB = 4, W = 4;
 constexpr int NACC = R * CB * 4;           // FP64 accumulators per lane (2 registers each)
-constexpr bool TWO_PER_CU = R <= 4;        // second workgroup on the CU: training inputs and alpha'
-                                           // stay in L2, the |a|^2 partials are folded per wavefront
 constexpr int C = 16 * CB;                 // cells per tile
 constexpr int RP = 16 * R * W;             // rows per panel (512)
 constexpr int RB = R * W;                  // row blocks per panel
@@ -85,7 +80,7 @@ constexpr int RB = R * W;                  // row blocks per panel
 constexpr int RUNC = 2 * SL_P + 2;         // per wavefront: x0[SL_P], step[SL_P], a^2, Q (see Fill)
 constexpr int KXS2 = CB * 128 + 4;
 constexpr int KXBUF = 8 * KXS2;
-static_assert(R == 8 || R == 4, "512- or 256-row panels");
+static_assert(R == 4, "256-row panels (tools/audit_gp4.py is told the same number by the build)");
 
 struct AFrag { sl_d2 v[R]; };
 struct BFrag { sl_d2 v[CB]; };
@@ -102,14 +97,7 @@ struct BFrag { sl_d2 v[CB]; };
     "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", SL_A10(1), SL_A10(2), SL_A10(3),   \
         SL_A10(4), SL_A10(5), SL_A10(6), SL_A10(7), SL_A10(8), SL_A10(9), SL_A10(10), SL_A10(11),   \
         "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
-#if SL_GP4_R == 8
-#define SL_ALL_AGPRS                                                                               \
-    SL_AGPRS_0_127, "a128", "a129", SL_A10(13), SL_A10(14), SL_A10(15), SL_A10(16), SL_A10(17),    \
-        SL_A10(18), SL_A10(19), SL_A10(20), SL_A10(21), SL_A10(22), SL_A10(23), SL_A10(24), "a250", \
-        "a251", "a252", "a253", "a254", "a255"
-#else
 #define SL_ALL_AGPRS SL_AGPRS_0_127
-#endif
 
 template <int BASE>
 __device__ __forceinline__ void acc_zero16() {
@@ -176,11 +164,7 @@ __device__ __forceinline__ void group(const sl_d2& av, const BFrag& b) {
                    "v"(b.v[2].x), "v"(b.v[2].y), "v"(b.v[3].x), "v"(b.v[3].y), "i"(N0), "i"(N0 + 1), \
                    "i"(N1), "i"(N1 + 1), "i"(N2), "i"(N2 + 1), "i"(N3), "i"(N3 + 1)                 \
                  : __VA_ARGS__)
-#ifdef SL_GP4_CLOBBER_ALL
-#define SL_GP4_ASM_R(TEXT, R_, H_) SL_GP4_ASM_CL(TEXT, SL_ALL_AGPRS)
-#else
 #define SL_GP4_ASM_R(TEXT, R_, H_) SL_GP4_ASM_CL(TEXT, SL_GP4_CL_##R_##H_)
-#endif
 #define SL_GP4_ASM_H(TEXT, H_)                                     \
     do {                                                           \
         if constexpr (RI == 0) SL_GP4_ASM_R(TEXT, 0, H_);          \
@@ -208,165 +192,16 @@ __device__ __forceinline__ void group(const sl_d2& av, const BFrag& b) {
 #undef SL_GP4_Y01
 #undef SL_GP4_Y23
 }
-// ---- work of the other phases, issued INSIDE the MFMA stream ---------------------------------------
-// One wavefront per SIMD means that everything a wavefront does between two chunks - the posterior
-// mean of the chunk (16 MFMAs behind a round trip of operand loads), the generation of the next
-// k_x chunk (two 20-deep FMA chains, a 16-deep chain of multiplies, LDS writes and their wait),
-// the barrier - leaves the matrix pipe idle: 0.8 us per chunk for ~90 FP64 instructions.  Cut into
-// pieces of two or three instructions and issued between the MFMAs of the chunk in flight, the
-// same work costs its issue slots only: every dependent instruction finds its operand ready (32+
-// cycles between slots).  A piece runs in slot I = ((slab pair * 4 + rotation) * 4 + k) of the
-// chunk, k = position inside the first MFMA group of the rotation (see rotation<>).
+// ---- slots inside the MFMA stream -------------------------------------------------------------------
+// rotation<> offers four issue slots behind the first MFMA pairs of every rotation (slot I = ((slab
+// pair * 4 + rotation) * 4 + k) of the chunk) to a filler object.  Round 3 measured the posterior
+// mean and the k_x generation of the next chunk cut into such pieces ("fillers", with the 512-row,
+// one-wavefront-per-SIMD shape of the workgroup): +0.7 %, and 2 % behind the two-workgroup shape that
+// ships, whose partner workgroup covers those phases (profiles/r03_summary.md) - the filler code and
+// the 512-row shape were removed in round 4; the slots stay empty.
 struct NoFill {
     static constexpr bool has(int) { return false; }
     template <int I> __device__ __forceinline__ void step() {}
-};
-template <bool MEAN, bool GEN, int P>
-struct Fill {
-    // posterior mean of the chunk in flight: mean[dd][cell] += sum_j alpha'[j][dd] k_x[j][cell] as
-    // 16 MFMAs (A = alpha'^T, rows dd = lane & 3, zero rows beyond dout come from the padded LDS
-    // copy; B = the rotation-0 k_x fragment of this wavefront's own cell block)
-    const double* kxr;          // LDS: this lane's (k, cell) item of the chunk in flight
-    const double* ap;           // alpha' of the chunk, this lane's column: LDS copy [point][4] (zero
-    int astride;                // padded), or the [point][dout] array in L2 (arow: the lane's row
-    bool arow;                  // dd = lane & 3 exists)
-    double* macc;               // [4] accumulators in rotation
-    sl_d2 kx[4];
-    double a0[4], a1[4];
-    // k_x of the NEXT chunk, lane = training point, the wavefront's 16 cells one affine run:
-    // e_{c+1} = e_c rho_c, rho_{c+1} = rho_c Q
-    const double* xs;           // LDS: scaled training inputs, this lane's point, stride n_pad
-    int n_pad;
-    const double* run;          // LDS: x0[SL_P], dlt[SL_P], a2, Q of the run (broadcast reads)
-    double variance;
-    double* w_lo;               // LDS write bases of the next chunk's buffer (cells 0-11 / 12-15)
-    double* w_hi;
-    bool odd;                   // odd training point: stores run one cell behind (w_lo / w_hi are
-                                // then one slot lower)
-    double xv[P], x0[P], dl[P], a2, qs, z, bj, x1, x2, k1, k2, r1, r2, q1, q2, e, rho, ep;
-
-    static constexpr int G0 = 14;                       // first generation slot
-    static constexpr int NCELL = SL_GP4_WRITE_SKEW ? 17 : 16;     // store steps
-    static constexpr bool has(int i) {
-        return (MEAN && (i < 4 || i == 5 || (i >= 6 && i < 10) || i == 11)) ||
-               (GEN && i >= G0 && i < G0 + 8 + P + 13 + NCELL);
-    }
-    template <int H> __device__ __forceinline__ void mean_loads(int j) {
-        kx[j] = *reinterpret_cast<const sl_d2*>(kxr + (4 * H + j) * KXS2);
-        const double t0 = ap[(8 * (4 * H + j)) * astride], t1 = ap[(8 * (4 * H + j) + 4) * astride];
-        a0[j] = arow ? t0 : 0.0;
-        a1[j] = arow ? t1 : 0.0;
-    }
-    __device__ __forceinline__ void mean_mfmas() {
-        // Accumulators in vector registers; a dependent FP64 MFMA must not issue right behind its
-        // producer (no interlock: the second product was lost): four accumulators in rotation
-        // keep three MFMAs between a write and its reuse.  The trailing wait states retire the
-        // results before any other reader (a register copy by the compiler).
-        // (s_nop 1: two wait states between a VALU write - a register copy of an accumulator
-        // by the compiler - and an MFMA that reads the register)
-        asm volatile("s_nop 1\n\t"
-                     "v_mfma_f64_4x4x4_4b_f64 %0, %4, %5, %0\n\t"
-                     "v_mfma_f64_4x4x4_4b_f64 %1, %6, %7, %1\n\t"
-                     "v_mfma_f64_4x4x4_4b_f64 %2, %8, %9, %2\n\t"
-                     "v_mfma_f64_4x4x4_4b_f64 %3, %10, %11, %3\n\t"
-                     "v_mfma_f64_4x4x4_4b_f64 %0, %12, %13, %0\n\t"
-                     "v_mfma_f64_4x4x4_4b_f64 %1, %14, %15, %1\n\t"
-                     "v_mfma_f64_4x4x4_4b_f64 %2, %16, %17, %2\n\t"
-                     "v_mfma_f64_4x4x4_4b_f64 %3, %18, %19, %3\n\t"
-                     "s_nop 7"
-                     : "+v"(macc[0]), "+v"(macc[1]), "+v"(macc[2]), "+v"(macc[3])
-                     : "v"(a0[0]), "v"(kx[0].x), "v"(a1[0]), "v"(kx[0].y), "v"(a0[1]), "v"(kx[1].x),
-                       "v"(a1[1]), "v"(kx[1].y), "v"(a0[2]), "v"(kx[2].x), "v"(a1[2]), "v"(kx[2].y),
-                       "v"(a0[3]), "v"(kx[3].x), "v"(a1[3]), "v"(kx[3].y));
-    }
-    template <int I> __device__ __forceinline__ void step() {
-        if constexpr (MEAN) {
-            if constexpr (I < 4) mean_loads<0>(I);
-            else if constexpr (I == 5) mean_mfmas();
-            else if constexpr (I >= 6 && I < 10) mean_loads<1>(I - 6);
-            else if constexpr (I == 11) mean_mfmas();
-        }
-#if defined(SL_GP4_FILLDBG) && SL_GP4_FILLDBG == 2               // (timing experiments: LDS writes only)
-        if constexpr (GEN && I >= G0 + 8 + P + 13 && I < G0 + 8 + P + 13 + 16) {   // (unskewed)
-            constexpr int c = I - G0 - (8 + P + 13);
-            (c < 12 ? w_lo : w_hi)[2 * c] = variance;
-        }
-#else
-        if constexpr (GEN && I >= G0) {
-            constexpr int K = I - G0;
-            if constexpr (K == 0) {
-#pragma unroll
-                for (int q = 0; q < P; ++q) xv[q] = xs[q * n_pad];
-            } else if constexpr (K == 1) {
-#pragma unroll
-                for (int q = 0; q < P; ++q) x0[q] = run[q];
-            } else if constexpr (K == 2) {
-#pragma unroll
-                for (int q = 0; q < P; ++q) dl[q] = run[SL_P + q];
-                a2 = run[2 * SL_P];
-                qs = run[2 * SL_P + 1];
-                z = 0.0;
-                bj = 0.0;
-            } else if constexpr (K < 3 + P) {                    // one input dimension per slot
-                const double dq = xv[K - 3] - x0[K - 3];
-                z = fma(dq, dq, z);
-                bj = fma(dq, dl[K - 3], bj);
-            } else if constexpr (K == 3 + P) {                   // exp arguments (sl_exp_nonpos twice,
-                x1 = -0.5 * z;                                   // the two chains side by side)
-                x2 = fmin(bj - 0.5 * a2, 700.0);
-            } else if constexpr (K == 4 + P) {
-                x1 = x1 < -800.0 ? -800.0 : x1;
-                x2 = x2 < -800.0 ? -800.0 : x2;
-            } else if constexpr (K == 5 + P) {
-                k1 = rint(x1 * 1.4426950408889634);
-                k2 = rint(x2 * 1.4426950408889634);
-            } else if constexpr (K == 6 + P) {
-                r1 = fma(k1, -6.93147180369123816490e-01, x1);
-                r2 = fma(k2, -6.93147180369123816490e-01, x2);
-            } else if constexpr (K == 7 + P) {
-                r1 = fma(k1, -1.90821492927058770002e-10, r1);
-                r2 = fma(k2, -1.90821492927058770002e-10, r2);
-                q1 = 1.6059043836821613e-10;
-                q2 = 1.6059043836821613e-10;
-            } else if constexpr (K < 8 + P + 13) {               // the 13 Horner steps
-                constexpr double C[13] = {2.08767569878681e-09, 2.505210838544172e-08,
-                                          2.755731922398589e-07, 2.7557319223985893e-06,
-                                          2.48015873015873e-05, 1.984126984126984e-04,
-                                          1.3888888888888889e-03, 8.333333333333333e-03,
-                                          4.1666666666666664e-02, 1.6666666666666666e-01, 0.5, 1.0, 1.0};
-                q1 = fma(q1, r1, C[K - 8 - P]);
-                q2 = fma(q2, r2, C[K - 8 - P]);
-                if constexpr (K == 8 + P + 12) {
-                    e = variance * ldexp(q1, (int)k1);
-                    rho = ldexp(q2, (int)k2);
-                }
-            } else if constexpr (K < 8 + P + 13 + NCELL) {       // the 16 cells, one per slot
-                constexpr int c = K - (8 + P + 13);
-#if !defined(SL_GP4_FILLDBG) || SL_GP4_FILLDBG != 1            // (timing experiments: 1 = no LDS writes)
-#if SL_GP4_WRITE_SKEW
-                // Lanes of odd training points store one cell BEHIND the even ones.  For one cell
-                // the 16 lanes of a store group reach only 8 of the 16 bank pairs (row k and row
-                // k + 1 of a fragment share the slot of a cell - the fragment reads need that):
-                // every store was a two-way conflict.  One slot apart, the two halves of a group
-                // interleave: 17 conflict-free stores instead of 16 conflicting ones.
-                const double val = odd ? ep : e;
-                double* at = (c == 12) ? (odd ? w_lo : w_hi) : (c < 12 ? w_lo : w_hi);
-                if (c == 0) { if (!odd) at[0] = val; }
-                else if (c == 16) { if (odd) at[2 * c] = val; }
-                else at[2 * c] = val;
-                ep = e;
-#else
-                (c < 12 ? w_lo : w_hi)[2 * c] = e;
-#endif
-#endif
-                if constexpr (c < 15) {
-                    e *= rho;
-                    rho *= qs;
-                }
-            }
-        }
-#endif
-    }
 };
 
 // One rotation of a slab pair against the row blocks r >= R0, operand loads INSIDE the MFMA
@@ -476,25 +311,12 @@ template <class F>
 __device__ __forceinline__ void chunk_any(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
                                           const int (&rowoff)[R], int q, int ch, int lane,
                                           const int (&boff)[4], F& f) {
-    if constexpr (R == 8) {
-        switch (q) {
-            case 1: chunk<1, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-            case 2: chunk<2, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-            case 3: chunk<3, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-            case 4: chunk<4 % R, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-            case 5: chunk<5 % R, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-            case 6: chunk<6 % R, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-            case 7: chunk<7 % R, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-            default: chunk<0, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-        }
-    } else {
         switch (q) {
             case 1: chunk<1, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
             case 2: chunk<2, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
             case 3: chunk<3, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
             default: chunk<0, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
         }
-    }
 }
 
 // exp of two arguments (sl_exp_nonpos twice), the two dependent FMA chains written alternately: a
@@ -537,7 +359,7 @@ __device__ __forceinline__ double uniform(double v) {
 
 // XSG: the scaled training inputs do not fit LDS and are read from L2 during generation.
 template <int DT, int MT, bool XSG>
-__global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
+__global__ __launch_bounds__(256, 2) void k_gp_sweep4(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
@@ -550,8 +372,8 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
     double* xs_l = smem;                           // [p][n_pad]
     double* alpha_l = xs_l + xs_doubles;           // [n_pad][dout] when it fits
     double* kx_l = alpha_l + alpha_doubles;        // [2][KXBUF]
-    constexpr int PSS = TWO_PER_CU ? W : W * 4;    // planes of |a|^2 partials
-    double* part_ss = kx_l + 2 * KXBUF;            // [W][4 rotations][C]  (TWO_PER_CU: [W][C])
+    constexpr int PSS = W;                         // planes of |a|^2 partials: one per wavefront
+    double* part_ss = kx_l + 2 * KXBUF;            // [W][C]
     double* cell_mean = part_ss + PSS * C;         // [C][SL_D]
     double* cell_err = cell_mean + C * SL_D;       // [C][SL_D]
     double* cin = cell_err + C * SL_D;             // [C][SL_P] scaled GP inputs of the tile's cells
@@ -575,23 +397,8 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
     uint64_t best_v = ~0ull;
     int64_t best_i = INT64_MAX;
     int staged_head = -1;
-#ifdef SL_GP4_TIMING     // development: s_memtime stamps of wavefront 0, printed by workgroup 0
-    unsigned long long tm_chunk[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tm_n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tm_barrier = 0, tm_head = 0, tm_tail = 0, tm_total = 0, tm_tiles = 0, tm_first = 0;
-    unsigned long long tm_x[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tm_last = 0;
-#define SL_TMX(k) do { const unsigned long long n__ = __builtin_readcyclecounter(); tm_x[k] += n__ - tm_last; tm_last = n__; } while (0)
-    const unsigned long long tm_begin = __builtin_readcyclecounter();
-#define SL_TM() __builtin_readcyclecounter()
-#endif
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-#ifdef SL_GP4_TIMING
-        const unsigned long long tm_t0 = SL_TM();
-        unsigned long long tm_loop0 = 0, tm_loop1 = 0;
-        tm_last = tm_t0;
-#else
-#define SL_TMX(k) do { } while (0)
-#endif
         const int64_t tile_base = lo + tile * C;
         if (tile_base >= hi) {                     // padding tile: only clears mask bits
             if (tid == 0) neg_bits[(tile_base - lo) >> 6] = 0ull;
@@ -626,9 +433,7 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
                 for (int q = 0; q < SL_P; ++q)
                     cin[(16 * wave + lcol) * SL_P + q] = (q < p) ? xg[q] * hd.inv_ls[q] : 0.0;
             }
-            SL_TMX(0);      // cin
             __syncthreads();
-            SL_TMX(1);      // barrier
             // Where the input is affine in the cell index, z_j(c) = |X_j - x(c)|^2 is quadratic in
             // c and k_x a Gaussian sequence.  Split the wavefront's 16 cells into maximal affine
             // runs (second differences vanish inside a run; a saturation kink or the end of a grid
@@ -698,14 +503,6 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
                 runc[wave * RUNC + 2 * SL_P] = a2;
                 runc[wave * RUNC + 2 * SL_P + 1] = qstep;
             }
-            // fast tiles: one affine run per wavefront, operands of the fillers in LDS
-            // Two workgroups per CU cover each other's phases: no fillers there (and no registers
-            // for their state: 128 vector registers next to the 128 accumulator registers).
-            // (16: force the slow path)
-            const bool fast = !TWO_PER_CU && !XSG && alpha_doubles > 0 && runs == 1u && !direct &&
-                              !(skip & 27);
-
-            SL_TMX(2);      // runs, run constants
             double macc[4] = {0.0, 0.0, 0.0, 0.0};   // posterior-mean accumulators (see mean_pass)
 
             // k_x chunk `ch` -> LDS buffer `buf` (lane = training point 64 ch + lane)
@@ -829,9 +626,7 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
 
             const int npanels = n_pad / RP;
             for (int pan = 0; pan < npanels; ++pan) {
-                SL_TMX(11);
                 acc_zero_all();
-                SL_TMX(3);  // zeroing
                 int rowoff[R];                     // byte offset of each owned row block's fragments
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -841,97 +636,26 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
                 constexpr int CPP = RP / 64;                     // chunks per panel (its diagonal band)
                 const int nchunks = (pan + 1) * CPP;
                 const int first_new_chunk = pan * (RP / 64);     // chunks not generated before
-                // (on fast tiles the last chunk of the previous panel has generated chunk 0)
-                if (!(fast && pan > 0) && !(skip & 1)) generate(0, 0);
-                SL_TMX(4);  // rowoff, first generate
+                if (!(skip & 1)) generate(0, 0);
                 __syncthreads();
-                SL_TMX(5);
-#ifdef SL_GP4_TIMING
-                if (pan == 0) tm_loop0 = SL_TM();
-#endif
                 for (int ch = 0; ch < nchunks; ++ch) {
                     const int buf = ch & 1;
                     const int q = __builtin_amdgcn_readfirstlane(ch - CPP * pan);
                     const double* kxb = kx_l + buf * KXBUF;
-#ifdef SL_GP4_TIMING
-                    const unsigned long long tm_c0 = SL_TM();
-#endif
-                    bool filled = false;
-                    if constexpr (!TWO_PER_CU) if (fast) {
-                        filled = true;
-                        // posterior mean of this chunk and k_x of the next one ride in the MFMA
-                        // stream (Fill).  The last chunk of a panel prepares chunk 0 for the next
-                        // panel (after the last panel: unused, the buffer is free).
-                        constexpr int PT = DT + MT;
-                        const int nxt = ch + 1 < nchunks ? ch + 1 : 0;
-                        // (odd training points store one cell behind: their bases sit one slot lower)
-                        const bool odd = SL_GP4_WRITE_SKEW && (lane & 1);
-                        double* wnext = kx_l + (buf ^ 1) * KXBUF + wbase + 2 * wswz - (odd ? 2 : 0);
-                        if (ch >= first_new_chunk) {
-                            Fill<true, true, PT> f;
-                            f.kxr = kxb + wave * 128 + own;
-                            if constexpr (TWO_PER_CU) {
-                                f.arow = low < dout;
-                                f.astride = dout;
-                                f.ap = hd.alpha + (64 * ch + lk) * dout + (f.arow ? low : 0);
-                                f.xs = xs_glob + 64 * nxt + lane;
-                            } else {
-                                f.arow = true;
-                                f.astride = 4;
-                                f.ap = alpha_l + (64 * ch + lk) * 4 + low;
-                                f.xs = xs_l + 64 * nxt + lane;
-                            }
-                            f.macc = macc;
-                            f.n_pad = n_pad;
-                            f.run = runc + wave * RUNC;
-                            f.variance = variance;
-                            f.w_lo = wnext;
-                            f.w_hi = wnext - 8 * wswz;
-                            f.odd = odd;
-                            chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, f);
-                        } else {                       // chunks of earlier panels: all row blocks
-                            Fill<false, true, PT> f;
-                            f.xs = (TWO_PER_CU ? xs_glob : xs_l) + 64 * nxt + lane;
-                            f.n_pad = n_pad;
-                            f.run = runc + wave * RUNC;
-                            f.variance = variance;
-                            f.w_lo = wnext;
-                            f.w_hi = wnext - 8 * wswz;
-                            f.odd = odd;
-                            chunk<0>(rsrc, kxb, rowoff, ch, lane, boff, f);
-                        }
+                    if (ch >= first_new_chunk && !(skip & 2)) {
+                        // two call sites: the LDS copy of alpha' is read with ds_read (a common
+                        // pointer would make every access a flat load that waits on both counters)
+                        if (alpha_doubles > 0) mean_pass(ch, buf, alpha_l, 4);
+                        else mean_pass(ch, buf, hd.alpha, dout);
                     }
-                    if (!filled) {
-                        SL_TMX(11);
-                        if (ch >= first_new_chunk && !(skip & 2)) {
-                            // two call sites: the LDS copy of alpha' is read with ds_read (a common
-                            // pointer would make every access a flat load that waits on both counters)
-                            if (alpha_doubles > 0) mean_pass(ch, buf, alpha_l, 4);
-                            else mean_pass(ch, buf, hd.alpha, dout);
-                        }
-                        SL_TMX(6);  // mean pass
-                        NoFill nf;
-                        if (!(skip & 8)) chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, nf);
-                        SL_TMX(7);  // MFMA stream
-                        if (ch + 1 < nchunks && !(skip & 1)) generate(ch + 1, buf ^ 1);
-                        SL_TMX(8);  // generation
-                    }
-#ifdef SL_GP4_TIMING
-                    const unsigned long long tm_c1 = SL_TM();
+                    NoFill nf;
+                    if (!(skip & 8)) chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, nf);
+                    if (ch + 1 < nchunks && !(skip & 1)) generate(ch + 1, buf ^ 1);
                     __syncthreads();
-                    const unsigned long long tm_c2 = SL_TM();
-                    tm_chunk[q < 0 ? 8 : q] += tm_c1 - tm_c0;
-                    tm_n[q < 0 ? 8 : q] += 1;
-                    tm_barrier += tm_c2 - tm_c1;
-                    tm_loop1 = tm_c2;
-#else
-                    __syncthreads();
-#endif
                 }
                 // |a|^2 of this panel's rows.  The rows of a block live in the four lane groups
                 // (row = lane >> 4): fold them; every (wave, rotation) plane of part_ss then holds
                 // one partial sum per cell, owned by one lane (no other wave touches the plane).
-                SL_TMX(11);
                 asm volatile("s_nop 15\n\ts_nop 15" ::: SL_ALL_AGPRS);   // MFMA results -> reads
                 double ssr[CB][4];
 #pragma unroll
@@ -946,17 +670,7 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
                         ssr[cb][rot] += __shfl_xor(ssr[cb][rot], 16, 64);
                         ssr[cb][rot] += __shfl_xor(ssr[cb][rot], 32, 64);
                     }
-                if (!TWO_PER_CU) {
-                    if (lane < 16) {
-#pragma unroll
-                        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                            for (int rot = 0; rot < 4; ++rot) {
-                                double* slot = part_ss + (wave * 4 + rot) * C + 16 * cb + 4 * ((blk + rot) & 3) + low;
-                                *slot = (pan == 0 ? 0.0 : *slot) + ssr[cb][rot];
-                            }
-                    }
-                } else {
+                {
                     // one plane per wavefront (LDS is short): the four rotations of a lane belong
                     // to four different cells, and within a rotation the lanes hit distinct cells,
                     // so the rotations are added one after the other (in-order LDS, same wavefront)
@@ -979,7 +693,6 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
                         __builtin_amdgcn_wave_barrier();
                     }
                 }
-                SL_TMX(9);  // |a|^2 of the panel
             }
             if (lk < dout)
                 cell_mean[(16 * wave + 4 * blk + low) * SL_D + hd.col0 + lk] =
@@ -995,7 +708,6 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
             __syncthreads();
         }
 
-        SL_TMX(10);         // variance, error, barriers
         // ---- per-cell decrease check, mask word, failing-cell key (as k_gp_sweep) -------------------
         const int64_t idx = tile_base + tid;
         const bool valid = (tid < C) && (idx < hi);
@@ -1033,27 +745,7 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
             if (valid && !okc) sl_key_min(best_v, best_i, sl_vbits(v_x), idx);
         }
         // (cell_mean / cell_err / cin are rewritten only after the next tile's barriers)
-#ifdef SL_GP4_TIMING
-        {
-            const unsigned long long tm_t1 = SL_TM();
-            tm_total += tm_t1 - tm_t0;
-            tm_head += tm_loop0 - tm_t0;
-            tm_tail += tm_t1 - tm_loop1;
-            tm_tiles += 1;
-        }
-#endif
     }
-#ifdef SL_GP4_TIMING
-    if (blockIdx.x == 7 && tid == 0 && tm_tiles > 0) {
-        printf("GP4TIMING tiles %llu cycles/tile %llu head %llu tail %llu barrier/tile %llu kernel %llu\n", tm_tiles,
-               tm_total / tm_tiles, tm_head / tm_tiles, tm_tail / tm_tiles, tm_barrier / tm_tiles,
-               SL_TM() - tm_begin);
-        for (int k = 0; k < 12; ++k) printf("GP4TIMING phase %d cycles/tile %llu\n", k, tm_x[k] / tm_tiles);
-        for (int k = 0; k < 9; ++k)
-            if (tm_n[k]) printf("GP4TIMING chunk q=%d n/tile %llu cycles/chunk %llu\n", k < 8 ? k : -1,
-                                tm_n[k] / tm_tiles, tm_chunk[k] / tm_n[k]);
-    }
-#endif
     __syncthreads();
     sl_block_reduce_key<true>(best_v, best_i, sv, si);
     if (tid == 0) { partials[blockIdx.x].vbits = best_v; partials[blockIdx.x].index = best_i; }
@@ -1063,7 +755,7 @@ __global__ __launch_bounds__(256, gp4::TWO_PER_CU ? 2 : 1) void k_gp_sweep4(
 // host side
 // =============================================================================================
 static size_t gp4_fixed_lds() {
-    return sizeof(double) * (2 * gp4::KXBUF + (gp4::TWO_PER_CU ? 1 : 4) * gp4::W * gp4::C +
+    return sizeof(double) * (2 * gp4::KXBUF + gp4::W * gp4::C +
                              2 * gp4::C * SL_D + gp4::C * SL_P + gp4::W * gp4::RUNC) +
            2 * gp4::W * sizeof(uint64_t);
 }
@@ -1099,16 +791,16 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
     xs_doubles = XSG ? 0 : ((xs_doubles + 1) & ~1);          // keep the k_x buffers 16-byte aligned
     alpha_doubles = (alpha_doubles + 1) & ~1;
     size_t lds = gp4_fixed_lds() + sizeof(double) * xs_doubles;
-    if (gp4::TWO_PER_CU) alpha_doubles = 0;                   // two workgroups per CU: 80 KB each
+    alpha_doubles = 0;                                        // two workgroups per CU: 80 KB each
     if (lds + sizeof(double) * alpha_doubles <= 160 * 1024) lds += sizeof(double) * alpha_doubles;
     else alpha_doubles = 0;                                   // alpha' then comes from L2
-    if (lds > (gp4::TWO_PER_CU ? 80 : 160) * 1024)
+    if (lds > 80 * 1024)
         return sl_fail(ctx, SL_ERR_UNSUPPORTED, "GP training set too large for LDS staging "
                                                 "(%zu bytes needed)", lds);
     auto kern = k_gp_sweep4<DT, MT, XSG>;
     SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t resident = (int64_t)ctx->num_cu * (gp4::TWO_PER_CU ? 2 : 1);
+    const int64_t resident = (int64_t)ctx->num_cu * 2;
     int64_t blocks = ntiles < resident ? ntiles : resident;
     if (blocks > SL_MAX_GRID) blocks = SL_MAX_GRID;
     *nblocks = (int)blocks;
@@ -1120,7 +812,7 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
                        ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, d_points, skip);
     SL_HIP_CHECK(ctx, hipGetLastError());
     sl_note_kernel(ctx, false, "k_gp_sweep4<d=%d, m=%d, xs_global=%d> (%d-row panels, %d workgroup(s) per CU)",
-                   DT, MT, (int)XSG, gp4::RP, gp4::TWO_PER_CU ? 2 : 1);
+                   DT, MT, (int)XSG, gp4::RP, 2);
     return SL_OK;
 }
 
@@ -1158,16 +850,14 @@ int sl_gp4_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
                         const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
                         int* nblocks, double* d_dbg, const double* d_points) {
     const int variant = sl_dim_variant_of(model);
-    const bool xsg = gp4::TWO_PER_CU || !sl_gp4_xs_fit(ctx, model.in_dim);
+    const bool xsg = true;                  // training inputs from L2 (no LDS left beside the k_x buffers)
 #define SL_GP4(D_)                                                                                 \
     return sl_gp4_launch_d##D_(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,     \
                                d_dbg, d_points, xsg)
     switch (variant) {
-#ifndef SL_GP4_ONLY_D4                 // (development: the 4-D instantiation only, one translation unit)
         case 1: SL_GP4(1);
         case 2: SL_GP4(2);
         case 3: SL_GP4(3);
-#endif
         case 4: SL_GP4(4);
         default: break;
     }
