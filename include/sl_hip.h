@@ -355,6 +355,14 @@ SL_API int  sl_state_membership(sl_ctx* ctx, int64_t count, const double* d_poin
 SL_API int  sl_argmax_masked(sl_ctx* ctx, int64_t count, const double* d_values, const uint8_t* d_mask,
                       int64_t* d_out);
 
+/* get_lyapunov_region (lyapunov.py:59-139): the region around the node `start` (flat index on the
+ * model's grid) that the reference's priority-queue flood of the function values visits before it
+ * reaches the grid boundary or has to descend - computed as a minimax-distance fixpoint.
+ *   d_values [nindex] the function on the grid (sl_values), d_work [nindex] scratch (the distances),
+ *   d_region [nindex] out: 1 inside; *sweeps_out (may be NULL) relaxation passes used. */
+SL_API int  sl_lyapunov_region(sl_ctx* ctx, const double* d_values, int64_t start, double* d_work,
+                        uint8_t* d_region, int* sweeps_out);
+
 /* Bit mask <-> byte mask helpers for the bool[N] safe_set of the reference (lyapunov.py:187). */
 SL_API int  sl_bits_to_bytes(sl_ctx* ctx, int64_t n, const uint64_t* d_bits, uint8_t* d_bytes);
 SL_API int  sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uint64_t* d_bits);

@@ -27,7 +27,7 @@ Third-party arithmetic that is not in the upstream checkout: the RBF kernel and
 ``oracle.np_functions.RBF`` and pinned by the reference's own known-answer test
 ``safe_learning/tests/test_functions.py:237-261``.
 
-Pinning, three layers:
+Pinning, five layers:
 
 1. the literal known-answer values of the reference's own tests, transcribed in
    ``tests/golden/reference_known_answers.json`` (``tests/test_oracle_golden.py``);
@@ -40,13 +40,21 @@ Pinning, three layers:
    (``reference_safe_sets.npz``, ``reference_policy_iteration.npz``,
    ``reference_functions.npz``) are reproduced by this oracle bit for bit
    (``tests/test_oracle_reference_*.py``): safe sets, ``c_max``, refinement arrays,
-   samples, value and policy tables, per-class outputs.
+   samples, value and policy tables, per-class outputs;
+4. the GP posterior by the reference's own ``GPRCached`` / ``GaussianProcess`` /
+   ``FunctionStack`` (``functions.py:254-307, 357-546``) at n = 3 ... 1024 training points,
+   executed behind ``tests/golden/numpy_gpflow.py`` (the restatement of the gpflow 0.4.0
+   pieces underneath, itself checked by the reference's four GP tests):
+   ``reference_gp_posterior.npz``, reproduced within 8 eps cond(K)
+   (``tests/test_oracle_reference_gp.py``);
+5. ``get_lyapunov_region`` by the reference's own function (``lyapunov.py:59-139``, Python-2 /
+   NumPy-1 code run behind three era shims): ``reference_regions.npz``, reproduced bit for bit
+   (``tests/test_oracle_reference_regions.py``).
 
-What stays "parity unpinned": the order of equal-valued cells in ``update_safe_set``
-(the reference uses NumPy's default argsort, whose tie order depends on the NumPy build
-and the CPU; the oracle fixes ascending (value, flat index)), ``get_lyapunov_region``
-(Python-2 code that cannot run), and the GP posterior beyond the reference's one
-known-answer test (gpflow is absent).
+What stays "parity unpinned": the order of equal-valued cells in ``update_safe_set`` and in the
+flood of ``get_lyapunov_region`` (the reference uses NumPy's default argsort / the push order of a
+heap; the oracle fixes ascending (value, flat index)), and the reference's behaviour for a flood
+started on a lower grid boundary (it wraps around the grid).
 
 Canonical arithmetic: small linear-algebra forms (policy, linear dynamics,
 quadratic V, thresholds) are evaluated left-to-right, one IEEE-754 rounding per

@@ -99,7 +99,7 @@ EXPORTS = [
     "sl_sort_pairs", "sl_partition_by_digit", "sl_gather_rows", "sl_adaptive_pack", "sl_adaptive_dest",
     "sl_adaptive_sort_keys", "sl_adaptive_analyse", "sl_adaptive_apply", "sl_adaptive_scatter",
     "sl_index_to_state", "sl_perturb_pairs", "sl_rows_sort_key", "sl_rows_duplicate_flags",
-    "sl_sample_bounds", "sl_state_membership", "sl_argmax_masked",
+    "sl_sample_bounds", "sl_state_membership", "sl_argmax_masked", "sl_lyapunov_region",
     "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_eval_points",
     "sl_comm_unique_id", "sl_comm_init", "sl_comm_destroy", "sl_allreduce_result", "sl_allgather",
     "sl_allreduce_sum_u64", "sl_allreduce_max_f64",
@@ -175,6 +175,7 @@ def load_library():
     lib.sl_sample_bounds.argtypes = [vp, i64, C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp]
     lib.sl_state_membership.argtypes = [vp, i64, vp, vp, vp]
     lib.sl_argmax_masked.argtypes = [vp, i64, vp, vp, vp]
+    lib.sl_lyapunov_region.argtypes = [vp, vp, i64, vp, vp, C.POINTER(C.c_int)]
     lib.sl_bits_to_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sl_bytes_to_bits.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sl_bellman_sweep.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, c_double_p,
@@ -437,6 +438,13 @@ class Context(object):
     def argmax_masked(self, count, d_values, d_mask, d_out):
         self.check(self.lib.sl_argmax_masked(self.handle, count, _ptr(d_values), _ptr(d_mask),
                                              _ptr(d_out)), "sl_argmax_masked")
+
+    def lyapunov_region(self, d_values, start, d_work, d_region):
+        """-> relaxation passes used (``sl_lyapunov_region``)."""
+        sweeps = C.c_int(0)
+        self.check(self.lib.sl_lyapunov_region(self.handle, _ptr(d_values), int(start), _ptr(d_work),
+                                               _ptr(d_region), C.byref(sweeps)), "sl_lyapunov_region")
+        return sweeps.value
 
     def bits_to_bytes(self, n, d_bits, d_bytes):
         self.check(self.lib.sl_bits_to_bytes(self.handle, n, _ptr(d_bits), _ptr(d_bytes)),

@@ -916,39 +916,26 @@ def get_safe_sample(lyapunov, perturbations=None, limits=None, positive=False,
 
 
 def get_lyapunov_region(lyapunov, discretization, init_node):
-    """Region around ``init_node`` in which the function ``lyapunov`` keeps increasing when the
-    grid is flooded in order of increasing value (``lyapunov.py:59-139``).  The values come from
-    the engine's value pass; the priority-queue flood fill is inherently sequential and runs on the
-    host exactly like the reference's (same neighbour order and tie-breaking counter)."""
-    import heapq
-    import itertools
+    """Region around ``init_node`` that the reference's priority-queue flood of the function values
+    visits before it reaches the grid boundary or has to descend (``lyapunov.py:59-139``).
+
+    The values come from the engine's value pass; the flood itself is computed on the GPU in
+    parallel form (``sl_lyapunov_region``, ``csrc/sl_region.hip``): the minimax distance from the
+    start node as a relaxation fixpoint, the stop level, the last regular pop and the node it
+    descends to.  Equal to the reference's region wherever the touched cells have distinct values
+    (``tests/golden/reference_regions.npz``, computed by the reference's own function); a start node
+    on the grid boundary gives the empty region (the reference does so on an upper boundary; on a
+    lower one it fails to notice - ``0 == tuple`` - and wraps around the grid)."""
+    import torch
     helper = Lyapunov.__new__(Lyapunov)
     helper._bare_init(discretization, lyapunov)
     shape = tuple(int(v) for v in discretization.num_points)
-    values = helper.values.reshape(shape)
-    ndim = discretization.ndim
-    steps = np.array(list(itertools.product((0, -1, 1), repeat=ndim))[1:])
-    upper = np.array(shape) - 1
-    start = tuple(int(v) for v in init_node)
-    visited = np.zeros(shape, dtype=bool)
-    visited[start] = True
-    counter = itertools.count()
-    heap = [(values[start], next(counter), start)]
-    last = values[start]
-    while heap:
-        value, _, node = heapq.heappop(heap)
-        at = np.array(node)
-        if (at == 0).any() or (at == upper).any():
-            visited[node] = False
-            break
-        if value < last:
-            break
-        last = value
-        for step in steps:
-            nb = tuple(int(v) for v in at + step)
-            if not visited[nb]:
-                visited[nb] = True
-                heapq.heappush(heap, (values[nb], next(counter), nb))
-    for _, _, node in heap:
-        visited[node] = False
-    return visited
+    start = int(np.ravel_multi_index(tuple(int(v) for v in init_node), shape))
+    n = discretization.nindex
+    dev = helper._ctx.torch_device
+    values = helper.gather_values().contiguous()
+    work = torch.empty(n, dtype=torch.float64, device=dev)
+    region = torch.empty(n, dtype=torch.uint8, device=dev)
+    helper._upload_model()
+    helper._ctx.lyapunov_region(values, start, work, region)
+    return region.cpu().numpy().astype(bool).reshape(shape)

@@ -309,3 +309,53 @@ def synthetic_adaptive_cells(n, seed, tau=0.5, hard=0.002):
     decrease[odd] = rng.choice([np.nan, 0.0, 0.3], int(odd.sum()))
     init = values < 0.01
     return values, decrease, thr / tau, tau, init
+
+
+def minimax_region(values, start):
+    """``sl_region.hip`` in NumPy (TEST INFRASTRUCTURE): the region of ``get_lyapunov_region`` from the
+    minimax-distance fixpoint D(v) = max(V(v), min over the 3^d - 1 neighbours of D), the stop level
+    c* = min(D on the grid boundary, D of nodes reached only by descending), the last regular pop x*
+    and the node it descends to.  ``values``: array of the grid's shape; ``start``: index tuple."""
+    import itertools
+    values = np.asarray(values, dtype=np.float64)
+    shape, d = values.shape, values.ndim
+    dist = np.full(shape, np.inf)
+    dist[tuple(start)] = values[tuple(start)]
+    offsets = [o for o in itertools.product((-1, 0, 1), repeat=d) if any(o)]
+    pad = np.pad(dist, 1, constant_values=np.inf)
+    inner = tuple(slice(1, -1) for _ in range(d))
+    boundary = np.zeros(shape, dtype=bool)
+    for k in range(d):
+        edge = [slice(None)] * d
+        for side in (0, -1):
+            edge[k] = side
+            boundary[tuple(edge)] = True
+    while True:
+        pad[inner] = dist
+        best = np.full(shape, np.inf)
+        for off in offsets:
+            view = pad[tuple(slice(1 + o, 1 + o + n) for o, n in zip(off, shape))]
+            best = np.minimum(best, view)
+        cand = np.maximum(values, best)
+        cand[tuple(start)] = values[tuple(start)]
+        new = np.minimum(dist, cand)
+        if np.array_equal(new, dist):
+            break
+        dist = new
+    reached = np.isfinite(dist)
+    stops = reached & (boundary | (dist > values))
+    cstar = dist[stops].min()
+    region = dist < cstar
+    last = np.argwhere((dist == cstar) & (values == cstar))
+    assert len(last) == 1                                     # (no ties at the stop level)
+    x = tuple(last[0])
+    if not boundary[x]:
+        region[x] = True
+        lows = [tuple(np.add(x, o)) for o in offsets]
+        lows = [n for n in lows if all(0 <= a < s for a, s in zip(n, shape))
+                and values[n] < cstar and dist[n] == cstar]
+        if lows:
+            y = min(lows, key=lambda n: values[n])
+            if not boundary[y]:
+                region[y] = True
+    return region
