@@ -46,6 +46,8 @@ struct sl_ctx {
 
     void* d_scratch = nullptr;         // grown on demand (sl_eval_points)
     size_t scratch_bytes = 0;
+    double* d_gp4_seeds = nullptr;     // k_gp_sweep4: seeds of the k_x sequences, per workgroup
+    size_t gp4_seed_bytes = 0;
     void* d_records = nullptr;         // GP posterior records of the two-pass network check
     size_t records_bytes = 0;
     sl_key* d_partials = nullptr;      // SL_MAX_GRID entries x 4 keys

@@ -77,7 +77,8 @@ constexpr int RB = R * W;                  // row blocks per panel
 #ifndef SL_GP4_WRITE_SKEW
 #define SL_GP4_WRITE_SKEW 1
 #endif
-constexpr int RUNC = 2 * SL_P + 2;         // per wavefront: x0[SL_P], step[SL_P], a^2, Q (see Fill)
+constexpr int RUNS = 4;                    // affine runs per wavefront handled by the recurrence
+constexpr int RUNC = SL_P + 2;             // per (wavefront, run): step[SL_P], a^2, Q
 constexpr int KXS2 = CB * 128 + 4;
 constexpr int KXBUF = 8 * KXS2;
 static_assert(R == 4, "256-row panels (tools/audit_gp4.py is told the same number by the build)");
@@ -363,7 +364,8 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
-    int xs_doubles, int alpha_doubles, const double* __restrict__ points, int skip) {
+    int xs_doubles, int alpha_doubles, const double* __restrict__ points, int skip,
+    double* __restrict__ seeds, int seed_chunks, unsigned long long* __restrict__ ticket) {
     // skip: diagnostics (SL_GP4_SKIP): 1 no k_x generation, 2 no mean pass, 4 no per-cell check,
     // 8 no MFMA chunks - timing attribution only, the results are then meaningless
     using namespace gp4;
@@ -377,9 +379,10 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
     double* cell_mean = part_ss + PSS * C;         // [C][SL_D]
     double* cell_err = cell_mean + C * SL_D;       // [C][SL_D]
     double* cin = cell_err + C * SL_D;             // [C][SL_P] scaled GP inputs of the tile's cells
-    double* runc = cin + C * SL_P;                 // [W][RUNC] x0, step, a^2, Q of each wavefront's run
-    uint64_t* sv = reinterpret_cast<uint64_t*>(runc + W * RUNC);       // [W]
+    double* runc = cin + C * SL_P;                 // [W][RUNS][RUNC] step, a^2, Q of a wavefront's runs
+    uint64_t* sv = reinterpret_cast<uint64_t*>(runc + W * RUNS * RUNC);   // [W]
     int64_t* si = reinterpret_cast<int64_t*>(sv + W);                  // [W]
+    int64_t* next_tile = si + W;                                       // the tile the workgroup drew
 
     const SlDims nd = sl_dims<DT, MT>(M);
     const int d = nd.d, p = nd.p;
@@ -397,11 +400,30 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
     uint64_t best_v = ~0ull;
     int64_t best_i = INT64_MAX;
     int staged_head = -1;
+    // Seeds of the Gaussian sequences, [chunk][wavefront][lane][e_0, rho_0] per workgroup: a panel
+    // of 256 rows walks over every chunk of the panels before it again (40 chunk generations per
+    // tile for 16 different chunks at n = 1024).  The first generation of a chunk keeps
+    // (e_0, rho_0) - the two exponentials and the distance sums, two thirds of its instructions -
+    // in this L2-resident scratch and the later ones only run the recurrence from them: the same
+    // lane reads back its own 16 bytes, the products are the same products, the k_x values
+    // bit for bit the same.  (Measured: 0.5 % of the sweep, profiles/r04_summary.md section 2.)
+    double* seed_w = seeds ? seeds + (((size_t)blockIdx.x * seed_chunks) * W + wave) * 128 + 2 * lane : nullptr;
+    // (tiles with kinks: the seeds of the runs 1 .. RUNS - 1 in further copies of that array)
+    const size_t seed_run = (size_t)gridDim.x * seed_chunks * W * 128;
 
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Tiles are drawn from a counter: a tile whose cells cross a saturation kink of the policy
+    // generates its k_x chunks at twice the cost (a fifth of the headline workload's tiles), and
+    // with a fixed tile list per workgroup the unlucky workgroups finish last (measured: 2 % of
+    // the sweep, profiles/r04_gp4_tickets_ab.txt).
+    for (;;) {
+        if (tid == 0) *next_tile = (int64_t)atomicAdd(ticket, 1ull);
+        __syncthreads();
+        const int64_t tile = *next_tile;       // rewritten after the barriers of the tile
+        if (tile >= ntiles) break;
         const int64_t tile_base = lo + tile * C;
         if (tile_base >= hi) {                     // padding tile: only clears mask bits
             if (tid == 0) neg_bits[(tile_base - lo) >> 6] = 0ull;
+            __syncthreads();                       // everybody has read next_tile
             continue;
         }
 
@@ -494,38 +516,72 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
             }
             a2 = uniform(a2);
             const double qstep = uniform(sl_exp_nonpos(-a2));
-            if (lane == 0) {
+            // a tile with a kink: the step, |step|^2 and Q of every run once per tile (lane r
+            // for run r), not once per training point and chunk
+            if (runs != 1u && !direct) {
+                if (lane < RUNS) {
+                    unsigned m = runs;
+                    for (int r = 0; r < lane; ++r) m &= m - 1;
+                    if (m) {
+                        const int c0 = __builtin_ctz(m);
+                        m &= m - 1;
+                        const int c1 = m ? __builtin_ctz(m) : 16;
+                        const double* at = cin + (16 * wave + c0) * SL_P;
+                        const bool single = c1 - c0 < 2;
+                        double a2r = 0.0;
+                        double* rc = runc + (wave * RUNS + lane) * RUNC;
 #pragma unroll
-                for (int q = 0; q < SL_P; ++q) {
-                    runc[wave * RUNC + q] = q < p ? x0[q] : 0.0;
-                    runc[wave * RUNC + SL_P + q] = q < p ? dlt[q] : 0.0;
+                        for (int q = 0; q < SL_P; ++q) {
+                            const double step = (q < p && !single) ? at[SL_P + q] - at[q] : 0.0;
+                            rc[q] = step;
+                            a2r = fma(step, step, a2r);
+                        }
+                        rc[SL_P] = a2r;
+                        rc[SL_P + 1] = sl_exp_nonpos(-a2r);
+                    }
                 }
-                runc[wave * RUNC + 2 * SL_P] = a2;
-                runc[wave * RUNC + 2 * SL_P + 1] = qstep;
+                __builtin_amdgcn_wave_barrier();
             }
             double macc[4] = {0.0, 0.0, 0.0, 0.0};   // posterior-mean accumulators (see mean_pass)
 
             // k_x chunk `ch` -> LDS buffer `buf` (lane = training point 64 ch + lane)
-            auto generate = [&](int ch, int buf) {
+            // first_new: chunks below it were generated for an earlier panel of this tile;
+            // keep: a later panel will want this chunk again
+            auto generate = [&](int ch, int buf, int first_new, bool keep) {
                 double* kxw = kx_l + buf * KXBUF + wbase;
                 const int j = 64 * ch + lane;
                 double xv[SL_P];
+                auto load_xv = [&]() {
 #pragma unroll
-                for (int q = 0; q < SL_P; ++q)
-                    if (q < p) xv[q] = XSG ? xs_glob[q * n_pad + j] : xs_l[q * n_pad + j];
+                    for (int q = 0; q < SL_P; ++q)
+                        if (q < p) xv[q] = XSG ? xs_glob[q * n_pad + j] : xs_l[q * n_pad + j];
+                };
                 if (runs == 1u) {                  // one affine run: e_{c+1} = e_c rho_c, rho_{c+1} = rho_c Q
-                    double z = 0.0, bj = 0.0;
+                    double e, rho;
+                    if (seed_w && ch < first_new) {
+                        const sl_d2 sd = *reinterpret_cast<const sl_d2*>(seed_w + (size_t)ch * (W * 128));
+                        e = sd.x;
+                        rho = sd.y;
+                    } else {
+                        load_xv();
+                        double z = 0.0, bj = 0.0;
 #pragma unroll
-                    for (int q = 0; q < SL_P; ++q) {
-                        if (q < p) {
-                            const double dq = xv[q] - x0[q];
-                            z = fma(dq, dq, z);
-                            bj = fma(dq, dlt[q], bj);
+                        for (int q = 0; q < SL_P; ++q) {
+                            if (q < p) {
+                                const double dq = xv[q] - x0[q];
+                                z = fma(dq, dq, z);
+                                bj = fma(dq, dlt[q], bj);
+                            }
+                        }
+                        exp_pair(-0.5 * z, fmin(bj - 0.5 * a2, 700.0), e, rho);
+                        e = variance * e;
+                        if (seed_w && keep) {
+                            sl_d2 sd;
+                            sd.x = e;
+                            sd.y = rho;
+                            *reinterpret_cast<sl_d2*>(seed_w + (size_t)ch * (W * 128)) = sd;
                         }
                     }
-                    double e, rho;
-                    exp_pair(-0.5 * z, fmin(bj - 0.5 * a2, 700.0), e, rho);
-                    e = variance * e;
                     // slot (c + wswz) & 15 with wswz 0 or 4: two bases, immediate offsets
                     double* w_lo = kxw + 2 * wswz;               // cells 0..11
                     double* w_hi = w_lo - 8 * wswz;              // cells 12..15 wrap for wswz = 4
@@ -536,27 +592,42 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                         rho *= qstep;
                     }
                 } else if (!direct) {              // a few runs: the recurrence restarts at each
+                    const bool reuse = seed_w && ch < first_new;
+                    if (!reuse) load_xv();
                     unsigned m = runs;
-                    while (m) {
+                    for (int r = 0; m; ++r) {
                         const int c0 = __builtin_ctz(m);
                         m &= m - 1;
                         const int c1 = m ? __builtin_ctz(m) : 16;
                         const double* at = cin + (16 * wave + c0) * SL_P;
-                        const bool single = c1 - c0 < 2;
-                        double z = 0.0, bj = 0.0, a2r = 0.0;
+                        const double* rc = runc + (wave * RUNS + r) * RUNC;
+                        // run r of a chunk: its seeds sit `seed_run` doubles behind those of run r - 1
+                        double* sp = seed_w ? seed_w + (size_t)ch * (W * 128) + (size_t)r * seed_run : nullptr;
+                        double e, rho;
+                        if (reuse) {
+                            const sl_d2 sd = *reinterpret_cast<const sl_d2*>(sp);
+                            e = sd.x;
+                            rho = sd.y;
+                        } else {
+                            double z = 0.0, bj = 0.0;
 #pragma unroll
-                        for (int q = 0; q < SL_P; ++q) {
-                            if (q < p) {
-                                const double dq = xv[q] - at[q];
-                                const double step = single ? 0.0 : at[SL_P + q] - at[q];
-                                z = fma(dq, dq, z);
-                                bj = fma(dq, step, bj);
-                                a2r = fma(step, step, a2r);
+                            for (int q = 0; q < SL_P; ++q) {
+                                if (q < p) {
+                                    const double dq = xv[q] - at[q];
+                                    z = fma(dq, dq, z);
+                                    bj = fma(dq, rc[q], bj);
+                                }
+                            }
+                            exp_pair(-0.5 * z, fmin(bj - 0.5 * rc[SL_P], 700.0), e, rho);
+                            e = variance * e;
+                            if (seed_w && keep) {
+                                sl_d2 sd;
+                                sd.x = e;
+                                sd.y = rho;
+                                *reinterpret_cast<sl_d2*>(sp) = sd;
                             }
                         }
-                        double e = variance * sl_exp_nonpos(-0.5 * z);
-                        double rho = sl_exp_nonpos(fmin(bj - 0.5 * a2r, 700.0));
-                        const double qr = sl_exp_nonpos(-a2r);
+                        const double qr = rc[SL_P + 1];
                         for (int c = c0; c < c1; ++c) {
                             kxw[2 * ((c + wswz) & 15)] = e;
                             e *= rho;
@@ -564,6 +635,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                         }
                     }
                 } else {
+                    load_xv();
                     for (int c = 0; c < 16; ++c) {
                         double z = 0.0;
 #pragma unroll
@@ -585,9 +657,9 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
             // lane mapping this cost 8 % of the sweep.)
             auto mean_pass = [&](int ch, int buf, const double* __restrict__ alpha_src, int stride) {
                 const double* kxr = kx_l + buf * KXBUF + wave * 128 + own;
-                // rows dd >= dout of A are zero: every lane loads a valid column, then selects
-                const bool row = low < dout;
-                const double* ap = alpha_src + (64 * ch + lk) * stride + (row ? low : 0);
+                // Rows dd >= dout of A hold whatever a valid column holds: row dd of the product
+                // depends on row dd of A only, and the rows >= dout of the result are never read.
+                const double* ap = alpha_src + (64 * ch + lk) * stride + (low < dout ? low : 0);
                 // all operands first (8 fragment reads, 16 alpha' entries: one round trip instead
                 // of eight dependent ones), then the sixteen MFMAs back to back
                 sl_d2 kx[8];
@@ -595,15 +667,13 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
 #pragma unroll
                 for (int s2 = 0; s2 < 8; ++s2) {
                     kx[s2] = *reinterpret_cast<const sl_d2*>(kxr + s2 * KXS2);
-                    const double t0 = ap[(8 * s2) * stride], t1 = ap[(8 * s2 + 4) * stride];
-                    a0[s2] = row ? t0 : 0.0;
-                    a1[s2] = row ? t1 : 0.0;
+                    a0[s2] = ap[(8 * s2) * stride];
+                    a1[s2] = ap[(8 * s2 + 4) * stride];
                 }
                 // Accumulators in vector registers (the builtin would route them through a0:a1).
                 // A dependent FP64 MFMA must not issue right behind its producer (no interlock:
                 // measured, the second product was lost): four accumulators in rotation keep
-                // three MFMAs between a write and its reuse.  The A operands come from VALU
-                // selects: wait states first.
+                // three MFMAs between a write and its reuse.
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
                     asm volatile("s_nop 3\n\t"
@@ -636,7 +706,8 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                 constexpr int CPP = RP / 64;                     // chunks per panel (its diagonal band)
                 const int nchunks = (pan + 1) * CPP;
                 const int first_new_chunk = pan * (RP / 64);     // chunks not generated before
-                if (!(skip & 1)) generate(0, 0);
+                const bool keep = pan + 1 < npanels;
+                if (!(skip & 1)) generate(0, 0, first_new_chunk, keep);
                 __syncthreads();
                 for (int ch = 0; ch < nchunks; ++ch) {
                     const int buf = ch & 1;
@@ -650,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                     }
                     NoFill nf;
                     if (!(skip & 8)) chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, nf);
-                    if (ch + 1 < nchunks && !(skip & 1)) generate(ch + 1, buf ^ 1);
+                    if (ch + 1 < nchunks && !(skip & 1)) generate(ch + 1, buf ^ 1, first_new_chunk, keep);
                     __syncthreads();
                 }
                 // |a|^2 of this panel's rows.  The rows of a block live in the four lane groups
@@ -756,8 +827,8 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
 // =============================================================================================
 static size_t gp4_fixed_lds() {
     return sizeof(double) * (2 * gp4::KXBUF + gp4::W * gp4::C +
-                             2 * gp4::C * SL_D + gp4::C * SL_P + gp4::W * gp4::RUNC) +
-           2 * gp4::W * sizeof(uint64_t);
+                             2 * gp4::C * SL_D + gp4::C * SL_P + gp4::W * gp4::RUNS * gp4::RUNC) +
+           (2 * gp4::W + 2) * sizeof(uint64_t);
 }
 
 // true when the training inputs of every head fit LDS next to the fixed buffers
@@ -800,16 +871,38 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
     auto kern = k_gp_sweep4<DT, MT, XSG>;
     SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t resident = (int64_t)ctx->num_cu * 2;
+    const char* env_wgs = getenv("SL_GP4_WGS");              // diagnostics: workgroups per CU
+    const int64_t resident = (int64_t)ctx->num_cu * (env_wgs ? atoi(env_wgs) : 2);
     int64_t blocks = ntiles < resident ? ntiles : resident;
     if (blocks > SL_MAX_GRID) blocks = SL_MAX_GRID;
     *nblocks = (int)blocks;
     SlAux aux{ctx->d_tri, ctx->d_net};
     const char* env = getenv("SL_GP4_SKIP");
     const int skip = env ? atoi(env) : 0;
+    // scratch of the sequence seeds: [workgroup][chunk][wavefront][lane][2] (see the kernel)
+    int seed_chunks = 0;
+    for (int h = 0; h < ctx->h_gp.nheads; ++h) {
+        const int c = ctx->gp_heads[h].n_pad / 64;
+        seed_chunks = c > seed_chunks ? c : seed_chunks;
+    }
+    const size_t head_bytes = 16;                               // the tile counter
+    const size_t seed_bytes = head_bytes + (size_t)gp4::RUNS * blocks * seed_chunks * gp4::W * 128 * sizeof(double);
+    if (seed_bytes > ctx->gp4_seed_bytes) {
+        SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_gp4_seeds) (void)hipFree(ctx->d_gp4_seeds);
+        ctx->d_gp4_seeds = nullptr;
+        ctx->gp4_seed_bytes = 0;
+        SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_gp4_seeds, seed_bytes));
+        ctx->gp4_seed_bytes = seed_bytes;
+    }
+    const char* env_seeds = getenv("SL_GP4_SEEDS");           // 0: every generation from scratch
+    double* seeds = (env_seeds && atoi(env_seeds) == 0) ? nullptr : ctx->d_gp4_seeds + head_bytes / sizeof(double);
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ctx->d_gp4_seeds);
+    SL_HIP_CHECK(ctx, hipMemsetAsync(ticket, 0, head_bytes, ctx->stream));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(gp4::W * 64), lds, ctx->stream, model,
                        ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,
-                       ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, d_points, skip);
+                       ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, d_points, skip, seeds,
+                       seed_chunks, ticket);
     SL_HIP_CHECK(ctx, hipGetLastError());
     sl_note_kernel(ctx, false, "k_gp_sweep4<d=%d, m=%d, xs_global=%d> (%d-row panels, %d workgroup(s) per CU)",
                    DT, MT, (int)XSG, gp4::RP, 2);

@@ -102,6 +102,7 @@ extern "C" int sl_ctx_destroy(sl_ctx* ctx) {
     (void)hipFree(ctx->d_tri);
     (void)hipFree(ctx->d_net);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_gp4_seeds) (void)hipFree(ctx->d_gp4_seeds);
     if (ctx->d_policy_cache) (void)hipFree(ctx->d_policy_cache);
     if (ctx->d_records) (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_partials);

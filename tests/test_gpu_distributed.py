@@ -89,6 +89,33 @@ def _worker(rank, world, port, results, backend="gloo"):
         if (not np.array_equal(lyap.safe_set, olyap.safe_set) or lyap.c_max != olyap.c_max
                 or not np.array_equal(lyap._refinement, olyap._refinement)):
             failures.append(("adaptive", shrink))
+    # the refinement array is sharded like V: every rank keeps its cells, the attribute gathers
+    if lyap._refinement_dev is None or lyap._refinement_dev.numel() != lyap._hi - lyap._lo:
+        failures.append(("adaptive", "refinement not sharded"))
+    # get_safe_sample on every rank (the mask words of the whole grid are on every rank): the same
+    # pair and bound as the oracle's
+    case = cases.make_case("pendulum", num_points=33, n_gp=40, tau_scale=0.01, signal_std=0.001,
+                           noise_std=0.0002, lengthscale=1.0)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    lyap.update_safe_set()
+    olyap.update_safe_set()
+    perturbations = np.array([[-0.2], [-0.05], [0.0], [0.05], [0.2]])
+    limits = np.array([[-1.0, 1.0]])
+    for positive in (True, False):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            pair, bound = sl.get_safe_sample(lyap, perturbations, limits, positive=positive)
+            opair, obound = oracle.get_safe_sample(olyap, perturbations, limits, positive=positive)
+        if not np.array_equal(pair, opair) or not np.isclose(bound, obound, rtol=1e-7, atol=0):
+            failures.append(("sample", positive, pair.tolist(), opair.tolist(), bound, obound))
+    # update_values(gather=True): the shards are gathered NOW, collectively, so that a later read on
+    # one rank only is local (a lazy gather behind a rank guard would wait for the others forever)
+    lyap.update_values(gather=True)
+    if world > 1 and lyap._d_values_full is None:
+        failures.append(("values", "not gathered eagerly"))
+    if rank == 0 and not np.array_equal(lyap.values, olyap.values):
+        failures.append(("values", "rank-guarded read"))
     # PolicyIteration across ranks: each rank sweeps its shard of the vertices (matrix-core
     # kernels; the shard boundary cuts a row of the last axis), the new table is all-gathered
     import test_gpu_rl
