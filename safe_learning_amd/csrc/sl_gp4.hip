@@ -655,21 +655,27 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
             // rotation-0 k_x fragment of cell block `wave`.  Lane (k, blk, low) ends up with the
             // mean of output dd = k at cell 4 blk + low.  (As FP64-VALU work in the (k, cell)
             // lane mapping this cost 8 % of the sweep.)
-            auto mean_pass = [&](int ch, int buf, const double* __restrict__ alpha_src, int stride) {
-                const double* kxr = kx_l + buf * KXBUF + wave * 128 + own;
+            // The pass comes in two parts around the generation of the same chunk: mean_fetch
+            // requests alpha' together with the inputs of the generation (one trip to L2 for
+            // both), mean_run multiplies once the wavefront has written its k_x values - its
+            // OWN values (lane = training point, the 16 cells of block `wave`): LDS serves a
+            // wavefront's instructions in order, no workgroup barrier is needed in between.
+            struct MeanIn { double a0[8], a1[8]; };
+            auto mean_fetch = [&](int ch, const double* __restrict__ alpha_src, int stride, MeanIn& mi) {
                 // Rows dd >= dout of A hold whatever a valid column holds: row dd of the product
                 // depends on row dd of A only, and the rows >= dout of the result are never read.
                 const double* ap = alpha_src + (64 * ch + lk) * stride + (low < dout ? low : 0);
-                // all operands first (8 fragment reads, 16 alpha' entries: one round trip instead
-                // of eight dependent ones), then the sixteen MFMAs back to back
-                sl_d2 kx[8];
-                double a0[8], a1[8];
 #pragma unroll
                 for (int s2 = 0; s2 < 8; ++s2) {
-                    kx[s2] = *reinterpret_cast<const sl_d2*>(kxr + s2 * KXS2);
-                    a0[s2] = ap[(8 * s2) * stride];
-                    a1[s2] = ap[(8 * s2 + 4) * stride];
+                    mi.a0[s2] = ap[(8 * s2) * stride];
+                    mi.a1[s2] = ap[(8 * s2 + 4) * stride];
                 }
+            };
+            auto mean_run = [&](int buf, const MeanIn& mi) {
+                const double* kxr = kx_l + buf * KXBUF + wave * 128 + own;
+                sl_d2 kx[8];
+#pragma unroll
+                for (int s2 = 0; s2 < 8; ++s2) kx[s2] = *reinterpret_cast<const sl_d2*>(kxr + s2 * KXS2);
                 // Accumulators in vector registers (the builtin would route them through a0:a1).
                 // A dependent FP64 MFMA must not issue right behind its producer (no interlock:
                 // measured, the second product was lost): four accumulators in rotation keep
@@ -686,12 +692,29 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                                  "v_mfma_f64_4x4x4_4b_f64 %2, %16, %17, %2\n\t"
                                  "v_mfma_f64_4x4x4_4b_f64 %3, %18, %19, %3"
                                  : "+v"(macc[0]), "+v"(macc[1]), "+v"(macc[2]), "+v"(macc[3])
-                                 : "v"(a0[4 * h]), "v"(kx[4 * h].x), "v"(a1[4 * h]), "v"(kx[4 * h].y),
-                                   "v"(a0[4 * h + 1]), "v"(kx[4 * h + 1].x), "v"(a1[4 * h + 1]), "v"(kx[4 * h + 1].y),
-                                   "v"(a0[4 * h + 2]), "v"(kx[4 * h + 2].x), "v"(a1[4 * h + 2]), "v"(kx[4 * h + 2].y),
-                                   "v"(a0[4 * h + 3]), "v"(kx[4 * h + 3].x), "v"(a1[4 * h + 3]), "v"(kx[4 * h + 3].y));
+                                 : "v"(mi.a0[4 * h]), "v"(kx[4 * h].x), "v"(mi.a1[4 * h]), "v"(kx[4 * h].y),
+                                   "v"(mi.a0[4 * h + 1]), "v"(kx[4 * h + 1].x), "v"(mi.a1[4 * h + 1]), "v"(kx[4 * h + 1].y),
+                                   "v"(mi.a0[4 * h + 2]), "v"(kx[4 * h + 2].x), "v"(mi.a1[4 * h + 2]), "v"(kx[4 * h + 2].y),
+                                   "v"(mi.a0[4 * h + 3]), "v"(kx[4 * h + 3].x), "v"(mi.a1[4 * h + 3]), "v"(kx[4 * h + 3].y));
                 // retired before any other reader (a register copy, the final sum)
                 asm volatile("s_nop 15\n\ts_nop 7" : "+v"(macc[0]), "+v"(macc[1]), "+v"(macc[2]), "+v"(macc[3]));
+            };
+            // chunk `ch` -> LDS buffer `buf`, and its contribution to the posterior mean
+            auto produce = [&](int ch, int buf, int first_new, bool keep) {
+                const bool with_mean = ch >= first_new && !(skip & 2);
+                MeanIn mi;
+                if (with_mean) {
+                    // two call sites: the LDS copy of alpha' is read with ds_read (a common
+                    // pointer would make every access a flat load that waits on both counters)
+                    if (alpha_doubles > 0) mean_fetch(ch, alpha_l, 4, mi);
+                    else mean_fetch(ch, hd.alpha, dout, mi);
+                }
+                if (!(skip & 1)) generate(ch, buf, first_new, keep);
+                if (with_mean) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    mean_run(buf, mi);
+                }
             };
 
             const int npanels = n_pad / RP;
@@ -707,21 +730,15 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                 const int nchunks = (pan + 1) * CPP;
                 const int first_new_chunk = pan * (RP / 64);     // chunks not generated before
                 const bool keep = pan + 1 < npanels;
-                if (!(skip & 1)) generate(0, 0, first_new_chunk, keep);
+                produce(0, 0, first_new_chunk, keep);
                 __syncthreads();
                 for (int ch = 0; ch < nchunks; ++ch) {
                     const int buf = ch & 1;
                     const int q = __builtin_amdgcn_readfirstlane(ch - CPP * pan);
                     const double* kxb = kx_l + buf * KXBUF;
-                    if (ch >= first_new_chunk && !(skip & 2)) {
-                        // two call sites: the LDS copy of alpha' is read with ds_read (a common
-                        // pointer would make every access a flat load that waits on both counters)
-                        if (alpha_doubles > 0) mean_pass(ch, buf, alpha_l, 4);
-                        else mean_pass(ch, buf, hd.alpha, dout);
-                    }
                     NoFill nf;
                     if (!(skip & 8)) chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, nf);
-                    if (ch + 1 < nchunks && !(skip & 1)) generate(ch + 1, buf ^ 1, first_new_chunk, keep);
+                    if (ch + 1 < nchunks) produce(ch + 1, buf ^ 1, first_new_chunk, keep);
                     __syncthreads();
                 }
                 // |a|^2 of this panel's rows.  The rows of a block live in the four lane groups
