@@ -888,8 +888,7 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
     auto kern = k_gp_sweep4<DT, MT, XSG>;
     SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const char* env_wgs = getenv("SL_GP4_WGS");              // diagnostics: workgroups per CU
-    const int64_t resident = (int64_t)ctx->num_cu * (env_wgs ? atoi(env_wgs) : 2);
+    const int64_t resident = (int64_t)ctx->num_cu * 2;
     int64_t blocks = ntiles < resident ? ntiles : resident;
     if (blocks > SL_MAX_GRID) blocks = SL_MAX_GRID;
     *nblocks = (int)blocks;

@@ -991,3 +991,32 @@ def test_six_dimensional_stack_of_six_heads_falls_back_to_the_wide_kernel(sl):
                         sl.Saturation(sl.LinearSystem((K,)), -1.0, 1.0), initial_set=init)
     lyap4.update_safe_set()
     assert lyap4._ctx.last_kernel().startswith("k_gp_small<"), lyap4._ctx.last_kernel()
+
+
+def test_gp4_sequence_seeds_are_bit_identical(sl, monkeypatch):
+    """k_gp_sweep4 keeps the seeds (e_0, rho_0) of a chunk's Gaussian sequences between the panels
+    of a tile and draws its tiles from a counter.  With SL_GP4_SEEDS=0 every generation starts from
+    the exponentials again: masks, failing keys and the per-cell records (decrease, threshold,
+    posterior mean and error) must be bit for bit the same - on a grid whose rows cross the
+    saturation kinks of the policy (several runs per wavefront) and with 2 and 3 panels."""
+    import torch
+    from safe_learning_amd.benchmarks import GP_VARIANTS, build_lyapunov
+    for n_gp in (300, 520):
+        case = cases.make_case("cartpole", num_points=[6, 6, 6, 64], n_gp=n_gp, tau_scale=0.0,
+                               **GP_VARIANTS["tight"])
+        n = int(np.prod(case["num_points"]))
+        out = []
+        for seeds in ("1", "0"):
+            monkeypatch.setenv("SL_GP4_SEEDS", seeds)
+            lyap = build_lyapunov(case)
+            d = case["d"]
+            dbg = torch.zeros((n, 2 + 2 * d), dtype=torch.float64, device="cuda:0")
+            lyap._ctx.lyap_sweep(0, n, lyap._d_init, lyap._d_values, lyap._d_neg, lyap._d_result, dbg)
+            assert lyap._ctx.last_kernel().startswith("k_gp_sweep4")
+            out.append((dbg.cpu().numpy(), lyap._d_neg.cpu().numpy().copy(), lyap._d_result.cpu().numpy().copy()))
+        for a, b in zip(out[0], out[1]):
+            assert_array_equal(a, b)
+        # kinks inside the rows: the policy saturates on a part of every row of 64 cells
+        states = np.stack(np.meshgrid(*[np.linspace(-1, 1, k) for k in case["num_points"]], indexing="ij"), -1)
+        u = states.reshape(-1, case["d"]) @ np.asarray(case["K"]).T
+        assert (np.abs(u) > 1).any() and (np.abs(u) < 1).any()
