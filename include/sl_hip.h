@@ -163,6 +163,33 @@ SL_API int  sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model);
 SL_API int  sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
                     const double* h_X, const double* h_Linv, const double* h_alpha,
                     double variance, const double* h_lengthscales);
+/* The same head with a kernel of the family the reference's notebooks build from gpflow 0.4.0's
+ * kernels.py (examples/inverted_pendulum.ipynb:152-158: Linear + Matern32 * Linear; the functions
+ * GPRCached calls are kern.K and kern.Kdiag, functions.py:401, 438, 445, 450): a SUM of PRODUCTS
+ * of leaf kernels.  Factor f belongs to product `product` (products are numbered 0, 1, ... in
+ * the order of their first factor; the factors of a product are adjacent):
+ *   SL_KERNEL_RBF       variance[0] exp(-r2 / 2),                    r2 = sum_q ((x_q - x'_q) inv_lengthscales[q])^2
+ *   SL_KERNEL_MATERN32  variance[0] (1 + sqrt(3) r) exp(-sqrt(3) r), r = sqrt(r2 + 1e-12)   (Stationary.euclid_dist)
+ *   SL_KERNEL_LINEAR    sum_q variance[q] x_q x'_q
+ * Dimensions outside a leaf's active_dims carry inv_lengthscales[q] = 0 (variance[q] = 0 for a
+ * Linear leaf).  K(x, x) of the posterior variance (functions.py:450) follows from the same
+ * formulas (Kdiag).  The inputs are stored unscaled. */
+#define SL_KERNEL_RBF 0
+#define SL_KERNEL_MATERN32 1
+#define SL_KERNEL_LINEAR 2
+#define SL_KERNEL_MAX_FACTORS 8
+typedef struct sl_gp_kernel_factor {
+    int32_t kind, product;
+    double  variance[SL_MAX_INPUT_DIM];
+    double  inv_lengthscales[SL_MAX_INPUT_DIM];
+} sl_gp_kernel_factor;
+typedef struct sl_gp_kernel {
+    int32_t nfactors, reserved;
+    sl_gp_kernel_factor factor[SL_KERNEL_MAX_FACTORS];
+} sl_gp_kernel;
+SL_API int  sl_gp_set_head_kernel(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
+                    const double* h_X, const double* h_Linv, const double* h_alpha,
+                    const sl_gp_kernel* h_kernel);
 /* One more training point for an uploaded head (GaussianProcess.add_data_point,
  * functions.py:525-546) without re-packing: the rank-one extension of the cached factors touches
  * one new row of L^-1, so only that row is scattered into the fragment layout.

@@ -13,7 +13,8 @@ Reference files followed (relative to the upstream checkout):
 * ``examples/utilities.py:48-104``   LyapunovNetwork
 * ``examples/utilities.py:144-289``  InvertedPendulum
 * ``examples/utilities.py:292-437``  CartPole
-* gpflow==0.4.0 ``kernels.py`` (``Stationary.square_dist``, ``RBF.K``, ``RBF.Kdiag``) and
+* gpflow==0.4.0 ``kernels.py`` (``Stationary.square_dist`` / ``euclid_dist``, ``RBF``, ``Matern32``,
+  ``Linear``, ``Add``, ``Prod``: ``K`` and ``Kdiag``) and
   ``gpr.py`` (``GPR.build_predict``): not in the checkout, published algorithm restated.
 """
 
@@ -178,6 +179,114 @@ class RBF(object):
 
     def Kdiag(self, X):
         return np.full(len(X), self.variance, dtype=np.float64)
+
+
+class _Sliced(object):
+    """``Kern._slice`` of gpflow==0.4.0: a kernel reads the columns ``active_dims`` of its inputs
+    (default: the first ``input_dim``), and ``+`` / ``*`` build ``Add`` / ``Prod``."""
+
+    def _init_dims(self, input_dim, active_dims):
+        self.input_dim = int(input_dim)
+        self.active_dims = (np.arange(self.input_dim) if active_dims is None
+                            else np.asarray(list(active_dims), dtype=np.int64))
+
+    def _slice(self, X, X2):
+        X = np.asarray(X, dtype=np.float64)[:, self.active_dims]
+        return X, (None if X2 is None else np.asarray(X2, dtype=np.float64)[:, self.active_dims])
+
+    def __add__(self, other):
+        return Add([self, other])
+
+    def __mul__(self, other):
+        return Prod([self, other])
+
+
+class Matern32(_Sliced):
+    """gpflow==0.4.0 ``kernels.Matern32``: ``variance (1 + sqrt(3) r) exp(-sqrt(3) r)`` with
+    ``r = Stationary.euclid_dist = sqrt(square_dist + 1e-12)``; ``Kdiag = variance``.  Used by the
+    reference's notebooks (``examples/inverted_pendulum.ipynb:152-158``), pinned by none of its
+    tests: parity unpinned beyond the published formula."""
+
+    def __init__(self, input_dim, variance=1.0, lengthscales=None, active_dims=None, ARD=False):
+        self._init_dims(input_dim, active_dims)
+        self._rbf = RBF(input_dim, variance, lengthscales, ARD)      # square_dist, lengthscales
+        self.variance, self.lengthscales = self._rbf.variance, self._rbf.lengthscales
+
+    def K(self, X, X2=None):
+        X, X2 = self._slice(X, X2)
+        r = np.sqrt(self._rbf.square_dist(X, X2) + 1e-12)
+        return self.variance * (1. + np.sqrt(3.) * r) * np.exp(-np.sqrt(3.) * r)
+
+    def Kdiag(self, X):
+        return np.full(len(X), self.variance, dtype=np.float64)
+
+
+class SlicedRBF(_Sliced):
+    """``kernels.RBF`` with ``active_dims`` (the plain :class:`RBF` above reads every column)."""
+
+    def __init__(self, input_dim, variance=1.0, lengthscales=None, active_dims=None, ARD=False):
+        self._init_dims(input_dim, active_dims)
+        self._rbf = RBF(input_dim, variance, lengthscales, ARD)
+        self.variance, self.lengthscales = self._rbf.variance, self._rbf.lengthscales
+
+    def K(self, X, X2=None):
+        X, X2 = self._slice(X, X2)
+        return self._rbf.K(X, X2)
+
+    def Kdiag(self, X):
+        return self._rbf.Kdiag(X)
+
+
+class Linear(_Sliced):
+    """gpflow==0.4.0 ``kernels.Linear``: ``K = (X * variance) X2^T``, ``Kdiag = sum(X^2 * variance)``
+    (one variance per active dimension with ``ARD``, else one for all)."""
+
+    def __init__(self, input_dim, variance=1.0, active_dims=None, ARD=False):
+        self._init_dims(input_dim, active_dims)
+        self.variance = np.broadcast_to(np.asarray(variance, dtype=np.float64), (self.input_dim,)).copy()
+
+    def K(self, X, X2=None):
+        X, X2 = self._slice(X, X2)
+        return (X * self.variance).dot((X if X2 is None else X2).T)
+
+    def Kdiag(self, X):
+        X, _ = self._slice(X, None)
+        return np.sum(np.square(X) * self.variance, 1)
+
+
+class Add(_Sliced):
+    """gpflow==0.4.0 ``kernels.Add``: the sum of the members' ``K`` / ``Kdiag``."""
+
+    def __init__(self, kern_list):
+        self.kern_list = list(kern_list)
+
+    def K(self, X, X2=None):
+        out = self.kern_list[0].K(X, X2)
+        for k in self.kern_list[1:]:
+            out = out + k.K(X, X2)
+        return out
+
+    def Kdiag(self, X):
+        out = self.kern_list[0].Kdiag(X)
+        for k in self.kern_list[1:]:
+            out = out + k.Kdiag(X)
+        return out
+
+
+class Prod(Add):
+    """gpflow==0.4.0 ``kernels.Prod``: the elementwise product."""
+
+    def K(self, X, X2=None):
+        out = self.kern_list[0].K(X, X2)
+        for k in self.kern_list[1:]:
+            out = out * k.K(X, X2)
+        return out
+
+    def Kdiag(self, X):
+        out = self.kern_list[0].Kdiag(X)
+        for k in self.kern_list[1:]:
+            out = out * k.Kdiag(X)
+        return out
 
 
 class GPRCached(object):

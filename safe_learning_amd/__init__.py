@@ -9,5 +9,5 @@ from .configuration import config
 from .functions import *          # noqa: F401,F403
 from .lyapunov import *           # noqa: F401,F403
 from .reinforcement_learning import *   # noqa: F401,F403
-from . import utilities, distributed
+from . import utilities, distributed, kernels
 from ._hip import HipEngineError

@@ -70,6 +70,22 @@ class LipschitzDesc(C.Structure):
                 ("lf_matrix", (C.c_double * MAX_STATE_DIM) * MAX_STATE_DIM)]
 
 
+KERNEL_RBF, KERNEL_MATERN32, KERNEL_LINEAR = 0, 1, 2
+KERNEL_MAX_FACTORS = 8
+
+
+class GpKernelFactor(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("product", C.c_int32),
+                ("variance", C.c_double * MAX_INPUT_DIM),
+                ("inv_lengthscales", C.c_double * MAX_INPUT_DIM)]
+
+
+class GpKernel(C.Structure):
+    """``sl_gp_kernel``: a sum of products of RBF / Matern32 / Linear leaves."""
+    _fields_ = [("nfactors", C.c_int32), ("reserved", C.c_int32),
+                ("factor", GpKernelFactor * KERNEL_MAX_FACTORS)]
+
+
 class ModelDesc(C.Structure):
     _fields_ = [("grid", GridDesc), ("policy", PolicyDesc), ("dynamics", DynamicsDesc),
                 ("value", ValueDesc), ("lipschitz", LipschitzDesc), ("reward", ValueDesc),
@@ -92,7 +108,7 @@ S_PREFIX, S_REMAINING, S_KEY_V, S_KEY_I, S_RANK, S_NONE = range(6)
 EXPORTS = [
     "sl_version", "sl_ctx_create", "sl_ctx_destroy", "sl_last_error", "sl_ctx_synchronize",
     "sl_last_kernel",
-    "sl_model_set", "sl_gp_set_head", "sl_gp_append_point", "sl_gp_configure", "sl_tri_set", "sl_tri_set_table",
+    "sl_model_set", "sl_gp_set_head", "sl_gp_set_head_kernel", "sl_gp_append_point", "sl_gp_configure", "sl_tri_set", "sl_tri_set_table",
     "sl_network_set", "sl_values", "sl_lyap_sweep", "sl_lyap_finalize", "sl_select_pass",
     "sl_values_implicit", "sl_fold_results", "sl_lyap_finalize_dev", "sl_select_begin",
     "sl_select_hist", "sl_select_digit",
@@ -135,6 +151,8 @@ def load_library():
     lib.sl_model_set.argtypes = [C.c_void_p, C.POINTER(ModelDesc)]
     lib.sl_gp_set_head.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    c_double_p, c_double_p, c_double_p, C.c_double, c_double_p]
+    lib.sl_gp_set_head_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          c_double_p, c_double_p, c_double_p, C.POINTER(GpKernel)]
     lib.sl_gp_append_point.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]
     lib.sl_gp_configure.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.sl_tri_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(GridDesc), C.c_int,
@@ -264,6 +282,25 @@ class Context(object):
         n, p = X.shape
         self.check(self.lib.sl_gp_set_head(self.handle, head, n, p, alpha.shape[1], col0, pX, pL,
                                            pA, float(variance), pls), "sl_gp_set_head")
+
+    def gp_set_head_kernel(self, head, X, Linv, alpha, col0, factors):
+        """``factors``: ``[(kind, product, variance[p], inv_lengthscales[p])]`` - a sum of products
+        of leaf kernels (``sl_gp_kernel`` of include/sl_hip.h)."""
+        X, pX = _as_c(X)
+        Linv, pL = _as_c(Linv)
+        alpha, pA = _as_c(alpha)
+        n, p = X.shape
+        if len(factors) > KERNEL_MAX_FACTORS:
+            raise ValueError("kernel with %d leaf factors (engine limit %d)" % (len(factors), KERNEL_MAX_FACTORS))
+        spec = GpKernel()
+        spec.nfactors = len(factors)
+        for f, (kind, product, variance, inv_ls) in enumerate(factors):
+            spec.factor[f].kind, spec.factor[f].product = int(kind), int(product)
+            for q in range(p):
+                spec.factor[f].variance[q] = float(variance[q])
+                spec.factor[f].inv_lengthscales[q] = float(inv_ls[q])
+        self.check(self.lib.sl_gp_set_head_kernel(self.handle, head, n, p, alpha.shape[1], col0, pX,
+                                                  pL, pA, C.byref(spec)), "sl_gp_set_head_kernel")
 
     def gp_append_point(self, head, x, linv_row, alpha_new):
         """One more training point for an uploaded head; False if the head has to be re-packed."""

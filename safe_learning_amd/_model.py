@@ -11,7 +11,8 @@ import numpy as np
 from . import _hip
 from .functions import (AbsFunction, CartPole, ConstantFunction, FunctionStack,
                         GaussianProcess, Gradient, InvertedPendulum, LinearSystem, LyapunovNetwork,
-                        Norm1Function, QuadraticFunction, Saturation, Triangulation, _gp_heads)
+                        Norm1Function, QuadraticFunction, Saturation, Triangulation, _gp_heads,
+                        _is_plain_rbf)
 
 
 class ModelBuilder(object):
@@ -123,8 +124,12 @@ class ModelBuilder(object):
                 continue                                # this head is already on the device
             if same_heads and self._follow_appends(h, gp, old[h][0]):
                 continue                                # add_data_point: new rows only
-            self.ctx.gp_set_head(h, gp.X, gp.cholesky_inverse, gp.alpha, col0, gp.kern.variance,
-                                 gp.kern.lengthscales)
+            if _is_plain_rbf(gp.kern, p):
+                self.ctx.gp_set_head(h, gp.X, gp.cholesky_inverse, gp.alpha, col0, gp.kern.variance,
+                                     gp.kern.lengthscales)
+            else:                                       # Linear / Matern32 / sums and products
+                self.ctx.gp_set_head_kernel(h, gp.X, gp.cholesky_inverse, gp.alpha, col0,
+                                            gp.kern._factors(p))
         self.ctx.gp_configure(len(heads), beta)
         self._gp_signature = signature
 

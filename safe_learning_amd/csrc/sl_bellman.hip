@@ -883,6 +883,11 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
     const bool is_gp = M.m.dynamics.kind == SL_DYN_GP;
     if (is_gp && ctx->h_gp.nheads < 1)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: GP dynamics without heads");
+    if (is_gp)
+        for (int h = 0; h < ctx->h_gp.nheads; ++h)
+            if (ctx->gp_heads[h].d_kernel)
+                return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_bellman_sweep: GP head %d has a kernel other "
+                               "than sl_gp_set_head's RBF (the Bellman kernels generate RBF values)", h);
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SL_HIP_CHECK(ctx, hipMemsetAsync(d_stats, 0, 2 * sizeof(double), ctx->stream));
     ctx->last_kernel[0] = 0;

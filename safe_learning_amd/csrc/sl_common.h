@@ -22,6 +22,8 @@ struct SlGpHeadHost {
     double* d_xs = nullptr;
     double* d_mpack = nullptr;
     double* d_alpha = nullptr;
+    sl_gp_kernel* d_kernel = nullptr;             // sum-of-products kernel of the head, or null (RBF)
+    sl_gp_kernel h_kernel;
 };
 
 struct sl_ctx {

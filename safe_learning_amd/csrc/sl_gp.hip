@@ -366,9 +366,11 @@ static int choose_cfg(int n) {
     return 2;        // 64-cell tiles: half the Linv traffic per MFMA of cfg 1, measured fastest
 }
 
-extern "C" int sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
-                              const double* h_X, const double* h_Linv, const double* h_alpha,
-                              double variance, const double* h_lengthscales) {
+// h_kernel: a sum-of-products kernel (sl_gp_set_head_kernel; variance / lengthscales unused), or
+// null for the RBF head
+static int gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0, const double* h_X,
+                       const double* h_Linv, const double* h_alpha, double variance,
+                       const double* h_lengthscales, const sl_gp_kernel* h_kernel) {
     if (!ctx || !h_X || !h_Linv || !h_alpha || !h_lengthscales)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head: NULL argument");
     if (head < 0 || head >= SL_MAX_GP_HEADS)
@@ -382,6 +384,10 @@ extern "C" int sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int
     for (int q = 0; q < p; ++q)
         if (!(h_lengthscales[q] > 0.0))
             return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head: lengthscale <= 0");
+    if (h_kernel && n > 256)
+        return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_gp_set_head_kernel: %d training points; kernels "
+                       "other than the RBF of sl_gp_set_head are implemented for up to 256 "
+                       "(k_gp_small, the shape of the reference's notebooks)", n);
     const int cfg = choose_cfg(n);
     const int rp = cfg_panel_rows(cfg);
     const int n_pad = ((n + rp - 1) / rp) * rp;
@@ -420,7 +426,14 @@ extern "C" int sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int
     if (hh.d_xs) (void)hipFree(hh.d_xs);
     if (hh.d_mpack) (void)hipFree(hh.d_mpack);
     if (hh.d_alpha) (void)hipFree(hh.d_alpha);
+    if (hh.d_kernel) (void)hipFree(hh.d_kernel);
     hh.d_xs = hh.d_mpack = hh.d_alpha = nullptr;
+    hh.d_kernel = nullptr;
+    if (h_kernel) {
+        SL_HIP_CHECK(ctx, hipMalloc(&hh.d_kernel, sizeof(sl_gp_kernel)));
+        SL_HIP_CHECK(ctx, hipMemcpy(hh.d_kernel, h_kernel, sizeof(sl_gp_kernel), hipMemcpyHostToDevice));
+        hh.h_kernel = *h_kernel;
+    }
     SL_HIP_CHECK(ctx, hipMalloc(&hh.d_xs, xs.size() * sizeof(double)));
     SL_HIP_CHECK(ctx, hipMalloc(&hh.d_mpack, mpack.size() * sizeof(double)));
     SL_HIP_CHECK(ctx, hipMalloc(&hh.d_alpha, alphap.size() * sizeof(double)));
@@ -436,7 +449,44 @@ extern "C" int sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int
     for (int q = 0; q < p; ++q) dv.inv_ls[q] = 1.0 / h_lengthscales[q];
     for (int q = 0; q < p; ++q) ctx->gp_heads[head].lengthscales[q] = h_lengthscales[q];
     dv.xs = hh.d_xs; dv.mpack = hh.d_mpack; dv.alpha = hh.d_alpha;
+    dv.kernel = hh.d_kernel;
     return SL_OK;
+}
+
+extern "C" int sl_gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
+                              const double* h_X, const double* h_Linv, const double* h_alpha,
+                              double variance, const double* h_lengthscales) {
+    return gp_set_head(ctx, head, n, p, dout, col0, h_X, h_Linv, h_alpha, variance, h_lengthscales,
+                       nullptr);
+}
+
+extern "C" int sl_gp_set_head_kernel(sl_ctx* ctx, int head, int n, int p, int dout, int col0,
+                                     const double* h_X, const double* h_Linv, const double* h_alpha,
+                                     const sl_gp_kernel* h_kernel) {
+    if (!h_kernel) return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head_kernel: NULL kernel");
+    if (h_kernel->nfactors < 1 || h_kernel->nfactors > SL_KERNEL_MAX_FACTORS)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head_kernel: %d factors outside [1,%d]",
+                       h_kernel->nfactors, SL_KERNEL_MAX_FACTORS);
+    int product = 0;
+    for (int f = 0; f < h_kernel->nfactors; ++f) {
+        const sl_gp_kernel_factor& fac = h_kernel->factor[f];
+        if (fac.kind != SL_KERNEL_RBF && fac.kind != SL_KERNEL_MATERN32 && fac.kind != SL_KERNEL_LINEAR)
+            return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head_kernel: factor %d has kind %d", f, fac.kind);
+        if (fac.product != product && fac.product != product + 1)
+            return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head_kernel: factor %d belongs to product "
+                           "%d after product %d (the factors of a product are adjacent, products "
+                           "numbered in order)", f, fac.product, product);
+        if (f == 0 && fac.product != 0)
+            return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head_kernel: the first product is number 0");
+        product = fac.product;
+        for (int q = 0; q < SL_MAX_INPUT_DIM; ++q)
+            if (!(fac.variance[q] >= 0.0) || !(fac.inv_lengthscales[q] >= 0.0))
+                return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head_kernel: factor %d: negative or "
+                               "NaN variance / inverse lengthscale", f);
+    }
+    double ones[SL_MAX_INPUT_DIM];
+    for (int q = 0; q < SL_MAX_INPUT_DIM; ++q) ones[q] = 1.0;
+    return gp_set_head(ctx, head, n, p, dout, col0, h_X, h_Linv, h_alpha, 1.0, ones, h_kernel);
 }
 
 // row n of the extended L^-1 into the A-fragment layout, the rank-one term of alpha', the new
@@ -602,6 +652,17 @@ int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
                        covered, model.m.grid.d);
     const bool general = sl_model_is_general(model);
     const int variant = sl_dim_variant_of(model);
+    // heads with a sum-of-products kernel (sl_gp_set_head_kernel): k_gp_small evaluates those
+    bool other_kernels = false;
+    for (int h = 0; h < ctx->h_gp.nheads; ++h) other_kernels = other_kernels || ctx->gp_heads[h].d_kernel;
+    if (other_kernels) {
+        if (!sl_gp_small_supports(ctx, model))
+            return sl_fail(ctx, SL_ERR_UNSUPPORTED, "a GP head has a kernel other than sl_gp_set_head's "
+                           "RBF: those run on k_gp_small (every head <= 256 training points, its "
+                           "tables within LDS), which does not take this model");
+        return sl_gp_small_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
+                                  d_dbg, d_points);
+    }
     // small training sets (one head, capacity <= 256 points): a wavefront per 64-cell tile
     if (ctx->gp_cfg == 0 && sl_gp_small_supports(ctx, model))
         return sl_gp_small_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,

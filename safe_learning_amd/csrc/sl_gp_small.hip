@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
         const int n_pad = hd.n_pad, dout = hd.dout, nslab2 = hd.nslab2, col0 = hd.col0;
         const int nrb = n_pad / 16, npass = (nrb + PRB - 1) / PRB;
         const double variance = hd.variance;
+        const sl_gp_kernel* __restrict__ kern = hd.kernel;           // null: the RBF of sl_gp_set_head
         const double* xs_l = head_base;                              // [p][n_pad]
         const double* alpha_l = xs_l + ((p * n_pad + 1) & ~1);       // [n_pad][dout]
         const double* a_l = alpha_l + ((n_pad * dout + 1) & ~1);     // lower-triangle fragments (ALDS)
@@ -155,8 +156,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
                             z1 = fma(d1, d1, z1);
                         }
                     }
-                    const double k0 = variance * sl_exp_nonpos(-0.5 * z0);
-                    const double k1 = variance * sl_exp_nonpos(-0.5 * z1);
+                    double k0, k1;
+                    if (kern) {                                 // sum-of-products kernel, unscaled inputs
+                        double xa[SL_P], xb[SL_P];
+#pragma unroll
+                        for (int q = 0; q < SL_P; ++q) {
+                            xa[q] = (q < p) ? xs_l[q * n_pad + j0] : 0.0;
+                            xb[q] = (q < p) ? xs_l[q * n_pad + j1] : 0.0;
+                        }
+                        // the padding columns of the tables are zero; their fragments of the
+                        // factor and of alpha' are zero as well
+                        k0 = sl_kernel_eval(*kern, p, xa, xg);
+                        k1 = sl_kernel_eval(*kern, p, xb, xg);
+                    } else {
+                        k0 = variance * sl_exp_nonpos(-0.5 * z0);
+                        k1 = variance * sl_exp_nonpos(-0.5 * z1);
+                    }
                     if (s2 >= new_s2) {                         // posterior mean k_x . alpha'
 #pragma unroll
                         for (int dd = 0; dd < SL_D; ++dd) {
@@ -213,7 +228,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
         }
         __builtin_amdgcn_wave_barrier();
         {   // this head's error bound for its output columns (lane = cell)
-            const double var = variance - ssq_w[lane];                     // functions.py:451
+            const double prior = kern ? sl_kernel_diag(*kern, p, x) : variance;   // functions.py:450
+            const double var = prior - ssq_w[lane];                        // functions.py:451
             const double e = gp.beta * sqrt(var);                          // functions.py:514
 #pragma unroll
             for (int dd = 0; dd < SL_D; ++dd)
@@ -282,8 +298,10 @@ static size_t lds_capacity(bool general) {
 // the heads' inputs / alpha' / the check's scratch fit LDS (a 6-D stack of six 256-point heads
 // does not: it stays on k_gp_sweep)
 bool sl_gp_small_supports(sl_ctx* ctx, const SlDevModel& model) {
+    bool other_kernels = false;
+    for (int k = 0; k < ctx->h_gp.nheads; ++k) other_kernels = other_kernels || ctx->gp_heads[k].d_kernel;
     const char* env = getenv("SL_GP_SMALL");
-    if (env && env[0] == '0') return false;
+    if (env && env[0] == '0' && !other_kernels) return false;
     if (ctx->h_gp.nheads < 1) return false;
     for (int k = 0; k < ctx->h_gp.nheads; ++k) {
         const SlGpHeadHost& h = ctx->gp_heads[k];

@@ -94,6 +94,7 @@ extern "C" int sl_ctx_destroy(sl_ctx* ctx) {
         if (ctx->gp_heads[h].d_xs) (void)hipFree(ctx->gp_heads[h].d_xs);
         if (ctx->gp_heads[h].d_mpack) (void)hipFree(ctx->gp_heads[h].d_mpack);
         if (ctx->gp_heads[h].d_alpha) (void)hipFree(ctx->gp_heads[h].d_alpha);
+        if (ctx->gp_heads[h].d_kernel) (void)hipFree(ctx->gp_heads[h].d_kernel);
     }
     for (int s = 0; s < 2; ++s) if (ctx->d_tri_points[s]) (void)hipFree(ctx->d_tri_points[s]);
     if (ctx->d_net_kernels) (void)hipFree(ctx->d_net_kernels);

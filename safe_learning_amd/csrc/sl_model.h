@@ -971,7 +971,71 @@ struct SlGpHeadDev {
     const double* xs;        // [p][n_pad], inputs already divided by the lengthscales
     const double* mpack;     // MFMA A-fragments of Linv, see sl_gp.hip
     const double* alpha;     // [n_pad][dout]  alpha' = Linv^T alpha
+    // sum-of-products kernel (sl_gp_set_head_kernel): device copy of the description, or null for
+    // the RBF head of sl_gp_set_head.  xs then holds the inputs unscaled and inv_ls is all ones.
+    const sl_gp_kernel* kernel;
 };
+
+// k(a, b) of a sum-of-products kernel (gpflow 0.4.0 kernels.py: Add.K / Prod.K over RBF.K,
+// Matern32.K, Linear.K; the description of include/sl_hip.h).  a, b: unscaled inputs.
+SL_HD double sl_kernel_eval(const sl_gp_kernel& ks, int p, const double* a, const double* b) {
+    double total = 0.0, prod = 1.0;
+    int cur = 0;
+    for (int f = 0; f < ks.nfactors; ++f) {
+        const sl_gp_kernel_factor& fac = ks.factor[f];
+        if (fac.product != cur) {
+            total += prod;
+            prod = 1.0;
+            cur = fac.product;
+        }
+        double v = 0.0;
+        if (fac.kind == SL_KERNEL_LINEAR) {
+#pragma unroll
+            for (int q = 0; q < SL_P; ++q)
+                if (q < p) v = fma(a[q] * fac.variance[q], b[q], v);
+        } else {
+            double r2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < SL_P; ++q) {
+                if (q < p) {
+                    const double dq = (a[q] - b[q]) * fac.inv_lengthscales[q];
+                    r2 = fma(dq, dq, r2);
+                }
+            }
+            if (fac.kind == SL_KERNEL_RBF) {
+                v = fac.variance[0] * sl_exp_nonpos(-0.5 * r2);
+            } else {                                    // Matern32, euclid_dist's 1e-12
+                const double r = 1.7320508075688772 * sqrt(r2 + 1e-12);
+                v = fac.variance[0] * (1.0 + r) * sl_exp_nonpos(-r);
+            }
+        }
+        prod *= v;
+    }
+    return total + prod;
+}
+// k(x, x) as kern.Kdiag states it (Stationary.Kdiag: the variance itself, not K through
+// euclid_dist; Linear.Kdiag: sum_q variance_q x_q^2)
+SL_HD double sl_kernel_diag(const sl_gp_kernel& ks, int p, const double* x) {
+    double total = 0.0, prod = 1.0;
+    int cur = 0;
+    for (int f = 0; f < ks.nfactors; ++f) {
+        const sl_gp_kernel_factor& fac = ks.factor[f];
+        if (fac.product != cur) {
+            total += prod;
+            prod = 1.0;
+            cur = fac.product;
+        }
+        double v = fac.variance[0];
+        if (fac.kind == SL_KERNEL_LINEAR) {
+            v = 0.0;
+#pragma unroll
+            for (int q = 0; q < SL_P; ++q)
+                if (q < p) v = fma(x[q] * x[q], fac.variance[q], v);
+        }
+        prod *= v;
+    }
+    return total + prod;
+}
 
 struct SlGpDev {
     int32_t nheads, reserved;

@@ -33,7 +33,7 @@ _TOKENS = itertools.count(1)
 
 __all__ = ['GridWorld', 'DimensionError', 'DeterministicFunction', 'UncertainFunction',
            'QuadraticFunction', 'LinearSystem', 'Saturation', 'AbsFunction', 'Norm1Function',
-           'AbsGradient', 'Gradient', 'ConstantFunction', 'RBF', 'GPRCached', 'GaussianProcess',
+           'AbsGradient', 'Gradient', 'ConstantFunction', 'RBF', 'Matern32', 'Linear', 'GPRCached', 'GaussianProcess',
            'FunctionStack', 'Triangulation', 'InvertedPendulum', 'CartPole', 'LyapunovNetwork']
 
 
@@ -308,12 +308,53 @@ def AbsGradient(fun):
 # Gaussian process
 # ----------------------------------------------------------------------------------------------
 
-class RBF(object):
-    """Squared-exponential kernel with the gpflow 0.4.0 ``kernels.RBF`` signature:
-    ``k(x, x') = variance * exp(-0.5 * sum_q ((x_q - x'_q) / lengthscales_q)^2)``."""
+class Kern(object):
+    """Kernels with the gpflow 0.4.0 ``kernels.py`` surface the reference relies on: ``K(X, X2)``,
+    ``Kdiag(X)`` (``functions.py:401, 438, 445, 450``), ``active_dims``, ``+`` and ``*``
+    (``examples/inverted_pendulum.ipynb:152-158``: ``Linear + Matern32 * Linear``).  The Gram
+    matrix of the training set is formed here on the host; the engine evaluates ``k(X, x)`` and
+    ``k(x, x)`` of the grid cells from :meth:`_factors`."""
 
-    def __init__(self, input_dim, variance=1.0, lengthscales=None, ARD=False):
+    def __init__(self, input_dim, active_dims=None):
         self.input_dim = int(input_dim)
+        if active_dims is None:
+            active_dims = range(self.input_dim)          # gpflow: slice(input_dim)
+        self.active_dims = np.asarray(list(active_dims), dtype=np.int64)
+        if len(self.active_dims) != self.input_dim:
+            raise ValueError('active_dims has %d entries, input_dim is %d'
+                             % (len(self.active_dims), self.input_dim))
+
+    def _slice(self, X, X2):
+        X = np.asarray(X, dtype=config.np_dtype)[:, self.active_dims]
+        X2 = X if X2 is None else np.asarray(X2, dtype=config.np_dtype)[:, self.active_dims]
+        return X, X2
+
+    def __add__(self, other):
+        return Add([self, other])
+
+    def __mul__(self, other):
+        return Prod([self, other])
+
+    def _products(self):
+        """The kernel as a sum of products of leaves: ``[[leaf, ...], ...]``."""
+        return [[self]]
+
+    def _factors(self, p):
+        """``[(kind, product, variance[p], inv_lengthscales[p])]`` for ``sl_gp_set_head_kernel``."""
+        out = []
+        for number, product in enumerate(self._products()):
+            for leaf in product:
+                variance, inv_ls = np.zeros(p), np.zeros(p)
+                if leaf.active_dims.max() >= p:
+                    raise ValueError('kernel reads input column %d of %d' % (leaf.active_dims.max(), p))
+                leaf._fill(variance, inv_ls)
+                out.append((leaf._kind, number, variance, inv_ls))
+        return out
+
+
+class _Stationary(Kern):
+    def __init__(self, input_dim, variance=1.0, lengthscales=None, active_dims=None, ARD=False):
+        Kern.__init__(self, input_dim, active_dims)
         self.variance = float(variance)
         if lengthscales is None:
             lengthscales = 1.0
@@ -321,17 +362,120 @@ class RBF(object):
                                             (self.input_dim,)).copy()
         self.ARD = bool(ARD)
 
+    def _square_dist(self, X, X2):
+        X, X2 = self._slice(X, X2)
+        diff = X[:, None, :] / self.lengthscales - X2[None, :, :] / self.lengthscales
+        return np.einsum('ijk,ijk->ij', diff, diff)
+
+    def Kdiag(self, X):
+        return np.full(len(X), self.variance, dtype=config.np_dtype)
+
+    def _fill(self, variance, inv_ls):
+        variance[0] = self.variance
+        inv_ls[self.active_dims] = 1.0 / self.lengthscales
+
+
+class RBF(_Stationary):
+    """Squared-exponential kernel with the gpflow 0.4.0 ``kernels.RBF`` signature:
+    ``k(x, x') = variance * exp(-0.5 * sum_q ((x_q - x'_q) / lengthscales_q)^2)``."""
+
+    _kind = _hip.KERNEL_RBF
+
+    def __init__(self, input_dim, variance=1.0, lengthscales=None, ARD=False, active_dims=None):
+        _Stationary.__init__(self, input_dim, variance, lengthscales, active_dims, ARD)
+
     def K(self, X, X2=None):
         """Gram matrix on the host (training-set side only)."""
-        X = np.asarray(X, dtype=config.np_dtype) / self.lengthscales
-        X2 = X if X2 is None else np.asarray(X2, dtype=config.np_dtype) / self.lengthscales
-        diff = X[:, None, :] - X2[None, :, :]
-        return self.variance * np.exp(-0.5 * np.einsum('ijk,ijk->ij', diff, diff))
+        return self.variance * np.exp(-0.5 * self._square_dist(X, X2))
+
+
+class Matern32(_Stationary):
+    """``variance * (1 + sqrt(3) r) * exp(-sqrt(3) r)`` with gpflow 0.4.0's
+    ``r = sqrt(square_dist + 1e-12)`` (``Stationary.euclid_dist``)."""
+
+    _kind = _hip.KERNEL_MATERN32
+
+    def K(self, X, X2=None):
+        r = np.sqrt(3.0) * np.sqrt(self._square_dist(X, X2) + 1e-12)
+        return self.variance * (1.0 + r) * np.exp(-r)
+
+
+class Linear(Kern):
+    """``k(x, x') = sum_q variance_q x_q x'_q`` (gpflow 0.4.0 ``kernels.Linear``; one variance
+    for all dimensions unless ``ARD``)."""
+
+    _kind = _hip.KERNEL_LINEAR
+
+    def __init__(self, input_dim, variance=1.0, active_dims=None, ARD=False):
+        Kern.__init__(self, input_dim, active_dims)
+        self.ARD = bool(ARD)
+        self.variance = np.broadcast_to(np.asarray(variance, dtype=config.np_dtype),
+                                        (self.input_dim,)).copy()
+
+    def K(self, X, X2=None):
+        X, X2 = self._slice(X, X2)
+        return (X * self.variance).dot(X2.T)
+
+    def Kdiag(self, X):
+        X, _ = self._slice(X, None)
+        return np.sum(np.square(X) * self.variance, axis=1)
+
+    def _fill(self, variance, inv_ls):
+        variance[self.active_dims] = self.variance
+
+
+class _Combination(Kern):
+    def __init__(self, kern_list):
+        self.kern_list = []
+        for kern in kern_list:
+            if not isinstance(kern, Kern):
+                raise TypeError('can only combine Kern instances')
+            # gpflow flattens nested combinations of the same kind
+            self.kern_list.extend(kern.kern_list if type(kern) is type(self) else [kern])
+        Kern.__init__(self, max(k.input_dim for k in self.kern_list))
+
+
+class Add(_Combination):
+    def K(self, X, X2=None):
+        return sum(k.K(X, X2) for k in self.kern_list)
+
+    def Kdiag(self, X):
+        return sum(k.Kdiag(X) for k in self.kern_list)
+
+    def _products(self):
+        return [product for k in self.kern_list for product in k._products()]
+
+
+class Prod(_Combination):
+    def K(self, X, X2=None):
+        out = self.kern_list[0].K(X, X2)
+        for k in self.kern_list[1:]:
+            out = out * k.K(X, X2)
+        return out
+
+    def Kdiag(self, X):
+        out = self.kern_list[0].Kdiag(X)
+        for k in self.kern_list[1:]:
+            out = out * k.Kdiag(X)
+        return out
+
+    def _products(self):
+        products = [[]]
+        for k in self.kern_list:                       # (a + b) * c = a c + b c
+            products = [left + right for left in products for right in k._products()]
+        return products
+
+
+def _is_plain_rbf(kern, p):
+    """The kernel of ``sl_gp_set_head`` (and of the MFMA paths that generate RBF values by
+    recurrence): an RBF over all ``p`` inputs in their order."""
+    return (type(kern) is RBF and kern.input_dim == p
+            and np.array_equal(kern.active_dims, np.arange(p)))
 
 
 class GPRCached(object):
     """GP regression model whose Cholesky data is cached for prediction
-    (``functions.py:357-458``).  ``kern`` is an :class:`RBF`; ``mean_function`` a
+    (``functions.py:357-458``).  ``kern`` is a :class:`Kern`; ``mean_function`` a
     :class:`LinearSystem` (or ``None`` for zero mean); ``likelihood_variance`` is gpflow's
     ``likelihood.variance`` (default 1.0, the notebooks overwrite it).  ``scale`` is accepted for
     signature compatibility; it cancels analytically in ``build_predict`` and is not used."""
@@ -340,8 +484,8 @@ class GPRCached(object):
                  likelihood_variance=1.0):
         self.X = np.atleast_2d(np.asarray(x, dtype=config.np_dtype))
         self.Y = np.atleast_2d(np.asarray(y, dtype=config.np_dtype))
-        if not isinstance(kern, RBF):
-            raise TypeError('the HIP engine implements the RBF kernel (BASELINE north_star)')
+        if not isinstance(kern, Kern):
+            raise TypeError('kern must be an RBF, Matern32 or Linear kernel or a sum / product of those')
         if mean_function is not None and not isinstance(mean_function, LinearSystem):
             raise TypeError('mean_function must be a LinearSystem or None')
         self.kern = kern
@@ -378,7 +522,7 @@ class GPRCached(object):
             n = len(self.X)
             k_vec = self.kern.K(self.X, xi)[:, 0]
             row = self.cholesky_inverse.dot(k_vec)                       # l = L^-1 k
-            s2 = self.kern.variance + self.likelihood_variance - row.dot(row)
+            s2 = self.kern.Kdiag(xi)[0] + self.likelihood_variance - row.dot(row)
             if not s2 > 0:
                 raise np.linalg.LinAlgError('kernel matrix is not positive definite')
             s = np.sqrt(s2)

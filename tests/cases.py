@@ -75,9 +75,11 @@ class _LyapunovWithoutValues(oracle.Lyapunov):
         self.values = None
 
 
-def oracle_lyapunov(case, compute_values=True):
+def oracle_lyapunov(case, compute_values=True, dynamics=None):
+    """``dynamics``: a model to use instead of the case's own (kernel cases of gp_cases.py)."""
     grid = oracle.GridWorld(case['limits'], case['num_points'])
-    policy, dynamics, value, lv = oracle_specs(case)
+    policy, own_dynamics, value, lv = oracle_specs(case)
+    dynamics = own_dynamics if dynamics is None else dynamics
     cls = oracle.Lyapunov if compute_values else _LyapunovWithoutValues
     return cls(grid, value, dynamics, case['lf'], lv, case['tau'], policy,
                initial_set=initial_safe_mask(case) if compute_values else None)

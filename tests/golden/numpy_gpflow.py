@@ -14,7 +14,8 @@ through SciPy).
 
 What is restated here, from gpflow 0.4.0's published sources, and nothing more:
 
-* ``kernels.RBF`` (``Stationary.square_dist``: ``-2 (X/l)(X2/l)^T + |X/l|^2 + |X2/l|^2``;
+* ``kernels.RBF`` / ``Matern32`` / ``Linear`` / ``Add`` / ``Prod`` with ``active_dims``
+  (``Stationary.square_dist``: ``-2 (X/l)(X2/l)^T + |X/l|^2 + |X2/l|^2``;
   ``K = variance * exp(-square_dist / 2)``; ``Kdiag = fill(variance)``);
 * ``mean_functions.Zero`` (``zeros([N, 1])``) and ``Linear`` (``X A + b``);
 * ``likelihoods.Gaussian`` (a ``variance`` parameter, default 1.0);
@@ -150,12 +151,31 @@ class Linear(Parameterized):
         return _tf().matmul(X, self.A) + self.b
 
 
-# ---- kernels (gpflow/kernels.py: Stationary, RBF) -----------------------------------------------
+# ---- kernels (gpflow/kernels.py: Kern, Stationary, RBF, Matern32, Linear, Add, Prod) -------------
 
-class RBF(Parameterized):
-    def __init__(self, input_dim, variance=1.0, lengthscales=None, active_dims=None, ARD=False):
-        assert active_dims is None
+class Kern(Parameterized):
+    """``Kern.__init__`` / ``_slice`` / ``__add__`` / ``__mul__`` of gpflow 0.4.0: a kernel reads the
+    columns ``active_dims`` of its inputs (default ``slice(input_dim)``)."""
+
+    def _init_dims(self, input_dim, active_dims):
         self.input_dim = int(input_dim)
+        object.__setattr__(self, "active_dims", slice(self.input_dim) if active_dims is None
+                           else np.asarray(list(active_dims), dtype=np.int64))
+
+    def _slice(self, X, X2):
+        X = X[:, self.active_dims]
+        return X, (None if X2 is None else X2[:, self.active_dims])
+
+    def __add__(self, other):
+        return Add([self, other])
+
+    def __mul__(self, other):
+        return Prod([self, other])
+
+
+class Stationary(Kern):
+    def __init__(self, input_dim, variance=1.0, lengthscales=None, active_dims=None, ARD=False):
+        self._init_dims(input_dim, active_dims)
         self.variance = Param(variance)
         if ARD:
             lengthscales = np.ones(self.input_dim) if lengthscales is None else \
@@ -177,12 +197,79 @@ class RBF(Parameterized):
         return -2 * tf.matmul(X, X2, transpose_b=True) + \
             tf.reshape(Xs, (-1, 1)) + tf.reshape(X2s, (1, -1))
 
-    def K(self, X, X2=None):
-        return self.variance * _tf().exp(-self.square_dist(X, X2) / 2)
+    def euclid_dist(self, X, X2):
+        return _tf().sqrt(self.square_dist(X, X2) + 1e-12)
 
     def Kdiag(self, X):
         tf = _tf()
         return tf.fill(tf.stack([tf.shape(X)[0]]), tf.squeeze(self.variance))
+
+
+class RBF(Stationary):
+    def K(self, X, X2=None):
+        X, X2 = self._slice(X, X2)
+        return self.variance * _tf().exp(-self.square_dist(X, X2) / 2)
+
+
+class Matern32(Stationary):
+    def K(self, X, X2=None):
+        X, X2 = self._slice(X, X2)
+        r = self.euclid_dist(X, X2)
+        return self.variance * (1. + np.sqrt(3.) * r) * _tf().exp(-np.sqrt(3.) * r)
+
+
+class LinearKernel(Kern):
+    """``kernels.Linear`` (the mean function of the same name is ``Linear`` above)."""
+
+    def __init__(self, input_dim, variance=1.0, active_dims=None, ARD=False):
+        self._init_dims(input_dim, active_dims)
+        self.ARD = ARD
+        self.variance = Param(np.ones(self.input_dim) * variance if ARD else variance)
+
+    def K(self, X, X2=None):
+        X, X2 = self._slice(X, X2)
+        return _tf().matmul(X * self.variance, X if X2 is None else X2, transpose_b=True)
+
+    def Kdiag(self, X):
+        tf = _tf()
+        X, _ = self._slice(X, None)
+        return tf.reduce_sum(tf.square(X) * self.variance, 1)
+
+
+class Add(Kern):
+    def __init__(self, kern_list):
+        kerns = []
+        for k in kern_list:                              # Combination: members of the same kind flatten
+            kerns.extend(k.kern_list if type(k) is type(self) else [k])
+        object.__setattr__(self, "kern_list", kerns)
+        for i, k in enumerate(kerns):
+            setattr(self, "kern_%d" % i, k)
+
+    def K(self, X, X2=None):
+        out = self.kern_list[0].K(X, X2)
+        for k in self.kern_list[1:]:
+            out = out + k.K(X, X2)
+        return out
+
+    def Kdiag(self, X):
+        out = self.kern_list[0].Kdiag(X)
+        for k in self.kern_list[1:]:
+            out = out + k.Kdiag(X)
+        return out
+
+
+class Prod(Add):
+    def K(self, X, X2=None):
+        out = self.kern_list[0].K(X, X2)
+        for k in self.kern_list[1:]:
+            out = out * k.K(X, X2)
+        return out
+
+    def Kdiag(self, X):
+        out = self.kern_list[0].Kdiag(X)
+        for k in self.kern_list[1:]:
+            out = out * k.Kdiag(X)
+        return out
 
 
 class Gaussian(Parameterized):
@@ -230,7 +317,8 @@ def module():
     gpflow.param.DataHolder, gpflow.param.Param = DataHolder, Param
     gpflow.param.AutoFlow, gpflow.param.Parameterized = AutoFlow, Parameterized
     gpflow.kernels = types.ModuleType("gpflow.kernels")
-    gpflow.kernels.RBF = RBF
+    gpflow.kernels.RBF, gpflow.kernels.Matern32, gpflow.kernels.Linear = RBF, Matern32, LinearKernel
+    gpflow.kernels.Add, gpflow.kernels.Prod = Add, Prod
     gpflow.mean_functions = types.ModuleType("gpflow.mean_functions")
     gpflow.mean_functions.Zero, gpflow.mean_functions.Linear = Zero, Linear
     gpflow.likelihoods = types.ModuleType("gpflow.likelihoods")

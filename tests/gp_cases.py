@@ -113,3 +113,81 @@ def reference_gp_model(ns, spec, case, fixture):
         for x, y in zip(fixture[name + "/added_x"], fixture[name + "/added_y"]):
             model.add_data_point(x[None, :], y[None, :])
     return model
+
+
+# ---- kernels other than the RBF: Linear + Matern32 * Linear of the reference's notebooks -----------
+# A kernel is a list of products, a product a list of leaves (kind, keyword arguments of the
+# gpflow 0.4.0 constructor).  The pendulum cases follow examples/inverted_pendulum.ipynb:145-158
+# (variances = squared difference of the true and the prior linearisation, clipped at 1e-5).
+
+def _notebook_kernel(variances):
+    return [[("linear", dict(input_dim=3, variance=[float(v) for v in variances], ARD=True))],
+            [("matern32", dict(input_dim=1, lengthscales=1.0, active_dims=[0])),
+             ("linear", dict(input_dim=1, variance=float(variances[1])))]]
+
+
+def kernel_case_list():
+    """-> the cases of ``tests/golden/reference_gp_kernels.npz``: name, grid / policy family, number
+    of training points, one kernel per output column (``FunctionStack`` of single-output GPs)."""
+    nb = [[2.3e-3, 1.1e-5, 4.0e-4], [1.0e-5, 6.2e-4, 2.5e-3]]
+    return [
+        dict(name="notebook_n40", n_gp=40, kernels=[_notebook_kernel(nb[0]), _notebook_kernel(nb[1])]),
+        dict(name="notebook_n130", n_gp=130, kernels=[_notebook_kernel(nb[0]), _notebook_kernel(nb[1])]),
+        dict(name="notebook_n250_added", n_gp=246, add_points=4,
+             kernels=[_notebook_kernel(nb[0]), _notebook_kernel(nb[1])]),
+        # every leaf kind, ARD lengthscales, active dimensions out of order, a product of three
+        dict(name="mixed_n90", n_gp=90, kernels=[
+            [[("matern32", dict(input_dim=3, variance=0.02, lengthscales=[0.6, 0.9, 1.3], ARD=True))],
+             [("rbf", dict(input_dim=2, variance=0.5, lengthscales=[0.8, 1.1], active_dims=[2, 0], ARD=True)),
+              ("linear", dict(input_dim=1, variance=0.01, active_dims=[1])),
+              ("matern32", dict(input_dim=1, variance=1.5, lengthscales=0.7, active_dims=[1]))]],
+            [[("rbf", dict(input_dim=3, variance=0.01, lengthscales=0.9))],
+             [("linear", dict(input_dim=3, variance=[1e-3, 2e-3, 5e-4], ARD=True))]]]),
+    ]
+
+
+def kernel_from_spec(products, lib):
+    """One kernel object from a spec: ``lib`` is the ``gpflow`` stand-in module, the ``oracle``
+    package or ``safe_learning_amd`` (its ``kernels`` namespace)."""
+    import oracle as _oracle
+    if lib is _oracle:
+        leaves = {"rbf": _oracle.np_functions.SlicedRBF, "matern32": _oracle.np_functions.Matern32,
+                  "linear": _oracle.np_functions.Linear}
+    else:
+        k = lib.kernels
+        leaves = {"rbf": k.RBF, "matern32": k.Matern32, "linear": k.Linear}
+    total = None
+    for product in products:
+        term = None
+        for kind, kwargs in product:
+            leaf = leaves[kind](**kwargs)
+            term = leaf if term is None else term * leaf
+        total = term if total is None else total + term
+    return total
+
+
+def kernel_build_case(spec):
+    """Pendulum grid, policy and prior of the parity tests with ``n_gp`` observations of the true
+    dynamics (``safe_learning_amd.benchmarks.make_case``); the GP models come from ``spec``."""
+    from safe_learning_amd.benchmarks import make_case
+    return make_case("pendulum", num_points=[65, 48], n_gp=spec["n_gp"], tau_scale=0.01,
+                     noise_std=0.001, stack=True)
+
+
+def kernel_model(ns, spec, case, fixture, kern_lib=None):
+    """The ``FunctionStack`` of a kernel case from the classes of ``ns`` (``oracle`` or
+    ``safe_learning_amd``), with the observations the fixture added."""
+    import numpy as np
+    name, d, dyn = spec["name"], case["d"], case["dynamics"]
+    assert np.array_equal(dyn["X"], fixture[name + "/X"]) and np.array_equal(dyn["Y"], fixture[name + "/Y"])
+    heads = []
+    for k in range(d):
+        kern = kernel_from_spec(spec["kernels"][k], ns if kern_lib is None else kern_lib)
+        gp = ns.GPRCached(dyn["X"], dyn["Y"][:, [k]], kern, ns.LinearSystem((dyn["prior"][[k], :],)),
+                          likelihood_variance=dyn["noise_variance"])
+        heads.append(ns.GaussianProcess(gp, dyn["beta"]))
+    model = ns.FunctionStack(heads)
+    if "add_points" in spec:
+        for x, y in zip(fixture[name + "/added_x"], fixture[name + "/added_y"]):
+            model.add_data_point(x[None, :], y[None, :])
+    return model

@@ -1,0 +1,121 @@
+"""``k_gp_small`` with the kernels of the reference's notebooks against the reference's own GP code
+(needs an MI355X).
+
+``tests/golden/reference_gp_kernels.npz``: ``FunctionStack``s of single-output GPs with
+``Linear + Matern32 * Linear`` kernels (``examples/inverted_pendulum.ipynb:152-181``) and a case
+with every leaf kind, evaluated by the reference's ``GPRCached`` / ``GaussianProcess`` /
+``FunctionStack`` behind the stand-ins (``tests/golden/make_reference_gp_kernels.py``).  Here the
+per-cell records of the grid sweep and the explicit-point entry are compared with the FIXTURE, a
+whole ``update_safe_set`` with the oracle, and the paths that do not take such kernels must say so.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from gp_cases import (kernel_build_case, kernel_case_list, kernel_model, reference_gp_tolerance)
+from test_gpu_reference_gp import sweep_records
+
+pytestmark = pytest.mark.gpu
+
+FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_gp_kernels.npz")
+SPECS = kernel_case_list()
+
+
+@pytest.fixture(scope="module")
+def fixture():
+    return np.load(FIXTURE)
+
+
+def build(spec, case, fixture):
+    import safe_learning_amd as sl
+    from safe_learning_amd.benchmarks import build_specs, initial_safe_mask
+    dynamics = kernel_model(sl, spec, case, fixture)
+    policy, _, value, lv = build_specs(case)
+    lyap = sl.Lyapunov(sl.GridWorld(case["limits"], case["num_points"]), value, dynamics, case["lf"],
+                       lv, case["tau"], policy, initial_set=initial_safe_mask(case))
+    return lyap, dynamics
+
+
+@pytest.mark.parametrize("spec", SPECS, ids=[s["name"] for s in SPECS])
+def test_sweep_reproduces_the_reference_posterior(spec, fixture):
+    from safe_learning_amd import _evaluate
+    name = spec["name"]
+    case = kernel_build_case(spec)
+    d = case["d"]
+    lyap, dynamics = build(spec, case, fixture)
+    lyap._upload_model()
+    lyap._refresh_init_bits()
+    tol = reference_gp_tolerance(float(fixture[name + "/cond"]))
+    rec, kernels = sweep_records(lyap, fixture[name + "/cell_index"])
+    assert all(k.startswith("k_gp_small") for k in kernels), kernels
+    want_mean, want_bound = fixture[name + "/cell_mean"], fixture[name + "/cell_bound"]
+    scale = np.abs(want_mean).max(axis=0)
+    assert np.all(np.abs(rec[:, 2:2 + d] - want_mean) <= tol * scale), (name, "mean")
+    assert np.all(np.abs(rec[:, 2 + d:] - want_bound) <= tol * want_bound), (name, "bound")
+    q = fixture[name + "/extra_inputs"]
+    mean, bound = _evaluate.dynamics(dynamics, q[:, :d], q[:, d:])
+    want_mean, want_bound = fixture[name + "/extra_mean"], fixture[name + "/extra_bound"]
+    scale = np.abs(want_mean).max(axis=0)
+    assert np.all(np.abs(mean - want_mean) <= tol * scale), (name, "points mean")
+    assert np.all(np.abs(bound - want_bound) <= tol * want_bound), (name, "points bound")
+
+
+@pytest.mark.parametrize("spec", SPECS[:2] + SPECS[3:], ids=[s["name"] for s in SPECS[:2] + SPECS[3:]])
+def test_update_safe_set_matches_the_oracle(spec, fixture):
+    """The whole level-set rule on a model with notebook kernels: masks, safe sets and c_max equal
+    the oracle's, and the workload is not degenerate."""
+    name = spec["name"]
+    case = kernel_build_case(spec)
+    lyap, _ = build(spec, case, fixture)
+    odyn = kernel_model(oracle, spec, case, fixture)
+    olyap = cases.oracle_lyapunov(case, dynamics=odyn)
+    for _ in range(2):
+        lyap.update_safe_set()
+        olyap.update_safe_set()
+        np.testing.assert_array_equal(lyap.safe_set, olyap.safe_set)
+        assert lyap.c_max == olyap.c_max
+    n = lyap.discretization.nindex
+    neg = np.unpackbits(lyap._d_neg.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+    ref_neg = olyap.negative(olyap.discretization.index_to_state(np.arange(n)))
+    assert (neg != ref_neg).sum() == 0
+    assert neg.any() and (~neg).any(), name
+
+
+def test_added_points_follow_the_rank_one_path(fixture):
+    """``add_data_point`` on an uploaded model: the engine extends the head in place."""
+    spec = SPECS[2]
+    case = kernel_build_case(spec)
+    lyap, dynamics = build({k: v for k, v in spec.items() if k != "add_points"}, case, fixture)
+    lyap.update_safe_set()
+    for x, y in zip(fixture[spec["name"] + "/added_x"], fixture[spec["name"] + "/added_y"]):
+        dynamics.add_data_point(x[None, :], y[None, :])
+    lyap._upload_model()
+    lyap._refresh_init_bits()
+    d = case["d"]
+    tol = reference_gp_tolerance(float(fixture[spec["name"] + "/cond"]))
+    rec, _ = sweep_records(lyap, fixture[spec["name"] + "/cell_index"])
+    want_mean, want_bound = fixture[spec["name"] + "/cell_mean"], fixture[spec["name"] + "/cell_bound"]
+    assert np.all(np.abs(rec[:, 2:2 + d] - want_mean) <= tol * np.abs(want_mean).max(axis=0))
+    assert np.all(np.abs(rec[:, 2 + d:] - want_bound) <= tol * want_bound)
+
+
+def test_unsupported_paths_say_so():
+    import safe_learning_amd as sl
+    from safe_learning_amd import kernels
+    from safe_learning_amd.benchmarks import build_specs, initial_safe_mask
+    # more than 256 training points: only the RBF has the large-set kernels
+    case = cases.make_case("pendulum", num_points=33, n_gp=300, stack=True)
+    dyn = case["dynamics"]
+    heads = []
+    for k in range(2):
+        gp = sl.GPRCached(dyn["X"], dyn["Y"][:, [k]], kernels.Matern32(3, 0.05 ** 2, 0.5),
+                          sl.LinearSystem((dyn["prior"][[k], :],)), likelihood_variance=dyn["noise_variance"])
+        heads.append(sl.GaussianProcess(gp, dyn["beta"]))
+    policy, _, value, lv = build_specs(case)
+    with pytest.raises(sl.HipEngineError, match="256"):      # the model is uploaded by the constructor
+        sl.Lyapunov(sl.GridWorld(case["limits"], case["num_points"]), value, sl.FunctionStack(heads),
+                    case["lf"], lv, case["tau"], policy, initial_set=initial_safe_mask(case))
