@@ -22,6 +22,7 @@ class ModelBuilder(object):
         self.ctx = ctx
         self.grid = grid
         self._gp_signature = None
+        self._gp_placeholder = set()       # heads uploaded for a model without observations
         self._tri_signature = [None, None]
         self._tri_structure = [None, None]
         self._net_signature = None
@@ -122,14 +123,21 @@ class ModelBuilder(object):
                                  % (gp.X.shape[1], p))
             if same_heads and old[h][0] == gp._version:
                 continue                                # this head is already on the device
-            if same_heads and self._follow_appends(h, gp, old[h][0]):
+            if (same_heads and h not in self._gp_placeholder
+                    and self._follow_appends(h, gp, old[h][0])):
                 continue                                # add_data_point: new rows only
+            X, Linv, alpha = gp.X, gp.cholesky_inverse, gp.alpha
+            self._gp_placeholder.discard(h)
+            if len(X) == 0:
+                self._gp_placeholder.add(h)             # nothing to extend by rank-one rows later
+                # a model without observations (the notebooks start that way,
+                # inverted_pendulum.ipynb:166-176): the posterior is the prior - one training
+                # point with a zero row of L^-1 and a zero alpha contributes nothing
+                X, Linv, alpha = np.zeros((1, p)), np.zeros((1, 1)), np.zeros((1, gp.Y.shape[1]))
             if _is_plain_rbf(gp.kern, p):
-                self.ctx.gp_set_head(h, gp.X, gp.cholesky_inverse, gp.alpha, col0, gp.kern.variance,
-                                     gp.kern.lengthscales)
+                self.ctx.gp_set_head(h, X, Linv, alpha, col0, gp.kern.variance, gp.kern.lengthscales)
             else:                                       # Linear / Matern32 / sums and products
-                self.ctx.gp_set_head_kernel(h, gp.X, gp.cholesky_inverse, gp.alpha, col0,
-                                            gp.kern._factors(p))
+                self.ctx.gp_set_head_kernel(h, X, Linv, alpha, col0, gp.kern._factors(p))
         self.ctx.gp_configure(len(heads), beta)
         self._gp_signature = signature
 

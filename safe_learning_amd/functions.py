@@ -499,13 +499,16 @@ class GPRCached(object):
         """Cholesky factor, its inverse and ``alpha = L^-1 (Y - m(X))`` (``functions.py:395-415``)."""
         n = len(self.X)
         gram = self.kern.K(self.X) + self.likelihood_variance * np.eye(n)
-        self.cholesky = scipy.linalg.cholesky(gram, lower=True)
+        self.cholesky = scipy.linalg.cholesky(gram, lower=True) if n else np.zeros((0, 0))
         resid = self.Y.copy()
         if self.mean_function is not None:
             resid = resid - self.X.dot(self.mean_function.matrix.T)
-        self.alpha = scipy.linalg.solve_triangular(self.cholesky, resid, lower=True)
-        self.cholesky_inverse = scipy.linalg.solve_triangular(self.cholesky, np.eye(n), lower=True)
-        self.cholesky_inverse = np.tril(self.cholesky_inverse)
+        if n == 0:                                      # no observations yet: the prior
+            self.alpha, self.cholesky_inverse = np.zeros_like(resid), np.zeros((0, 0))
+        else:
+            self.alpha = scipy.linalg.solve_triangular(self.cholesky, resid, lower=True)
+            self.cholesky_inverse = scipy.linalg.solve_triangular(self.cholesky, np.eye(n), lower=True)
+            self.cholesky_inverse = np.tril(self.cholesky_inverse)
         self._version = next(_TOKENS)
         self._append_log = []          # rank-one extensions since the last full rebuild
 
@@ -522,7 +525,9 @@ class GPRCached(object):
             n = len(self.X)
             k_vec = self.kern.K(self.X, xi)[:, 0]
             row = self.cholesky_inverse.dot(k_vec)                       # l = L^-1 k
-            s2 = self.kern.Kdiag(xi)[0] + self.likelihood_variance - row.dot(row)
+            # K(x, x) as the rebuild of functions.py:401 forms it (kern.K, not kern.Kdiag: the
+            # two differ by 1.5e-12 for a Matern32 leaf, whose distance carries euclid_dist's 1e-12)
+            s2 = self.kern.K(xi)[0, 0] + self.likelihood_variance - row.dot(row)
             if not s2 > 0:
                 raise np.linalg.LinAlgError('kernel matrix is not positive definite')
             s = np.sqrt(s2)

@@ -119,3 +119,50 @@ def test_unsupported_paths_say_so():
     with pytest.raises(sl.HipEngineError, match="256"):      # the model is uploaded by the constructor
         sl.Lyapunov(sl.GridWorld(case["limits"], case["num_points"]), value, sl.FunctionStack(heads),
                     case["lf"], lv, case["tau"], policy, initial_set=initial_safe_mask(case))
+
+
+def test_notebook_flow_from_a_model_without_observations(fixture):
+    """``inverted_pendulum.ipynb:166-176`` builds its GPs on ``np.empty((0, 3))`` and adds the
+    observations one by one: the engine's posterior is the prior first, follows every
+    ``add_data_point`` (full upload for the first point, rank-one rows afterwards), and the level
+    sets equal the oracle's at every stage."""
+    import safe_learning_amd as sl
+    from safe_learning_amd.benchmarks import build_specs, initial_safe_mask
+    from gp_cases import kernel_from_spec
+    spec = SPECS[0]
+    case = kernel_build_case(spec)
+    d, dyn = case["d"], case["dynamics"]
+
+    def stack(ns):
+        heads = []
+        for k in range(d):
+            kern = kernel_from_spec(spec["kernels"][k], ns)
+            gp = ns.GPRCached(np.empty((0, d + 1)), np.empty((0, 1)), kern,
+                              ns.LinearSystem((dyn["prior"][[k], :],)),
+                              likelihood_variance=dyn["noise_variance"])
+            heads.append(ns.GaussianProcess(gp, dyn["beta"]))
+        return ns.FunctionStack(heads)
+
+    dynamics, odynamics = stack(sl), stack(oracle)
+    policy, _, value, lv = build_specs(case)
+    lyap = sl.Lyapunov(sl.GridWorld(case["limits"], case["num_points"]), value, dynamics, case["lf"],
+                       lv, case["tau"], policy, initial_set=initial_safe_mask(case))
+    olyap = cases.oracle_lyapunov(case, dynamics=odynamics)
+    n = lyap.discretization.nindex
+    sizes = []
+    for stage in range(4):
+        if stage:
+            for x, y in zip(dyn["X"][3 * stage - 3:3 * stage], dyn["Y"][3 * stage - 3:3 * stage]):
+                dynamics.add_data_point(x[None, :], y[None, :])
+                odynamics.add_data_point(x[None, :], y[None, :])
+        lyap.update_safe_set()
+        olyap.update_safe_set()
+        assert lyap._ctx.last_kernel().startswith("k_gp_small")
+        np.testing.assert_array_equal(lyap.safe_set, olyap.safe_set)
+        assert lyap.c_max == olyap.c_max
+        rec = cases.oracle_cell_records(olyap, np.arange(n))
+        got, _ = sweep_records(lyap, np.arange(n))
+        np.testing.assert_allclose(got[:, 2:], rec[:, 2:], rtol=1e-9, atol=1e-13)
+        sizes.append(int(lyap.safe_set.sum()))
+    assert len(dynamics.functions[0].X) == 9
+    assert sizes[-1] > sizes[0]                 # the observations shrink the error bounds

@@ -144,3 +144,27 @@ def test_kernel_algebra():
     with pytest.raises(TypeError):
         from safe_learning_amd.functions import GPRCached
         GPRCached(X, X[:, :1], kern="rbf")
+
+
+def test_model_without_observations_is_the_prior():
+    """``inverted_pendulum.ipynb:166-176`` starts from ``np.empty((0, 3))``: mean = the mean function,
+    variance = ``Kdiag``; the first ``add_data_point`` yields what a one-point model holds."""
+    import safe_learning_amd as sl
+    from safe_learning_amd import kernels as K
+    kern = K.Linear(3, [0.1, 0.2, 0.3], ARD=True) + K.Matern32(1, active_dims=[0]) * K.Linear(1, 0.5)
+    okern = kernel_from_spec([[("linear", dict(input_dim=3, variance=[0.1, 0.2, 0.3], ARD=True))],
+                              [("matern32", dict(input_dim=1, active_dims=[0])),
+                               ("linear", dict(input_dim=1, variance=0.5))]], oracle)
+    prior = np.array([[0.5, -0.2, 0.1]])
+    gp = sl.GPRCached(np.empty((0, 3)), np.empty((0, 1)), kern, sl.LinearSystem((prior,)), likelihood_variance=1e-4)
+    ogp = oracle.GPRCached(np.empty((0, 3)), np.empty((0, 1)), okern, oracle.LinearSystem((prior,)), likelihood_variance=1e-4)
+    q = np.random.default_rng(2).normal(size=(5, 3))
+    mean, var = ogp.build_predict(q)
+    np.testing.assert_allclose(mean, q.dot(prior.T), rtol=1e-15)
+    np.testing.assert_allclose(var[:, 0], kern.Kdiag(q), rtol=1e-14)
+    assert gp.alpha.shape == (0, 1) and gp.cholesky_inverse.shape == (0, 0)
+    x, y = np.array([[0.3, -0.4, 0.2]]), np.array([[0.7]])
+    gp.append_data(x, y)
+    one = sl.GPRCached(x, y, kern, sl.LinearSystem((prior,)), likelihood_variance=1e-4)
+    np.testing.assert_allclose(gp.alpha, one.alpha, rtol=1e-13)
+    np.testing.assert_allclose(gp.cholesky_inverse, one.cholesky_inverse, rtol=1e-13)
