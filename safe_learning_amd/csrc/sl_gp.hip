@@ -111,6 +111,7 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
             const int n_pad = hd.n_pad, dout = hd.dout;
             const int nslab2 = hd.nslab2;
             const double variance = hd.variance;
+            const sl_gp_kernel* __restrict__ kern = hd.kernel;    // null: the RBF of sl_gp_set_head
             const double* __restrict__ alphap = alpha_doubles > 0 ? alpha_l : hd.alpha;
             const double* __restrict__ mpack = hd.mpack;
             const double* __restrict__ xs_glob = hd.xs;
@@ -163,15 +164,19 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
                         const int s = f / CB;
                         const int j = 64 * ch + 4 * s + lk;
                         double z = 0.0;
+                        double xa[SL_P];
 #pragma unroll
                         for (int q = 0; q < SL_P; ++q) {
+                            xa[q] = 0.0;
                             if (q < p) {
                                 const double xv = XSG ? xs_glob[q * n_pad + j] : xs_l[q * n_pad + j];
                                 const double dlt = xv - xg[q];
                                 z = fma(dlt, dlt, z);
+                                xa[q] = xv;
                             }
                         }
-                        const double kx = variance * exp(-0.5 * z);
+                        // (sum-of-products kernels: inputs unscaled, sl_gp_set_head_kernel)
+                        const double kx = kern ? sl_kernel_eval(*kern, p, xa, xg) : variance * exp(-0.5 * z);
                         if (add_mean) {
 #pragma unroll
                             for (int dd = 0; dd < DOUT_UNROLL; ++dd)
@@ -287,7 +292,17 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
             if (tid < C) {
                 double sumsq = 0.0;
                 for (int w = 0; w < W; ++w) sumsq += part_ss[w * C + tid];
-                const double var = variance - sumsq;                       // functions.py:451
+                double prior_var = variance;                               // functions.py:450
+                if (kern) {                        // Kdiag of the cell's own input
+                    double xc[SL_P], uc[SL_M];
+                    int64_t gi = tile_base + tid;
+                    gi = gi < hi ? gi : hi - 1;
+                    sl_cell_state(M, d, gi, points, xc);
+                    sl_policy_any<GENERAL>(M, nd, aux.tri, gi, xc, uc);
+                    sl_append_action(nd, uc, xc);
+                    prior_var = sl_kernel_diag(*kern, p, xc);
+                }
+                const double var = prior_var - sumsq;                      // functions.py:451
                 const double e = gp.beta * sqrt(var);                      // functions.py:514
                 const int cb = tid >> 4, cc = tid & 15;
                 for (int dd = 0; dd < dout; ++dd) {
@@ -384,10 +399,6 @@ static int gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0, 
     for (int q = 0; q < p; ++q)
         if (!(h_lengthscales[q] > 0.0))
             return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head: lengthscale <= 0");
-    if (h_kernel && n > 256)
-        return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_gp_set_head_kernel: %d training points; kernels "
-                       "other than the RBF of sl_gp_set_head are implemented for up to 256 "
-                       "(k_gp_small, the shape of the reference's notebooks)", n);
     const int cfg = choose_cfg(n);
     const int rp = cfg_panel_rows(cfg);
     const int n_pad = ((n + rp - 1) / rp) * rp;
@@ -655,19 +666,15 @@ int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
     // heads with a sum-of-products kernel (sl_gp_set_head_kernel): k_gp_small evaluates those
     bool other_kernels = false;
     for (int h = 0; h < ctx->h_gp.nheads; ++h) other_kernels = other_kernels || ctx->gp_heads[h].d_kernel;
-    if (other_kernels) {
-        if (!sl_gp_small_supports(ctx, model))
-            return sl_fail(ctx, SL_ERR_UNSUPPORTED, "a GP head has a kernel other than sl_gp_set_head's "
-                           "RBF: those run on k_gp_small (every head <= 256 training points, its "
-                           "tables within LDS), which does not take this model");
+    // (k_gp_small and k_gp_sweep evaluate them; k_gp_sweep4 generates RBF values by recurrence)
+    if (other_kernels && sl_gp_small_supports(ctx, model))
         return sl_gp_small_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
                                   d_dbg, d_points);
-    }
     // small training sets (one head, capacity <= 256 points): a wavefront per 64-cell tile
     if (ctx->gp_cfg == 0 && sl_gp_small_supports(ctx, model))
         return sl_gp_small_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
                                   d_dbg, d_points);
-    if (ctx->gp_cfg == 2 && sl_gp4_supports(model))
+    if (ctx->gp_cfg == 2 && !other_kernels && sl_gp4_supports(model))
         return sl_gp4_sweep_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
                                    d_dbg, d_points);
     // training inputs too large to sit in LDS beside the k_x buffers: 64-cell-tile configuration

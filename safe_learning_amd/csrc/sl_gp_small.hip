@@ -298,10 +298,8 @@ static size_t lds_capacity(bool general) {
 // the heads' inputs / alpha' / the check's scratch fit LDS (a 6-D stack of six 256-point heads
 // does not: it stays on k_gp_sweep)
 bool sl_gp_small_supports(sl_ctx* ctx, const SlDevModel& model) {
-    bool other_kernels = false;
-    for (int k = 0; k < ctx->h_gp.nheads; ++k) other_kernels = other_kernels || ctx->gp_heads[k].d_kernel;
     const char* env = getenv("SL_GP_SMALL");
-    if (env && env[0] == '0' && !other_kernels) return false;
+    if (env && env[0] == '0') return false;
     if (ctx->h_gp.nheads < 1) return false;
     for (int k = 0; k < ctx->h_gp.nheads; ++k) {
         const SlGpHeadHost& h = ctx->gp_heads[k];

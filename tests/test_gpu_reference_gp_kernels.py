@@ -16,7 +16,8 @@ import pytest
 
 import cases
 import oracle
-from gp_cases import (kernel_build_case, kernel_case_list, kernel_model, reference_gp_tolerance)
+from gp_cases import (kernel_build_case, kernel_case_list, kernel_from_spec, kernel_model,
+                      reference_gp_tolerance)
 from test_gpu_reference_gp import sweep_records
 
 pytestmark = pytest.mark.gpu
@@ -103,22 +104,62 @@ def test_added_points_follow_the_rank_one_path(fixture):
     assert np.all(np.abs(rec[:, 2 + d:] - want_bound) <= tol * want_bound)
 
 
-def test_unsupported_paths_say_so():
-    import safe_learning_amd as sl
-    from safe_learning_amd import kernels
-    from safe_learning_amd.benchmarks import build_specs, initial_safe_mask
-    # more than 256 training points: only the RBF has the large-set kernels
-    case = cases.make_case("pendulum", num_points=33, n_gp=300, stack=True)
+def _matern_stack(ns, kern_lib, case, n):
     dyn = case["dynamics"]
     heads = []
-    for k in range(2):
-        gp = sl.GPRCached(dyn["X"], dyn["Y"][:, [k]], kernels.Matern32(3, 0.05 ** 2, 0.5),
-                          sl.LinearSystem((dyn["prior"][[k], :],)), likelihood_variance=dyn["noise_variance"])
-        heads.append(sl.GaussianProcess(gp, dyn["beta"]))
+    for k in range(case["d"]):
+        kern = kernel_from_spec([[("matern32", dict(input_dim=3, variance=0.05 ** 2, lengthscales=[0.5, 0.6, 0.7], ARD=True))],
+                                 [("linear", dict(input_dim=3, variance=[1e-4, 2e-4, 1e-4], ARD=True))]], kern_lib)
+        gp = ns.GPRCached(dyn["X"][:n], dyn["Y"][:n, [k]], kern, ns.LinearSystem((dyn["prior"][[k], :],)),
+                          likelihood_variance=dyn["noise_variance"])
+        heads.append(ns.GaussianProcess(gp, dyn["beta"]))
+    return ns.FunctionStack(heads)
+
+
+@pytest.mark.parametrize("n,cfg", [(300, None), (130, "3"), (130, "1")], ids=["n300", "n130_cfg3", "n130_cfg1"])
+def test_large_sets_run_on_the_16x16x4_kernel(n, cfg, monkeypatch):
+    """More than 256 training points (or a forced configuration): ``k_gp_sweep`` evaluates the
+    leaves; records, masks and the safe set equal the oracle's."""
+    import safe_learning_amd as sl
+    from safe_learning_amd.benchmarks import build_specs, initial_safe_mask
+    if cfg is not None:
+        monkeypatch.setenv("SL_GP_CFG", cfg)
+        monkeypatch.setenv("SL_GP_SMALL", "0")
+    case = cases.make_case("pendulum", num_points=[40, 33], n_gp=300, stack=True, tau_scale=0.01,
+                           noise_std=0.001)
+    dynamics, odynamics = _matern_stack(sl, sl, case, n), _matern_stack(oracle, oracle, case, n)
     policy, _, value, lv = build_specs(case)
-    with pytest.raises(sl.HipEngineError, match="256"):      # the model is uploaded by the constructor
-        sl.Lyapunov(sl.GridWorld(case["limits"], case["num_points"]), value, sl.FunctionStack(heads),
-                    case["lf"], lv, case["tau"], policy, initial_set=initial_safe_mask(case))
+    lyap = sl.Lyapunov(sl.GridWorld(case["limits"], case["num_points"]), value, dynamics, case["lf"],
+                       lv, case["tau"], policy, initial_set=initial_safe_mask(case))
+    olyap = cases.oracle_lyapunov(case, dynamics=odynamics)
+    lyap.update_safe_set()
+    olyap.update_safe_set()
+    assert lyap._ctx.last_kernel().startswith("k_gp_sweep<"), lyap._ctx.last_kernel()
+    np.testing.assert_array_equal(lyap.safe_set, olyap.safe_set)
+    assert lyap.c_max == olyap.c_max
+    nidx = lyap.discretization.nindex
+    got, _ = sweep_records(lyap, np.arange(nidx))
+    rec = cases.oracle_cell_records(olyap, np.arange(nidx))
+    np.testing.assert_allclose(got[:, 2:], rec[:, 2:], rtol=1e-8, atol=1e-12)
+    neg = got[:, 0] < got[:, 1]
+    assert neg.any() and (~neg).any()
+
+
+def test_policy_iteration_refuses_other_kernels():
+    """The Bellman kernels generate RBF values: a model with another kernel must be refused, not
+    evaluated with the wrong formula."""
+    import scipy.linalg
+    import safe_learning_amd as sl
+    from safe_learning_amd.benchmarks import build_specs
+    case = cases.make_case("pendulum", num_points=17, n_gp=60, stack=True)
+    dynamics = _matern_stack(sl, sl, case, 60)
+    policy, _, _, _ = build_specs(case)
+    vgrid = sl.GridWorld(case["limits"], 17)
+    vf = sl.Triangulation(vgrid, np.zeros((vgrid.nindex, 1)), project=True)
+    qmat = -scipy.linalg.block_diag(np.eye(2), 0.1 * np.eye(1))
+    rl = sl.PolicyIteration(policy, dynamics, sl.QuadraticFunction(qmat), vf, gamma=0.95)
+    with pytest.raises(sl.HipEngineError, match="RBF"):
+        rl.value_iteration()
 
 
 def test_notebook_flow_from_a_model_without_observations(fixture):
