@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 FP64_MFMA_PEAK_TFLOPS = 78.6        # MI355X FP64 matrix (= vector) peak, SURVEY 8d / BASELINE.md
 HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 HEADLINE_METRIC = "grid-cell Lyapunov checks/sec + ms/safe_set-update, 4D 128^4 grid, 1k-pt GP"
-CONFIGS = ("C1", "C2", "C2-table", "C2-table-large", "C2-table-stack", "C2-table-det", "C3", "C4", "C4-lin",
+CONFIGS = ("C1", "C2", "C2-table", "C2-table-large", "C2-table-stack", "C2-notebook", "C2-table-det", "C3", "C4", "C4-lin",
            "C4-det", "C5", "C5-policy")
 
 
@@ -73,19 +73,24 @@ def build_workload(args):
         npts, n_gp = args.num_points or 256, args.n_gp or 512
         case = make_case("pendulum", num_points=npts, n_gp=n_gp, tau_scale=0.01, **informed)
         label = "pendulum %d^2 GridWorld, %d-point RBF GP dynamics, quadratic V" % (npts, n_gp)
-    elif cfg in ("C2-table", "C2-table-large", "C2-table-stack", "C2-table-det"):
-        from safe_learning_amd.benchmarks import table_case
+    elif cfg in ("C2-table", "C2-table-large", "C2-table-stack", "C2-notebook", "C2-table-det"):
+        from safe_learning_amd.benchmarks import notebook_kernels, table_case
         shape = (args.num_points,) * 2 if args.num_points else (
             (251, 251) if cfg == "C2-table" else (2001, 1501))
         det = cfg == "C2-table-det"
         # C2-table-stack: the notebooks' dynamics model proper - a FunctionStack of one
         # single-output GP per state dimension (inverted_pendulum.ipynb:152-181)
         case = table_case(num_points=shape, n_gp=args.n_gp or 128,
-                          dynamics="analytic" if det else None, stack=cfg == "C2-table-stack")
+                          dynamics="analytic" if det else None,
+                          stack=cfg in ("C2-table-stack", "C2-notebook"))
+        if cfg == "C2-notebook":     # ... with the notebook's kernels: Linear + Matern32 * Linear
+            case["dynamics"]["kernels"] = notebook_kernels(case)
         label = ("pendulum %dx%d GridWorld, %s dynamics, V and policy piecewise-linear "
                  "tables on 101x101 vertices, L_v = |grad V| (inverted_pendulum.ipynb cell 14)"
                  % (shape[0], shape[1], "explicit-Euler pendulum" if det
-                    else ("FunctionStack of two %d-point RBF GPs" if cfg == "C2-table-stack"
+                    else ("FunctionStack of two %d-point Linear + Matern32 x Linear GPs"
+                          if cfg == "C2-notebook" else
+                          "FunctionStack of two %d-point RBF GPs" if cfg == "C2-table-stack"
                           else "%d-point RBF GP") % (args.n_gp or 128)))
     elif cfg == "C3":
         npts, n_gp = args.num_points or 2048, args.n_gp or 2048

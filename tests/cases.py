@@ -7,6 +7,10 @@ import oracle
 from safe_learning_amd.benchmarks import initial_safe_mask, make_case  # noqa: F401
 
 
+ORACLE_KERNEL_LEAVES = {'rbf': oracle.np_functions.SlicedRBF, 'matern32': oracle.np_functions.Matern32,
+                        'linear': oracle.np_functions.Linear}
+
+
 def oracle_specs(case):
     if 'policy_table' in case:
         tab = case['policy_table']
@@ -30,7 +34,11 @@ def oracle_specs(case):
         if case['stack']:
             heads = []
             for k in range(d):
-                kern = oracle.RBF(d + 1, dyn['variance'], dyn['lengthscales'][k], ARD=True)
+                if 'kernels' in dyn:
+                    from safe_learning_amd.benchmarks import kernel_from_products
+                    kern = kernel_from_products(dyn['kernels'][k], ORACLE_KERNEL_LEAVES)
+                else:
+                    kern = oracle.RBF(d + 1, dyn['variance'], dyn['lengthscales'][k], ARD=True)
                 gp = oracle.GPRCached(dyn['X'], dyn['Y'][:, [k]], kern,
                                       oracle.LinearSystem((dyn['prior'][[k], :],)),
                                       likelihood_variance=dyn['noise_variance'])

@@ -150,20 +150,14 @@ def kernel_from_spec(products, lib):
     """One kernel object from a spec: ``lib`` is the ``gpflow`` stand-in module, the ``oracle``
     package or ``safe_learning_amd`` (its ``kernels`` namespace)."""
     import oracle as _oracle
+    from safe_learning_amd.benchmarks import kernel_from_products
     if lib is _oracle:
         leaves = {"rbf": _oracle.np_functions.SlicedRBF, "matern32": _oracle.np_functions.Matern32,
                   "linear": _oracle.np_functions.Linear}
     else:
         k = lib.kernels
         leaves = {"rbf": k.RBF, "matern32": k.Matern32, "linear": k.Linear}
-    total = None
-    for product in products:
-        term = None
-        for kind, kwargs in product:
-            leaf = leaves[kind](**kwargs)
-            term = leaf if term is None else term * leaf
-        total = term if total is None else total + term
-    return total
+    return kernel_from_products(products, leaves)
 
 
 def kernel_build_case(spec):
