@@ -395,6 +395,88 @@ extern "C" int sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values) 
 }
 
 // =============================================================================================
+// table flavours on large training sets: action table, then k_gp_sweep4, then the check
+// =============================================================================================
+// A GP model whose V, L_v or policy is a piecewise-linear table cannot run inside k_gp_sweep4
+// (its workgroups have no LDS left for the table descriptors); on more than 256 training points
+// the sweep is therefore cut in three: the interpolated policy becomes a per-cell action table
+// (k_policy_table), k_gp_sweep4 writes the posterior records of the closed loop with that table as
+// its policy, and k_check_records runs the decrease check with the real V and L_v on the records
+// (56 bytes per cell written and read back at d = 2, against ~0.5 MFLOP per cell at n = 512).
+template <bool GENERAL, int DT, int MT>
+__global__ __launch_bounds__(SL_BLOCK) void k_policy_table(const SlDevModel M_arg, SlAux aux_arg,
+                                                           int64_t lo, int64_t hi,
+                                                           const double* __restrict__ points,
+                                                           double* __restrict__ actions) {
+    __shared__ SlTriLds<GENERAL> tri_lds;
+    const SlAux aux = sl_stage_aux<GENERAL>(tri_lds, aux_arg);
+    const SlDevModel& M = M_arg;
+    const SlDims n = sl_dims<DT, MT>(M);
+    for (int64_t idx = lo + (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; idx < hi;
+         idx += (int64_t)gridDim.x * SL_BLOCK) {
+        double x[SL_P], u[SL_M];
+        sl_cell_state(M, n.d, idx, points, x);
+        sl_policy_any<GENERAL>(M, n, aux.tri, idx, x, u);
+#pragma unroll
+        for (int a = 0; a < SL_M; ++a) if (a < n.m) actions[(idx - lo) * n.m + a] = u[a];
+    }
+}
+
+// records: [decrease, threshold, mean[d], err[d]] per cell of [lo, hi) from the posterior-only pass
+template <bool GENERAL, int DT, int MT>
+__global__ __launch_bounds__(SL_BLOCK) void k_check_records(
+    const SlDevModel M_arg, SlAux aux_arg, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
+    const double* __restrict__ values, const double* __restrict__ records,
+    uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
+    const double* __restrict__ points) {
+    __shared__ uint64_t sv[SL_BLOCK / 64];
+    __shared__ int64_t si[SL_BLOCK / 64];
+    __shared__ SlTriLds<GENERAL> tri_lds;
+    const SlAux aux = sl_stage_aux<GENERAL>(tri_lds, aux_arg);
+    const SlDevModel& M = M_arg;
+    const SlDims n = sl_dims<DT, MT>(M);
+    const int d = n.d;
+    const int lane = threadIdx.x & 63;
+    uint64_t best_v = ~0ull;
+    int64_t best_i = INT64_MAX;
+    for (int64_t base = lo + (int64_t)blockIdx.x * SL_BLOCK; base < hi;
+         base += (int64_t)gridDim.x * SL_BLOCK) {
+        const int64_t idx = base + threadIdx.x;
+        const bool valid = idx < hi;
+        const int64_t wbase = base + (threadIdx.x & ~63);        // first cell of this wavefront
+        const uint64_t init = (init_bits && wbase < hi) ? init_bits[(wbase - lo) >> 6] : 0ull;
+        bool negative = false;
+        double v_x = 0.0;
+        if (valid) {
+            double x[SL_P], u[SL_M], mean[SL_D], err[SL_D];
+            const double* rec = records + (idx - lo) * (2 + 2 * d);
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) if (k < d) { mean[k] = rec[2 + k]; err[k] = rec[2 + d + k]; }
+            sl_cell_state(M, d, idx, points, x);
+            sl_policy_any<GENERAL>(M, n, aux.tri, idx, x, u);
+            sl_append_action(n, u, x);
+            SlCellCheck c = sl_cell_check<SlSweepFlavour<GENERAL>::value>(M, d, aux, x, mean, err);
+            negative = c.negative;
+            v_x = values ? values[idx - lo] : c.v_x;       // ordering key: lyapunov.py:512
+            if (dbg) {
+                double* o = dbg + (idx - lo) * (2 + 2 * d);
+                o[0] = c.decrease; o[1] = c.threshold;
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k) if (k < d) { o[2 + k] = mean[k]; o[2 + d + k] = err[k]; }
+            }
+        }
+        const uint64_t word = __ballot(negative);
+        if (wbase < hi) {
+            if (lane == 0) neg_bits[(wbase - lo) >> 6] = word;
+            const bool ok = negative || ((init >> lane) & 1ull);
+            if (valid && !ok) sl_key_min(best_v, best_i, sl_vbits(v_x), idx);
+        }
+    }
+    sl_block_reduce_key<true>(best_v, best_i, sv, si);
+    if (threadIdx.x == 0) { partials[blockIdx.x].vbits = best_v; partials[blockIdx.x].index = best_i; }
+}
+
+// =============================================================================================
 // deterministic-dynamics decrease check                    (lyapunov.py:436-441, 524-535)
 // =============================================================================================
 // The model constants of the closed-form path outnumber the scalar registers (the compiler spills
@@ -591,6 +673,29 @@ __global__ __launch_bounds__(SL_BLOCK) void k_reduce_fail(const sl_key* __restri
 
 
 // shared by sl_lyap_sweep (grid cells) and sl_eval_points (explicit points)
+// the model the posterior pass of a split sweep sees: same grid, policy and GP; a zero quadratic V
+// and a scalar L_v (the fast path of the GP kernels) - its records carry mean and error only
+static SlDevModel sl_posterior_only(const SlDevModel& full) {
+    SlDevModel m = full;
+    memset(&m.m.value, 0, sizeof(m.m.value));
+    m.m.value.kind = SL_V_QUADRATIC;
+    m.m.lipschitz.lv_kind = SL_LIP_CONST;
+    m.m.lipschitz.lv_cols = 1;
+    return m;
+}
+
+// table flavours (V, L_v = |grad V|, interpolated policy) of a GP model whose heads are served by
+// k_gp_sweep4: action table + posterior records + check instead of k_gp_sweep's 16x16x4 structure
+static bool sl_gp_three_pass(sl_ctx* ctx) {
+    const SlDevModel& M = ctx->h_model;
+    if (M.m.value.kind == SL_V_NETWORK || !sl_model_is_general(M) || ctx->gp_cfg != 2) return false;
+    for (int h = 0; h < ctx->h_gp.nheads; ++h)
+        if (ctx->gp_heads[h].d_kernel) return false;
+    SlDevModel po = sl_posterior_only(M);
+    if (po.m.policy.kind == SL_POLICY_TRI) po.m.policy.kind = SL_POLICY_TABLE;
+    return sl_gp4_supports(po);
+}
+
 int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
                  const double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
                  double* d_dbg, const double* d_points) {
@@ -622,11 +727,7 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
             }
             double* rec = reinterpret_cast<double*>(ctx->d_records);
             uint64_t* tmp_bits = reinterpret_cast<uint64_t*>(rec + (size_t)(hi - lo) * (2 + 2 * d));
-            SlDevModel posterior_only = ctx->h_model;      // quadratic zero V, scalar L_v: fast path
-            memset(&posterior_only.m.value, 0, sizeof(posterior_only.m.value));
-            posterior_only.m.value.kind = SL_V_QUADRATIC;
-            posterior_only.m.lipschitz.lv_kind = SL_LIP_CONST;
-            posterior_only.m.lipschitz.lv_cols = 1;
+            SlDevModel posterior_only = sl_posterior_only(ctx->h_model);
             int gp_blocks = 0;
             rc = sl_gp_sweep_launch(ctx, posterior_only, lo, hi, nullptr, nullptr, tmp_bits,
                                     &gp_blocks, rec, d_points);
@@ -636,6 +737,51 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
         rc = sl_nn_check_launch(ctx, lo, hi, d_init_bits, d_values, records, d_neg_bits, &blocks,
                                 d_dbg, d_points);
         if (rc) return rc;
+    } else if (ctx->h_model.m.dynamics.kind == SL_DYN_GP && sl_gp_three_pass(ctx)) {
+        // table V / L_v = |grad V| / interpolated policy on a large training set (see k_policy_table)
+        const SlDevModel& full = ctx->h_model;
+        const int d = full.m.grid.d, m = full.in_dim - d;
+        const size_t rec_doubles = (size_t)(hi - lo) * (2 + 2 * d), act_doubles = (size_t)(hi - lo) * m;
+        const size_t need = sizeof(double) * (rec_doubles + act_doubles) +
+                            sizeof(uint64_t) * (size_t)((hi - lo + 63) / 64 + 1);
+        if (need > ctx->records_bytes) {
+            if (ctx->d_records) (void)hipFree(ctx->d_records);
+            ctx->d_records = nullptr;
+            ctx->records_bytes = 0;
+            SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_records, need));
+            ctx->records_bytes = need;
+        }
+        double* rec = reinterpret_cast<double*>(ctx->d_records);
+        double* act = rec + rec_doubles;
+        uint64_t* tmp_bits = reinterpret_cast<uint64_t*>(act + act_doubles);
+        SlAux aux{ctx->d_tri, ctx->d_net};
+        SlDevModel posterior_only = sl_posterior_only(full);
+        const int variant = sl_dim_variant(full);
+        const bool tri_policy = full.m.policy.kind == SL_POLICY_TRI;
+        blocks = sl_grid_blocks(hi - lo);
+        if (tri_policy) {
+#define SL_CALL(G, D_, M_)                                                                     \
+    hipLaunchKernelGGL((k_policy_table<true, D_, M_>), dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream, \
+                       full, aux, lo, hi, d_points, act)
+            SL_DISPATCH_DIMS(variant, true, SL_CALL);
+#undef SL_CALL
+            SL_HIP_CHECK(ctx, hipGetLastError());
+            // the per-cell table is indexed by the cell (or point) number
+            posterior_only.m.policy.kind = SL_POLICY_TABLE;
+            posterior_only.m.policy.d_table = act - lo * m;
+        }
+        int gp_blocks = 0;
+        rc = sl_gp_sweep_launch(ctx, posterior_only, lo, hi, nullptr, nullptr, tmp_bits, &gp_blocks,
+                                rec, d_points);
+        if (rc) return rc;
+#define SL_CALL(G, D_, M_)                                                                     \
+    hipLaunchKernelGGL((k_check_records<true, D_, M_>), dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream, \
+                       full, aux, lo, hi, d_init_bits, d_values, rec, d_neg_bits, ctx->d_partials, \
+                       d_dbg, d_points)
+        SL_DISPATCH_DIMS(variant, true, SL_CALL);
+#undef SL_CALL
+        SL_HIP_CHECK(ctx, hipGetLastError());
+        sl_note_kernel(ctx, true, tri_policy ? "k_policy_table + k_check_records" : "k_check_records");
     } else if (ctx->h_model.m.dynamics.kind == SL_DYN_GP) {
         rc = sl_gp_sweep_launch(ctx, ctx->h_model, lo, hi, d_init_bits, d_values, d_neg_bits,
                                 &blocks, d_dbg, d_points);

@@ -437,6 +437,50 @@ def test_table_value_and_table_policy_with_gp(sl):
     _check_masks(neg[both], ref_neg[both], rec[both], ref_rec[both])
 
 
+@pytest.mark.parametrize("closed_form_policy", [False, True], ids=["table_policy", "closed_form_policy"])
+def test_table_flavours_on_a_large_training_set(sl, closed_form_policy):
+    """The same sweep with more than 256 training points: the interpolated policy becomes a
+    per-cell action table (``k_policy_table``), ``k_gp_sweep4`` writes the posterior records of
+    that closed loop and ``k_check_records`` runs the check with the real V and L_v - instead of
+    ``k_gp_sweep``'s 16x16x4 structure.  Same comparisons as above, and whole level sets."""
+    from safe_learning_amd.benchmarks import build_lyapunov, table_case
+    case = table_case(num_points=(45, 40), table_points=(11, 9), n_gp=300, tau_scale=0.01)
+    if closed_form_policy:
+        del case["policy_table"]
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    values, neg, rec = _engine_records(lyap)
+    kernel = lyap._ctx.last_kernel()
+    assert "k_gp_sweep4" in kernel and "k_check_records" in kernel, kernel
+    assert ("k_policy_table" in kernel) == (not closed_form_policy), kernel
+    ref_rec, ref_neg = _oracle_all(olyap)
+    otri = olyap.lyapunov_function
+    states = olyap.discretization.all_points
+    opol = olyap.policy.fun if hasattr(olyap.policy, "fun") else olyap.policy
+    ok_x = ~_on_table_face(otri, states)
+    if not closed_form_policy:
+        ok_x &= ~_on_table_face(opol, states)
+    ok_n = ~_on_table_face(otri, ref_rec[:, 2:4])
+    assert ok_x.sum() > 800 and (ok_x & ok_n).sum() > 800
+    assert_allclose(values[ok_x], olyap.values[ok_x], rtol=1e-12, atol=1e-14)
+    assert_allclose(rec[ok_x][:, 2:], ref_rec[ok_x][:, 2:], rtol=RTOL_GP, atol=1e-12)  # mean, error
+    assert_allclose(rec[ok_x][:, 1], ref_rec[ok_x][:, 1], rtol=1e-9, atol=1e-14)
+    both = ok_x & ok_n
+    assert_allclose(rec[both][:, 0], ref_rec[both][:, 0], rtol=1e-7, atol=1e-12)
+    assert 10 < ref_neg.sum() < len(ref_neg) - 10
+    _check_masks(neg[both], ref_neg[both], rec[both], ref_rec[both])
+    # the 16x16x4 kernel computes the same records (SL_GP_CFG=3 at upload time)
+    import os
+    os.environ["SL_GP_CFG"] = "3"
+    try:
+        other = build_lyapunov(case)
+        _, neg3, rec3 = _engine_records(other)
+        assert other._ctx.last_kernel().startswith("k_gp_sweep<")
+    finally:
+        del os.environ["SL_GP_CFG"]
+    assert_allclose(rec[ok_x][:, 2:], rec3[ok_x][:, 2:], rtol=1e-9, atol=1e-13)
+    assert (neg[both] != neg3[both]).sum() == 0
+
+
 def test_gp_known_answer_through_engine(sl, golden):
     """tests/test_functions.py:237-261 evaluated by the MFMA kernel (explicit points)."""
     import torch
