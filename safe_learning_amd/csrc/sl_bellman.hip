@@ -28,9 +28,15 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
     sl_stage_tri(&vt_lds, &aux.tri[0]);
     const SlTri& vt = vt_lds;
 
+    // heads with a sum-of-products kernel (sl_gp_set_head_kernel) do not factorise over state and
+    // action: every (x, u) is evaluated on its own (the generic path below)
+    bool other_kernels = false;
+    for (int h = 0; h < gp.nheads; ++h) other_kernels = other_kernels || gp.head[h].kernel != nullptr;
+    other_kernels = other_kernels && is_gp;
+
     // ---- per-workgroup table of action factors E_j(u_a) -------------------------------------
     int e_off[SL_MAX_GP_HEADS];
-    if (ACTIONS && is_gp) {
+    if (ACTIONS && is_gp && !other_kernels) {
         int off = 0;
         for (int h = 0; h < gp.nheads; ++h) {
             const SlGpHeadDev& hd = gp.head[h];
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
 
         double best_q = 0.0;
         int best_a = 0;
-        if (!ACTIONS || !is_gp) {
+        if (!ACTIONS || !is_gp || other_kernels) {
             // ---- generic path: one (x, u) at a time --------------------------------------------
             for (int a = 0; a < A; ++a) {
                 double u[SL_M], nxt[SL_D];
@@ -87,14 +93,18 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
 #pragma unroll 4
                         for (int j = 0; j < hd.n; ++j) {
                             double z = 0.0;
+                            double xa[SL_P];
 #pragma unroll
                             for (int qd = 0; qd < SL_P; ++qd) {
+                                xa[qd] = 0.0;
                                 if (qd < p) {
-                                    const double dlt = hd.xs[qd * hd.n_pad + j] - xg[qd];
+                                    xa[qd] = hd.xs[qd * hd.n_pad + j];
+                                    const double dlt = xa[qd] - xg[qd];
                                     z = fma(dlt, dlt, z);
                                 }
                             }
-                            const double kx = hd.variance * sl_exp_nonpos(-0.5 * z);
+                            const double kx = hd.kernel ? sl_kernel_eval(*hd.kernel, p, xa, xg)
+                                                        : hd.variance * sl_exp_nonpos(-0.5 * z);
 #pragma unroll
                             for (int k = 0; k < SL_D; ++k) {
                                 const int dd = k - hd.col0;
@@ -883,11 +893,11 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
     const bool is_gp = M.m.dynamics.kind == SL_DYN_GP;
     if (is_gp && ctx->h_gp.nheads < 1)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: GP dynamics without heads");
+    // heads with a sum-of-products kernel: the matrix-core sweeps generate RBF values (state and
+    // action factors); such models take k_bellman's one-(x, u)-at-a-time path
+    bool other_kernels = false;
     if (is_gp)
-        for (int h = 0; h < ctx->h_gp.nheads; ++h)
-            if (ctx->gp_heads[h].d_kernel)
-                return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_bellman_sweep: GP head %d has a kernel other "
-                               "than sl_gp_set_head's RBF (the Bellman kernels generate RBF values)", h);
+        for (int h = 0; h < ctx->h_gp.nheads; ++h) other_kernels = other_kernels || ctx->gp_heads[h].d_kernel;
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SL_HIP_CHECK(ctx, hipMemsetAsync(d_stats, 0, 2 * sizeof(double), ctx->stream));
     ctx->last_kernel[0] = 0;
@@ -900,11 +910,11 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
                                          hipMemcpyHostToDevice, ctx->stream));
         SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         amax = n_actions <= 3 ? 3 : (n_actions <= 9 ? 9 : SL_MAX_ACTIONS);
-        if (is_gp)
+        if (is_gp && !other_kernels)
             for (int h = 0; h < ctx->h_gp.nheads; ++h)
                 lds += sizeof(double) * (size_t)ctx->gp_heads[h].n_pad * amax;
     }
-    if (is_gp) {                                  // dense K_nm @ alpha contraction on the matrix cores
+    if (is_gp && !other_kernels) {                // dense K_nm @ alpha contraction on the matrix cores
         int done = 0;
         int rc = bellman_mfma(ctx, lo, hi, n_actions, d_v_new, d_argmax, d_q, d_stats, &done);
         if (rc) return rc;

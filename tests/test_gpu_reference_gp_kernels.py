@@ -145,21 +145,45 @@ def test_large_sets_run_on_the_16x16x4_kernel(n, cfg, monkeypatch):
     assert neg.any() and (~neg).any()
 
 
-def test_policy_iteration_refuses_other_kernels():
-    """The Bellman kernels generate RBF values: a model with another kernel must be refused, not
-    evaluated with the wrong formula."""
+@pytest.mark.parametrize("nv,na", [(15, 9), ([9, 65], 5)], ids=["15x15", "9x65"])
+def test_policy_iteration_with_notebook_kernels(nv, na):
+    """``inverted_pendulum.ipynb`` hands its GP ``FunctionStack`` to ``PolicyIteration``: value
+    iteration and the discrete policy optimisation on a model with the notebook's kernels equal
+    the oracle's (the matrix-core sweeps generate RBF values; such models take ``k_bellman``)."""
     import scipy.linalg
     import safe_learning_amd as sl
-    from safe_learning_amd.benchmarks import build_specs
-    case = cases.make_case("pendulum", num_points=17, n_gp=60, stack=True)
-    dynamics = _matern_stack(sl, sl, case, 60)
-    policy, _, _, _ = build_specs(case)
-    vgrid = sl.GridWorld(case["limits"], 17)
-    vf = sl.Triangulation(vgrid, np.zeros((vgrid.nindex, 1)), project=True)
+    from safe_learning_amd.benchmarks import build_specs, notebook_kernels
+    from test_gpu_rl import ambiguous_points
+    case = cases.make_case("pendulum", num_points=nv, n_gp=70, stack=True)
+    case["dynamics"]["kernels"] = notebook_kernels(case)
+    policy, dynamics, _, _ = build_specs(case)
+    opolicy, odynamics, _, _ = cases.oracle_specs(case)
     qmat = -scipy.linalg.block_diag(np.eye(2), 0.1 * np.eye(1))
+    vgrid, ovgrid = sl.GridWorld(case["limits"], nv), oracle.GridWorld(case["limits"], nv)
+    v0 = -np.random.default_rng(4).random((vgrid.nindex, 1))
+    vf, ovf = sl.Triangulation(vgrid, v0, project=True), oracle.Triangulation(ovgrid, v0, project=True)
     rl = sl.PolicyIteration(policy, dynamics, sl.QuadraticFunction(qmat), vf, gamma=0.95)
-    with pytest.raises(sl.HipEngineError, match="RBF"):
+    orl = oracle.PolicyIteration(opolicy, odynamics, oracle.QuadraticFunction(qmat), ovf, gamma=0.95)
+    x = orl.state_space
+    ok = ~ambiguous_points(ovf, orl.dynamics(x, orl.policy(x))[0])
+    assert ok.mean() > 0.9
+    for _ in range(2):
+        vf.parameters = ovf.parameters.copy()
         rl.value_iteration()
+        orl.value_iteration()
+        assert rl._ctx.last_kernel().startswith("k_bellman<"), rl._ctx.last_kernel()
+        np.testing.assert_allclose(vf._host_parameters()[ok], ovf.parameters[ok], rtol=1e-9, atol=1e-12)
+    actions = np.linspace(-1, 1, na)[:, None]
+    rl.policy = sl.Triangulation(vgrid, np.zeros((vgrid.nindex, 1)))
+    orl.policy = oracle.Triangulation(ovgrid, np.zeros((ovgrid.nindex, 1)))
+    vf.parameters = ovf.parameters.copy()
+    q = rl.discrete_policy_optimization(actions, return_values=True).cpu().numpy()
+    oq, _ = orl.discrete_policy_optimization(actions)
+    ok_q = np.ones_like(oq, dtype=bool)
+    for a, action in enumerate(actions):
+        ok_q[:, a] = ~ambiguous_points(ovf, orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))[0])
+    assert ok_q.mean() > 0.9
+    np.testing.assert_allclose(q[ok_q], oq[ok_q], rtol=1e-9, atol=1e-12)
 
 
 def test_notebook_flow_from_a_model_without_observations(fixture):
