@@ -74,6 +74,9 @@ constexpr int RB = R * W;                  // row blocks per panel
 // cell for the rotated fragment reads to be conflict free; the shift between the row pairs and
 // the slab-pair skew leave the generation writes (lane = training point, 8 B, one cell per
 // instruction) with 2-way conflicts only.
+#ifndef SL_GP4_GRAM
+#define SL_GP4_GRAM 1
+#endif
 #ifndef SL_GP4_WRITE_SKEW
 #define SL_GP4_WRITE_SKEW 1
 #endif
@@ -134,6 +137,26 @@ __device__ __forceinline__ void acc_squares(double (&ssr)[CB][4]) {
     const double v = acc_read<2 * I>();
     ssr[(I / 4) % CB][I % 4] = fma(v, v, ssr[(I / 4) % CB][I % 4]);
     if constexpr (I + 1 < NACC) acc_squares<I + 1>(ssr);
+}
+
+// The same sums on the matrix pipe: with an accumulator register as BOTH operands of a 4x4x4 MFMA
+// (lane (k, blk, low) holds a[row k of the register's four][cell low of its group]: the layout of
+// the B operand and, transposed, of the A operand) the product is the 4 x 4 Gram matrix of the
+// four rows, whose diagonal - lanes with k == low - is sum_k a[k][cell]^2.  Chained over the row
+// blocks: gram[cb][rot] = sum_r acc(r, cb, rot)^T acc(r, cb, rot), sixteen independent chains
+// (a dependent FP64 MFMA must not follow its producer directly), no accumulator reads, no folds
+// across the lane groups.
+template <int RI = 0, int J = 0>
+__device__ __forceinline__ void acc_gram(double (&gram)[CB][4]) {
+    constexpr int N = 2 * ((RI * CB + J / 4) * 4 + J % 4);
+    if constexpr (RI == 0)
+        asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, a[%c1:%c2], a[%c1:%c2], 0"
+                     : "=v"(gram[J / 4][J % 4]) : "i"(N), "i"(N + 1));
+    else
+        asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, a[%c1:%c2], a[%c1:%c2], %0"
+                     : "+v"(gram[J / 4][J % 4]) : "i"(N), "i"(N + 1));
+    if constexpr (J + 1 < 4 * CB) acc_gram<RI, J + 1>(gram);
+    else if constexpr (RI + 1 < R) acc_gram<RI + 1, 0>(gram);
 }
 
 // eight MFMAs of one (row block, rotation): both slabs of the pair for the four cell blocks.  The
@@ -746,6 +769,16 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                 // one partial sum per cell, owned by one lane (no other wave touches the plane).
                 asm volatile("s_nop 15\n\ts_nop 15" ::: SL_ALL_AGPRS);   // MFMA results -> reads
                 double ssr[CB][4];
+#if SL_GP4_GRAM
+                acc_gram(ssr);
+                // retired before the stores read them
+                asm volatile("s_nop 15\n\ts_nop 7"
+                             : "+v"(ssr[0][0]), "+v"(ssr[0][1]), "+v"(ssr[0][2]), "+v"(ssr[0][3]),
+                               "+v"(ssr[1][0]), "+v"(ssr[1][1]), "+v"(ssr[1][2]), "+v"(ssr[1][3]),
+                               "+v"(ssr[2][0]), "+v"(ssr[2][1]), "+v"(ssr[2][2]), "+v"(ssr[2][3]),
+                               "+v"(ssr[3][0]), "+v"(ssr[3][1]), "+v"(ssr[3][2]), "+v"(ssr[3][3]));
+                const bool owner = lk == low;          // the diagonal of the Gram matrices
+#else
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -758,6 +791,8 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                         ssr[cb][rot] += __shfl_xor(ssr[cb][rot], 16, 64);
                         ssr[cb][rot] += __shfl_xor(ssr[cb][rot], 32, 64);
                     }
+                const bool owner = lane < 16;
+#endif
                 {
                     // one plane per wavefront (LDS is short): the four rotations of a lane belong
                     // to four different cells, and within a rotation the lanes hit distinct cells,
@@ -771,7 +806,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                     }
 #pragma unroll
                     for (int rot = 0; rot < 4; ++rot) {
-                        if (lane < 16) {
+                        if (owner) {
 #pragma unroll
                             for (int cb = 0; cb < CB; ++cb) {
                                 double* slot = part_ss + wave * C + 16 * cb + 4 * ((blk + rot) & 3) + low;
