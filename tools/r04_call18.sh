@@ -22,7 +22,7 @@ grep -h '^{' $OUT/trace.log | cut -c1-600 > $OUT/r04_bench_lines.txt
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_a
 cat $OUT/r04_kernel_stats.md $OUT/r04_pmc_128.txt $OUT/r04_pmc_48.txt; cut -c1-300 $OUT/pmc_traffic.log
 rm -f gpurun_out/r04_lines_18.jsonl
-for cfg in C2 C3 C2-table-stack; do
+for cfg in C2 C3 C2-table-stack C2-notebook; do
   timeout 300 python bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '^{' >> gpurun_out/r04_lines_18.jsonl
 done
 python - <<'PY'
