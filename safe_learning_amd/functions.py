@@ -381,7 +381,7 @@ class RBF(_Stationary):
 
     _kind = _hip.KERNEL_RBF
 
-    def __init__(self, input_dim, variance=1.0, lengthscales=None, ARD=False, active_dims=None):
+    def __init__(self, input_dim, variance=1.0, lengthscales=None, active_dims=None, ARD=False):
         _Stationary.__init__(self, input_dim, variance, lengthscales, active_dims, ARD)
 
     def K(self, X, X2=None):
