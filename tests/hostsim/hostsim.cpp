@@ -184,4 +184,21 @@ int hs_row_values(const sl_model_desc* desc, int64_t n, double* rows, double* po
 }
 double hs_vbits_to_double(uint64_t b) { return sl_vbits_to_double(b); }
 
+
+// sum-of-products kernels (sl_gp_set_head_kernel): K[i][j] = k(a_i, b_j) and the diagonal k(a_i, a_i)
+// exactly as the sweep kernels evaluate them (sl_kernel_eval / sl_kernel_diag of sl_model.h)
+int hs_kernel_matrix(const sl_gp_kernel* ks, int p, const double* a, int na, const double* b, int nb,
+                     double* out, double* diag) {
+    for (int i = 0; i < na; ++i) {
+        double xa[SL_P] = {};
+        for (int q = 0; q < p; ++q) xa[q] = a[i * p + q];
+        for (int j = 0; j < nb; ++j) {
+            double xb[SL_P] = {};
+            for (int q = 0; q < p; ++q) xb[q] = b[j * p + q];
+            out[i * nb + j] = sl_kernel_eval(*ks, p, xa, xb);
+        }
+        diag[i] = sl_kernel_diag(*ks, p, xa);
+    }
+    return 0;
+}
 }  // extern "C"

@@ -401,3 +401,34 @@ def test_fast_key_map_equals_the_reference_map(hostsim):
                                np.finfo(float).max, np.finfo(float).min]])
     for v in samples:
         assert hostsim.hs_vbits_fast(float(v)) == hostsim.hs_vbits(float(v)), v
+
+
+def test_kernel_family_device_functions(hostsim):
+    """``sl_kernel_eval`` / ``sl_kernel_diag`` (what ``k_gp_small``, ``k_gp_sweep`` and ``k_bellman``
+    evaluate for a head uploaded with ``sl_gp_set_head_kernel``), compiled for the host, against the
+    oracle's statement of gpflow 0.4.0's kernels for the cases of the reference-run fixture."""
+    import oracle
+    from gp_cases import kernel_case_list, kernel_from_spec
+    import safe_learning_amd as sl
+    from safe_learning_amd import _hip
+    rng = np.random.default_rng(11)
+    A, B = rng.uniform(-1.5, 1.5, (29, 3)), rng.uniform(-1.5, 1.5, (17, 3))
+    A[3] = B[5]                                        # a coinciding pair: euclid_dist's 1e-12
+    hostsim.hs_kernel_matrix.restype = C.c_int
+    for spec in kernel_case_list():
+        for products in spec["kernels"]:
+            factors = kernel_from_spec(products, sl)._factors(3)
+            ks = _hip.GpKernel()
+            ks.nfactors = len(factors)
+            for f, (kind, product, variance, inv_ls) in enumerate(factors):
+                ks.factor[f].kind, ks.factor[f].product = int(kind), int(product)
+                for q in range(3):
+                    ks.factor[f].variance[q], ks.factor[f].inv_lengthscales[q] = variance[q], inv_ls[q]
+            out, diag = np.zeros((len(A), len(B))), np.zeros(len(A))
+            rc = hostsim.hs_kernel_matrix(C.byref(ks), 3, A.ctypes.data_as(C.c_void_p), len(A),
+                                          B.ctypes.data_as(C.c_void_p), len(B),
+                                          out.ctypes.data_as(C.c_void_p), diag.ctypes.data_as(C.c_void_p))
+            assert rc == 0
+            okern = kernel_from_spec(products, oracle)
+            assert_allclose(out, okern.K(A, B), rtol=1e-12, atol=1e-16)
+            assert_allclose(diag, okern.Kdiag(A), rtol=1e-14)
