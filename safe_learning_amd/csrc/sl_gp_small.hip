@@ -44,7 +44,9 @@ __host__ __device__ constexpr int tri_offset(int I) { return I * (I + 1); }
 }  // namespace gps
 
 // ALDS: the A fragments are read from the workgroup's LDS copy (else from L2).
-template <bool GENERAL, int DT, int MT, bool ALDS, int WAVES>
+// KERN: some head carries a sum-of-products kernel (sl_gp_set_head_kernel); the plain-RBF
+// instantiation has no trace of that path in its generation loop.
+template <bool GENERAL, int DT, int MT, bool ALDS, int WAVES, bool KERN>
 __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
     const SlDevModel M, const SlGpDev gp, SlAux aux_arg, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
         const int n_pad = hd.n_pad, dout = hd.dout, nslab2 = hd.nslab2, col0 = hd.col0;
         const int nrb = n_pad / 16, npass = (nrb + PRB - 1) / PRB;
         const double variance = hd.variance;
-        const sl_gp_kernel* __restrict__ kern = hd.kernel;           // null: the RBF of sl_gp_set_head
+        const sl_gp_kernel* __restrict__ kern = KERN ? hd.kernel : nullptr;   // null: the RBF of sl_gp_set_head
         const double* xs_l = head_base;                              // [p][n_pad]
         const double* alpha_l = xs_l + ((p * n_pad + 1) & ~1);       // [n_pad][dout]
         const double* a_l = alpha_l + ((n_pad * dout + 1) & ~1);     // lower-triangle fragments (ALDS)
@@ -345,9 +347,12 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
     if (blocks < 1) blocks = 1;
     *nblocks = (int)blocks;
     SlAux aux{ctx->d_tri, ctx->d_net};
+    bool other_kernels = false;
+    for (int k = 0; k < ctx->h_gp.nheads; ++k) other_kernels = other_kernels || ctx->gp_heads[k].d_kernel;
 #define SL_GPS_GO(ALDS_, W_)                                                                       \
     do {                                                                                           \
-        auto kern = k_gp_small<GENERAL, DT, MT, ALDS_, W_>;                                        \
+        auto kern = other_kernels ? k_gp_small<GENERAL, DT, MT, ALDS_, W_, true>                   \
+                                  : k_gp_small<GENERAL, DT, MT, ALDS_, W_, false>;                 \
         SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                 \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * W_), lds, ctx->stream, model,   \
