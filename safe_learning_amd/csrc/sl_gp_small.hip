@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
     const SlDevModel M, const SlGpDev gp, SlAux aux_arg, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
-    int head_doubles, const double* __restrict__ points) {
+    int head_doubles, const double* __restrict__ points, unsigned long long* __restrict__ ticket) {
     using namespace gps;
     __shared__ SlTriLds<GENERAL> tri_lds;
     __shared__ uint64_t sv[WAVES];
@@ -98,8 +98,18 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
     uint64_t best_v = ~0ull;
     int64_t best_i = INT64_MAX;
 
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles;
-         tile += (int64_t)gridDim.x * WAVES) {
+    // Tiles are drawn from a counter, one per wavefront: table look-ups and saturation kinks make
+    // tiles differ in cost (3 - 7 % on the 3e6-cell configurations, profiles/r04_gp_small_tickets_ab.txt).
+    // Small sweeps (ticket == nullptr: a handful of tiles per wavefront) keep the fixed list - there
+    // the counter's memset and atomics cost more than they balance.
+    auto next_tile = [&](int64_t previous) -> int64_t {
+        if (!ticket) return previous < 0 ? (int64_t)blockIdx.x * WAVES + wave : previous + (int64_t)gridDim.x * WAVES;
+        int64_t t = 0;
+        if (lane == 0) t = (int64_t)atomicAdd(ticket, 1ull);
+        return ((int64_t)__builtin_amdgcn_readfirstlane((int)(t >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    for (int64_t tile = next_tile(-1); tile < ntiles; tile = next_tile(tile)) {
         const int64_t tile_base = lo + tile * 64;
         const int64_t idx = tile_base + lane;
         const bool valid = idx < hi;
@@ -347,6 +357,11 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
     if (blocks < 1) blocks = 1;
     *nblocks = (int)blocks;
     SlAux aux{ctx->d_tri, ctx->d_net};
+    unsigned long long* ticket = nullptr;
+    if (ntiles > 4 * blocks * waves) {               // enough tiles per wavefront to balance
+        ticket = ctx->d_ticket;
+        SL_HIP_CHECK(ctx, hipMemsetAsync(ticket, 0, sizeof(unsigned long long), ctx->stream));
+    }
     bool other_kernels = false;
     for (int k = 0; k < ctx->h_gp.nheads; ++k) other_kernels = other_kernels || ctx->gp_heads[k].d_kernel;
 #define SL_GPS_GO(ALDS_, W_)                                                                       \
@@ -357,7 +372,7 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * W_), lds, ctx->stream, model,   \
                            ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,      \
-                           ctx->d_partials, d_dbg, head_doubles, d_points);                     \
+                           ctx->d_partials, d_dbg, head_doubles, d_points, ticket);             \
     } while (0)
     if constexpr (DT > 0) {
         if (waves == WAVES_MAX) { if (alds) SL_GPS_GO(true, WAVES_MAX); else SL_GPS_GO(false, WAVES_MAX); }

@@ -77,6 +77,7 @@ extern "C" int sl_ctx_create(int device, void* hip_stream, sl_ctx** out) {
     SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_net, sizeof(SlNet)));
     SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_partials, sizeof(sl_key) * 4 * SL_MAX_GRID));
     SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_partial_counts, sizeof(int64_t) * 2 * SL_MAX_GRID));
+    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_ticket, 16));
     SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_actions, sizeof(double) * 1024));
     SL_HIP_CHECK(ctx, hipMemset(ctx->d_tri, 0, 2 * sizeof(SlTri)));
     SL_HIP_CHECK(ctx, hipMemset(ctx->d_net, 0, sizeof(SlNet)));
@@ -108,6 +109,7 @@ extern "C" int sl_ctx_destroy(sl_ctx* ctx) {
     if (ctx->d_records) (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_partials);
     (void)hipFree(ctx->d_partial_counts);
+    (void)hipFree(ctx->d_ticket);
     (void)hipFree(ctx->d_actions);
     delete ctx;
     return SL_OK;
