@@ -77,7 +77,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
         double* dst = smem;
         for (int h = 0; h < nheads; ++h) {
             const SlGpHeadDev& hd = gp.head[h];
-            const int n_pad = hd.n_pad, nrb = n_pad / 16;
+            // row blocks that hold training points: the padding of the upload (a multiple of the
+            // 16x16x4 fallback's 64-row panels) is rows and columns of zeros - neither staged
+            // nor multiplied here (a 130-point head of the notebooks works on 144 of its 192)
+            const int n_pad = hd.n_pad, nrb = (hd.n + 15) / 16;
             for (int k = tid; k < p * n_pad; k += 64 * WAVES) dst[k] = hd.xs[k];
             dst += (p * n_pad + 1) & ~1;
             for (int k = tid; k < n_pad * hd.dout; k += 64 * WAVES) dst[k] = hd.alpha[k];
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
         for (int h = 0; h < nheads; ++h) {
         const SlGpHeadDev& hd = gp.head[h];
         const int n_pad = hd.n_pad, dout = hd.dout, nslab2 = hd.nslab2, col0 = hd.col0;
-        const int nrb = n_pad / 16, npass = (nrb + PRB - 1) / PRB;
+        const int nrb = (hd.n + 15) / 16, npass = (nrb + PRB - 1) / PRB;
         const double variance = hd.variance;
         const sl_gp_kernel* __restrict__ kern = KERN ? hd.kernel : nullptr;   // null: the RBF of sl_gp_set_head
         const double* xs_l = head_base;                              // [p][n_pad]
@@ -333,7 +336,7 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
     for (int k = 0; k < ctx->h_gp.nheads; ++k) {
         const SlGpHeadHost& h = ctx->gp_heads[k];
         small += (size_t)((p * h.n_pad + 1) & ~1) + (size_t)((h.n_pad * h.dout + 1) & ~1);
-        tri += (size_t)tri_offset(h.n_pad / 16) * 128;
+        tri += (size_t)tri_offset((h.n + 15) / 16) * 128;         // row blocks with training points
     }
     const size_t cap = lds_capacity(GENERAL);
     auto scratch_of = [&](int waves) { return (size_t)waves * 64 * (p + 1 + 2 * d); };
