@@ -144,7 +144,7 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
 #pragma unroll
             for (int dd = 0; dd < DOUT_UNROLL; ++dd) gmean[dd] = 0.0;
 
-            const int npanels = n_pad / RP;
+            const int npanels = (hd.n + RP - 1) / RP;     // panels that hold training points
             for (int pan = 0; pan < npanels; ++pan) {
                 sl_d4 acc[R][CB];
 #pragma unroll

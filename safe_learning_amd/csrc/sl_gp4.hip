@@ -740,7 +740,9 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                 }
             };
 
-            const int npanels = n_pad / RP;
+            // panels that hold training points (the upload pads to the 16x16x4 fallback's 512 rows:
+            // a panel of zero rows contributes nothing - 600 points are three panels, not four)
+            const int npanels = (hd.n + RP - 1) / RP;
             for (int pan = 0; pan < npanels; ++pan) {
                 acc_zero_all();
                 int rowoff[R];                     // byte offset of each owned row block's fragments
