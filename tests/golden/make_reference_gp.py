@@ -52,8 +52,13 @@ def reference_gp_dynamics(case, ref, scale=1.0, zero_mean=False):
     F = ref.functions
     dyn, d = case["dynamics"], case["d"]
 
-    def model(Y, prior, lengthscales):
-        kern = gpflow.kernels.RBF(d + 1, variance=dyn["variance"], lengthscales=lengthscales, ARD=True)
+    def model(Y, prior, lengthscales, kernel=None):
+        if kernel is not None:                  # a sum of products of leaves (tests/gp_cases.py)
+            from safe_learning_amd.benchmarks import kernel_from_products
+            kern = kernel_from_products(kernel, {"rbf": gpflow.kernels.RBF, "matern32": gpflow.kernels.Matern32,
+                                                 "linear": gpflow.kernels.Linear})
+        else:
+            kern = gpflow.kernels.RBF(d + 1, variance=dyn["variance"], lengthscales=lengthscales, ARD=True)
         if zero_mean:
             mean = gpflow.mean_functions.Zero()
         else:
@@ -64,7 +69,8 @@ def reference_gp_dynamics(case, ref, scale=1.0, zero_mean=False):
         return F.GaussianProcess(gp, beta=dyn["beta"])
 
     if case["stack"]:
-        return F.FunctionStack([model(dyn["Y"][:, [k]], dyn["prior"][[k], :], dyn["lengthscales"][k])
+        return F.FunctionStack([model(dyn["Y"][:, [k]], dyn["prior"][[k], :], dyn["lengthscales"][k],
+                                      dyn["kernels"][k] if "kernels" in dyn else None)
                                 for k in range(d)])
     return model(dyn["Y"], dyn["prior"], dyn["lengthscales"])
 

@@ -232,6 +232,25 @@ def scenarios():
                 [[-1, 1.03], [-0.97, 1]])
     out.append(dict(name="adaptive_gp", case=case, batch=80, unique=True, adaptive=True,
                     steps=[("update", dict(max_refinement=4, safety_factor=1.2))]))
+    # the notebooks' dynamics model (inverted_pendulum.ipynb:145-181): a FunctionStack of
+    # single-output GPs with the kernels Linear + Matern32 * Linear, through the notebook's loop -
+    # level set, most uncertain safe pair, new observations, level set again
+    from safe_learning_amd.benchmarks import notebook_kernels
+    for n_gp, name in ((40, "notebook_kernels"), (135, "notebook_kernels_130")):
+        case = skew(make_case("pendulum", num_points=25, n_gp=n_gp, tau_scale=0.01, stack=True,
+                              noise_std=0.001), [[-1, 1.03], [-0.97, 1]])
+        kernels = notebook_kernels(case)
+        for spec in kernels:                     # (a prior wide enough for the bound to matter)
+            spec[0][0][1]["variance"] = [3e-3, 3e-3, 3e-3]
+            spec[1][1][1]["variance"] = 3e-3
+        case["dynamics"]["kernels"] = kernels
+        new_x = np.random.default_rng(n_gp).uniform(-0.5, 0.5, (3, 3))
+        new_y = new_x @ case["dynamics"]["prior"].T + 1e-3
+        perturb = dict(perturbations=np.linspace(-0.3, 0.3, 5)[:, None], limits=np.array([[-1.0, 1.0]]),
+                       positive=True)
+        out.append(dict(name=name, case=case, batch=100, unique=True,
+                        steps=[("update", {}), ("sample", perturb), ("add_data", (new_x, new_y)),
+                               ("update", {"can_shrink": False}), ("sample", perturb)]))
     # sixteen of the random variations of the live comparison (seed 7), so that the engine meets
     # them too (tests/test_gpu_reference_safe_sets.py)
     for scenario in random_scenarios(16, 7):
