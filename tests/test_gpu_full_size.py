@@ -195,3 +195,29 @@ def test_cartpole_gp_function_stack_full_head_count():
     from safe_learning_amd.benchmarks import headline_case
     case = headline_case(num_points=48, stack=True)
     _gp_full_size_checks(case, 1500, 3)
+
+
+def test_headline_kernel_seeds_bit_identical_at_size(monkeypatch):
+    """``k_gp_sweep4`` on the headline model (1024 training points, four panels, tiles with
+    saturation kinks) at 48^4 cells: with the sequence seeds (``SL_GP4_SEEDS`` unset) and with every
+    generation from the exponentials (``SL_GP4_SEEDS=0``) the mask, the failing key and the
+    counters are bit for bit the same; so they are with the tiles drawn in another order (a second
+    launch - the counter hands the tiles out in the order the workgroups ask)."""
+    import torch
+    from safe_learning_amd.benchmarks import build_lyapunov, headline_case
+    case = headline_case(num_points=48)
+    out = []
+    for seeds in ("1", "0", "1"):
+        monkeypatch.setenv("SL_GP4_SEEDS", seeds)
+        lyap = build_lyapunov(case)
+        lyap.update_safe_set()
+        assert lyap._ctx.last_kernel().startswith("k_gp_sweep4")
+        out.append((lyap._d_neg.cpu().numpy().copy(), lyap.safe_set.copy(), lyap.c_max,
+                    lyap._d_result.cpu().numpy().copy()))
+    for other in out[1:]:
+        assert_array_equal(out[0][0], other[0])
+        assert_array_equal(out[0][1], other[1])
+        assert out[0][2] == other[2]
+        assert_array_equal(out[0][3], other[3])
+    neg = np.unpackbits(out[0][0].view(np.uint8), bitorder="little")[:48 ** 4]
+    assert 0.05 < neg.mean() < 0.95 and out[0][1].sum() > 100
