@@ -468,6 +468,12 @@ def test_table_flavours_on_a_large_training_set(sl, closed_form_policy):
     assert_allclose(rec[both][:, 0], ref_rec[both][:, 0], rtol=1e-7, atol=1e-12)
     assert 10 < ref_neg.sum() < len(ref_neg) - 10
     _check_masks(neg[both], ref_neg[both], rec[both], ref_rec[both])
+    # a shard that does not start at cell 0 (the action table and the records are shard-relative)
+    from test_gpu_reference_gp import sweep_records
+    idx = np.arange(1088, 1800)
+    part, kernels = sweep_records(lyap, idx)
+    assert all("k_check_records" in k for k in kernels)
+    assert_array_equal(part, rec[idx])
     # the 16x16x4 kernel computes the same records (SL_GP_CFG=3 at upload time)
     import os
     os.environ["SL_GP_CFG"] = "3"
