@@ -208,6 +208,10 @@ SL_API int  sl_gp_configure(sl_ctx* ctx, int nheads, double beta);
 SL_API int  sl_tri_set(sl_ctx* ctx, int slot, const sl_grid_desc* h_grid, int nsimplex,
                 const int32_t* h_simplices, const double* h_hyperplanes,
                 const double* h_discrete_points, int project, int ncols, const double* d_table);
+/* New vertex values for a slot whose grid stays.  Call it again whenever the values of the POLICY
+ * table (slot 1) change, also when they were overwritten in place: what the policy-evaluation
+ * sweep derives from the policy alone is kept between sweeps until this, sl_tri_set(slot 1) or an
+ * sl_model_set with another policy description says that the policy is a new one. */
 SL_API int  sl_tri_set_table(sl_ctx* ctx, int slot, const double* d_table);
 
 /* LyapunovNetwork (examples/utilities.py:85-104): h_kernels = per-layer kernel matrices

@@ -65,10 +65,12 @@ struct sl_ctx {
     // distinct values, the tile order) is kept between sweeps as long as the policy is the same
     void* d_policy_cache = nullptr;
     size_t policy_cache_bytes = 0;
+    unsigned long long policy_token = 0;   // bumped by sl_model_set (policy / grid changed), sl_tri_set
+                                           // and sl_tri_set_table of slot 1
     struct {
         bool valid = false;
         int64_t lo = 0, hi = 0;
-        unsigned long long table_sum = 0, desc_hash = 0;
+        unsigned long long token = 0;
         int n_glob = 0;
         unsigned long long bits[64];
     } policy_cache;

@@ -184,6 +184,12 @@ extern "C" int sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model) {
     if ((lk == SL_LIP_ABS_GRAD || lk == SL_LIP_NORM_GRAD) && vk == SL_V_QUADRATIC)
         return sl_fail(ctx, SL_ERR_INVALID, "ABS_GRAD L_v needs a table or network V "
                                              "(use ABS_LINEAR with P + P^T)");
+    // what k_bellman4_policy derives from the policy alone is kept between sweeps under this
+    // token: a new policy description or another grid is a new policy (a model uploaded again
+    // unchanged - every value-iteration sweep does that - is not)
+    if (!ctx->model_set || memcmp(&ctx->h_model.m.policy, &M.m.policy, sizeof(M.m.policy)) != 0 ||
+        memcmp(&ctx->h_model.m.grid, &M.m.grid, sizeof(M.m.grid)) != 0)
+        ++ctx->policy_token;
     ctx->h_model = M;
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_model, &ctx->h_model, sizeof(SlDevModel),
@@ -233,6 +239,7 @@ extern "C" int sl_tri_set(sl_ctx* ctx, int slot, const sl_grid_desc* h_grid, int
                                 hipMemcpyHostToDevice));
     t.points = ctx->d_tri_points[slot];
     t.table = d_table;
+    if (slot == 1) ++ctx->policy_token;
     sl_tri_finish(t, h_discrete_points);
     SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_tri + slot, &t, sizeof(SlTri), hipMemcpyHostToDevice));
     return SL_OK;
@@ -242,6 +249,7 @@ extern "C" int sl_tri_set_table(sl_ctx* ctx, int slot, const double* d_table) {
     if (!ctx || slot < 0 || slot > 1 || !ctx->h_tri[slot].set)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_tri_set_table: slot not set");
     ctx->h_tri[slot].table = d_table;
+    if (slot == 1) ++ctx->policy_token;            // new vertex values of the policy
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_tri + slot, &ctx->h_tri[slot], sizeof(SlTri),

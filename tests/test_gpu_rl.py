@@ -534,8 +534,9 @@ def test_4x4x4_kernels_on_sub_ranges(sl):
 
 def test_policy_data_are_reused_until_the_policy_changes(sl):
     """k_bellman4_policy keeps what depends on the policy alone (actions, distinct values, tile
-    order) between sweeps, keyed by a checksum of the policy table: a second sweep reuses them, an
-    in-place edit of one table entry is noticed, results equal the uncached ones bit for bit."""
+    order) between sweeps, keyed by the context's policy token (bumped whenever a policy table or
+    description is handed in): a second sweep reuses them, another table is noticed, results equal
+    the uncached ones bit for bit."""
     case = cases.make_case("pendulum", num_points=[12, 64], n_gp=70)
     rl, orl, vf, ovf = _rl_pair(sl, case, [12, 64])
     grid = vf.discretization
