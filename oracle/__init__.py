@@ -25,7 +25,14 @@ Third-party arithmetic that is not in the upstream checkout: the RBF kernel and
 ``GPR.build_predict`` of gpflow==0.4.0 (pinned in the reference's
 ``requirements.txt:3``).  The published algorithm is restated in
 ``oracle.np_functions.RBF`` and pinned by the reference's own known-answer test
-``safe_learning/tests/test_functions.py:237-261``.
+``safe_learning/tests/test_functions.py:237-261``.  The kernels the reference's notebooks use
+instead (``Matern32``, ``Linear``, ``Add``, ``Prod`` with ``active_dims``;
+``examples/inverted_pendulum.ipynb:152-158``) are restated from the same published sources in
+``oracle.np_functions`` as well; no test of the reference holds a number for them: their FORMULAS
+are **parity unpinned** (three independent restatements - this one, the gpflow stand-in of the
+fixtures, the engine - are compared with each other), the reference's arithmetic around them is
+pinned by running its ``GPRCached`` / ``FunctionStack`` / ``Lyapunov`` / ``PolicyIteration`` on such
+models (``tests/golden/reference_gp_kernels.npz`` and the ``notebook_kernels*`` scenarios).
 
 Pinning, five layers:
 
