@@ -437,6 +437,32 @@ def test_table_value_and_table_policy_with_gp(sl):
     _check_masks(neg[both], ref_neg[both], rec[both], ref_rec[both])
 
 
+def test_table_policy_with_quadratic_value_on_a_large_training_set(sl):
+    """Only the POLICY is a table (quadratic V, linear L_v): the same three passes, and here every
+    number has a bit-exact or tight counterpart in the oracle."""
+    from safe_learning_amd.benchmarks import build_lyapunov, table_case
+    case = table_case(num_points=(45, 40), table_points=(11, 9), n_gp=300, tau_scale=0.01)
+    del case["V"]
+    case["lv"] = ("abs_linear", 2 * case["P"])
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    values, neg, rec = _engine_records(lyap)
+    kernel = lyap._ctx.last_kernel()
+    assert "k_gp_sweep4" in kernel and "k_policy_table" in kernel and "k_check_records" in kernel, kernel
+    ref_rec, ref_neg = _oracle_all(olyap)
+    opol = olyap.policy.fun if hasattr(olyap.policy, "fun") else olyap.policy
+    ok = ~_on_table_face(opol, olyap.discretization.all_points)
+    assert ok.sum() > 800
+    assert_array_equal(values, olyap.values)
+    assert_allclose(rec[ok][:, 2:], ref_rec[ok][:, 2:], rtol=RTOL_GP, atol=1e-12)
+    assert_allclose(rec[ok][:, :2], ref_rec[ok][:, :2], rtol=1e-7, atol=1e-12)
+    _check_masks(neg[ok], ref_neg[ok], rec[ok], ref_rec[ok])
+    lyap.update_safe_set()
+    olyap.update_safe_set()
+    if (neg == ref_neg).all():
+        assert_array_equal(lyap.safe_set, olyap.safe_set)
+        assert lyap.c_max == olyap.c_max
+
+
 @pytest.mark.parametrize("closed_form_policy", [False, True], ids=["table_policy", "closed_form_policy"])
 def test_table_flavours_on_a_large_training_set(sl, closed_form_policy):
     """The same sweep with more than 256 training points: the interpolated policy becomes a
