@@ -80,6 +80,9 @@ constexpr int RB = R * W;                  // row blocks per panel
 #ifndef SL_GP4_WRITE_SKEW
 #define SL_GP4_WRITE_SKEW 1
 #endif
+#ifndef SL_GP4_DIAG_SKIP
+#define SL_GP4_DIAG_SKIP 1                 // leave out the zero slab pairs of the diagonal blocks
+#endif
 constexpr int RUNS = 4;                    // affine runs per wavefront handled by the recurrence
 constexpr int RUNC = SL_P + 2;             // per (wavefront, run): step[SL_P], a^2, Q
 constexpr int KXS2 = CB * 128 + 4;
@@ -238,11 +241,11 @@ struct NoFill {
 // buffer load of A fragment r of the slab pair two ahead in the rotation (r - R0) & 3, so every
 // fragment is requested once per slab pair.  sched_barrier pins the placement (the scheduler
 // would otherwise gather the loads in front of the group).
-template <int R0, int ROT, bool LOADA, int S2, class F, int RI = R0>
+template <int R0, int ROT, bool LOADA, int S2, class F, int RI = R0, int REND = R>
 __device__ __forceinline__ void rotation(const AFrag& a, const BFrag& b, BFrag& bn, const double* kxn,
                                          AFrag& an, __amdgpu_buffer_rsrc_t rsrc,
                                          const int (&rowoff)[R], int s2n, int lane, F& f) {
-    if constexpr (RI < R) {
+    if constexpr (RI < REND) {
         constexpr bool LA = LOADA && ((RI - R0) & 3) == ROT;
         if constexpr (RI == R0) {
             constexpr int I0 = (S2 * 4 + ROT) * 4;
@@ -278,7 +281,7 @@ __device__ __forceinline__ void rotation(const AFrag& a, const BFrag& b, BFrag& 
         } else {
             group<RI, ROT>(a.v[RI], b);
         }
-        rotation<R0, ROT, LOADA, S2, F, RI + 1>(a, b, bn, kxn, an, rsrc, rowoff, s2n, lane, f);
+        rotation<R0, ROT, LOADA, S2, F, RI + 1, REND>(a, b, bn, kxn, an, rsrc, rowoff, s2n, lane, f);
     }
 }
 __device__ __forceinline__ void load_b(BFrag& b, const double* kxs, int off) {
@@ -316,31 +319,98 @@ __device__ __forceinline__ void slab_pairs(AFrag (&a)[3], BFrag& be, BFrag& bo, 
         slab_pairs<R0, S2 + 1, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f);
     }
 }
-// one chunk of 64 training points against the row blocks r >= R0
-template <int R0, class F>
+// The DIAGONAL block of a wavefront (row block R0 in chunk R0 of the panel's diagonal band): its 16
+// rows end inside the chunk, so its fragments are zero from slab pair `nz` on (2, 4, 6 or 8: the
+// wavefront that owns block s of the band's four has rows 16 s .. 16 s + 15 of the chunk's 64
+// columns), and a product with those zeros leaves the accumulators as they are.  The diagonal block
+// therefore runs on its own, in front of the blocks below it, and stops after `nz` slab pairs (a
+// wave-uniform test in front of every second one).  At n = 1024, 6 of the 136 (row block, chunk)
+// products of a tile are such zeros: 4.4 % of the MFMAs; measured 3.0 % of the sweep at 64^4
+// (profiles/r05_gp4_diag_ab.txt: the split itself, never leaving early, costs 0.5 %).
+template <int R0, int S2, class F>
+__device__ __forceinline__ void diag_pairs(AFrag (&a)[3], BFrag& be, BFrag& bo, const double* kxb,
+                                           const int (&boff)[4], __amdgpu_buffer_rsrc_t rsrc,
+                                           const int (&rowoff)[R], int ch, int lane, F& f, int nz) {
+    if constexpr (S2 < 8) {
+        if constexpr (S2 >= 2 && S2 % 2 == 0) {
+            if (S2 == nz) return;
+        }
+        constexpr bool LOADA = S2 < 6;
+        const double* kxs = kxb + S2 * KXS2;
+        const double* kxs_next = kxb + (S2 < 7 ? S2 + 1 : 7) * KXS2;
+        const AFrag& ac = a[S2 % 3];
+        AFrag& an = a[(S2 + 2) % 3];
+        const int s2n = 8 * ch + S2 + 2;
+        rotation<R0, 0, LOADA, S2, F, R0, R0 + 1>(ac, be, bo, kxs + boff[1], an, rsrc, rowoff, s2n, lane, f);
+        rotation<R0, 1, LOADA, S2, F, R0, R0 + 1>(ac, bo, be, kxs + boff[2], an, rsrc, rowoff, s2n, lane, f);
+        rotation<R0, 2, LOADA, S2, F, R0, R0 + 1>(ac, be, bo, kxs + boff[3], an, rsrc, rowoff, s2n, lane, f);
+        rotation<R0, 3, LOADA, S2, F, R0, R0 + 1>(ac, bo, be, kxs_next + boff[0], an, rsrc, rowoff, s2n, lane, f);
+        diag_pairs<R0, S2 + 1, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f, nz);
+    }
+}
+// one chunk of 64 training points against the row blocks r >= R0 (DIAG: R0 is the diagonal block)
+template <int R0, bool DIAG, class F>
 __device__ __forceinline__ void chunk(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
                                       const int (&rowoff)[R], int ch, int lane, const int (&boff)[4],
-                                      F& f) {
+                                      F& f, int nz) {
     AFrag a[3];
     BFrag be, bo;
-    load_a<R0>(a[0], rsrc, rowoff, 8 * ch, lane);
-    load_a<R0>(a[1], rsrc, rowoff, 8 * ch + 1, lane);
-    load_b(be, kxb, boff[0]);
-    slab_pairs<R0, 0, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f);
+    if constexpr (DIAG) {
+        // the diagonal block first; the first fragments of the blocks below it are requested with
+        // its own (one trip to L2 in front of the chunk, as without the split)
+        AFrag ad[3];
+        ad[0].v[R0] = __builtin_bit_cast(
+            sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[R0] + (8 * ch) * 1024, 0));
+        ad[1].v[R0] = __builtin_bit_cast(
+            sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[R0] + (8 * ch + 1) * 1024, 0));
+        if constexpr (R0 + 1 < R) {
+            load_a<R0 + 1>(a[0], rsrc, rowoff, 8 * ch, lane);
+            load_a<R0 + 1>(a[1], rsrc, rowoff, 8 * ch + 1, lane);
+        }
+        load_b(be, kxb, boff[0]);
+        diag_pairs<R0, 0, F>(ad, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f, nz);
+        if constexpr (R0 + 1 < R) {
+            // The blocks below READ their first k_x fragments again.  (Handing them over from the
+            // diagonal stream - its last rotation fetching slab pair 0 - made the compiler join the
+            // four ways out of that stream with register copies right in front of the first MFMA:
+            // a VALU write of an MFMA source one issue slot ahead of the MFMA, which the hardware
+            // does not interlock for the inline-asm MFMAs - wrong |a|^2, found by the parity tests;
+            // tools/audit_gp4.py now refuses such a listing.)
+            load_b(be, kxb, boff[0]);
+            asm volatile("s_nop 1");
+            slab_pairs<R0 + 1, 0, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f);
+        }
+    } else {
+        load_a<R0>(a[0], rsrc, rowoff, 8 * ch, lane);
+        load_a<R0>(a[1], rsrc, rowoff, 8 * ch + 1, lane);
+        load_b(be, kxb, boff[0]);
+        slab_pairs<R0, 0, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f);
+    }
 }
 // q = chunk index relative to the panel's diagonal band.  Row block r of a wavefront has its
 // diagonal in chunk r of the band: blocks r >= q are active (the diagonal block's fragments are
-// zero above the diagonal), blocks r < q lie above it; q < 0: every block is active.
+// zero above the diagonal: from slab pair nzd[q] on), blocks r < q lie above it; q < 0: every block
+// is active and full.
 template <class F>
 __device__ __forceinline__ void chunk_any(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
                                           const int (&rowoff)[R], int q, int ch, int lane,
-                                          const int (&boff)[4], F& f) {
+                                          const int (&boff)[4], F& f, const int (&nzd)[R]) {
+#if SL_GP4_DIAG_SKIP
         switch (q) {
-            case 1: chunk<1, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-            case 2: chunk<2, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-            case 3: chunk<3, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
-            default: chunk<0, F>(rsrc, kxb, rowoff, ch, lane, boff, f); break;
+            case 0: chunk<0, true, F>(rsrc, kxb, rowoff, ch, lane, boff, f, nzd[0]); break;
+            case 1: chunk<1, true, F>(rsrc, kxb, rowoff, ch, lane, boff, f, nzd[1]); break;
+            case 2: chunk<2, true, F>(rsrc, kxb, rowoff, ch, lane, boff, f, nzd[2]); break;
+            case 3: chunk<3, true, F>(rsrc, kxb, rowoff, ch, lane, boff, f, nzd[3]); break;
+            default: chunk<0, false, F>(rsrc, kxb, rowoff, ch, lane, boff, f, 8); break;
         }
+#else
+        switch (q) {
+            case 1: chunk<1, false, F>(rsrc, kxb, rowoff, ch, lane, boff, f, 8); break;
+            case 2: chunk<2, false, F>(rsrc, kxb, rowoff, ch, lane, boff, f, 8); break;
+            case 3: chunk<3, false, F>(rsrc, kxb, rowoff, ch, lane, boff, f, 8); break;
+            default: chunk<0, false, F>(rsrc, kxb, rowoff, ch, lane, boff, f, 8); break;
+        }
+#endif
 }
 
 // exp of two arguments (sl_exp_nonpos twice), the two dependent FMA chains written alternately: a
@@ -746,10 +816,12 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
             for (int pan = 0; pan < npanels; ++pan) {
                 acc_zero_all();
                 int rowoff[R];                     // byte offset of each owned row block's fragments
+                int nzd[R];                        // slab pairs of its diagonal chunk that are not zero
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int wsel = (r & 1) ? (W - 1 - wave) : wave;     // balance the triangle
                     rowoff[r] = (pan * RB + r * W + wsel) * hd.nslab2 * 1024;
+                    nzd[r] = 2 * wsel + 2;
                 }
                 constexpr int CPP = RP / 64;                     // chunks per panel (its diagonal band)
                 const int nchunks = (pan + 1) * CPP;
@@ -762,7 +834,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                     const int q = __builtin_amdgcn_readfirstlane(ch - CPP * pan);
                     const double* kxb = kx_l + buf * KXBUF;
                     NoFill nf;
-                    if (!(skip & 8)) chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, nf);
+                    if (!(skip & 8)) chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, nf, nzd);
                     if (ch + 1 < nchunks) produce(ch + 1, buf ^ 1, first_new_chunk, keep);
                     __syncthreads();
                 }

@@ -23,6 +23,7 @@
 // after the relaxation has converged.  Equal values among the
 // touched cells are outside this equivalence (the heap's order of equal keys is its push order) -
 // like the tie order of the level-set rule, parity-unpinned.
+#include <climits>
 #include "sl_common.h"
 
 namespace {
@@ -126,36 +127,54 @@ __global__ __launch_bounds__(SL_BLOCK) void k_region_bound(RegionGrid g, const d
     if ((threadIdx.x & 63) == 0 && best < INF) atomic_min_f64(&state[0], best);
 }
 
-// the last regular pop x* (V = D = c*) and, unless it lies on the boundary, the lowest neighbour it
-// descends to: out[0] = x*, out[1] = y (or -1)
-__global__ __launch_bounds__(SL_BLOCK) void k_region_stop(RegionGrid g, const double* __restrict__ values,
-                                                          const double* __restrict__ dist,
-                                                          const double* __restrict__ state,
-                                                          long long* out) {
+// The last regular pop x* (V = D = c*).  Several nodes can qualify (on a grid that is symmetric
+// about the origin x and -x always tie): ONE of them is the reference's last pop - which one is
+// decided by its heap's insertion counter, not pinned by anything - and the region holds that node
+// and ITS descent neighbour only.  The lowest flat index is taken (pick), and the second kernel
+// lets that node alone write out[0] = x*, out[1] = y (the lowest neighbour it descends to, -1 / -2).
+__global__ __launch_bounds__(SL_BLOCK) void k_region_stop_pick(RegionGrid g, const double* __restrict__ values,
+                                                               const double* __restrict__ dist,
+                                                               const double* __restrict__ state,
+                                                               long long* pick) {
     const double cstar = state[0];
+    long long best = LLONG_MAX;
     for (int64_t i = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; i < g.nindex;
-         i += (int64_t)gridDim.x * SL_BLOCK) {
-        if (!(dist[i] == cstar && values[i] == cstar)) continue;
-        int64_t ijk[SL_D];
-        unravel(g, i, ijk);
-        long long y = -1;
-        if (!on_boundary(g, ijk)) {
-            double low = INF;
-            neighbours(g, ijk, [&](int64_t u) {
-                const double vu = values[u];
-                if (vu < cstar && dist[u] == cstar && vu < low) { low = vu; y = (long long)u; }
-            });
-            if (y >= 0) {                                  // a descent onto the boundary is dropped
-                int64_t yk[SL_D];
-                unravel(g, y, yk);
-                if (on_boundary(g, yk)) y = -2;
-            }
-            out[0] = (long long)i;
-            out[1] = y;
-        } else {
-            out[0] = -1;                                   // x* on the boundary: dropped
-            out[1] = -1;
+         i += (int64_t)gridDim.x * SL_BLOCK)
+        if (dist[i] == cstar && values[i] == cstar) best = (long long)i < best ? (long long)i : best;
+    for (int off = 32; off >= 1; off >>= 1) {
+        const long long o = __shfl_xor(best, off, 64);
+        best = o < best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best != LLONG_MAX) atomicMin(pick, best);
+}
+
+__global__ __launch_bounds__(64) void k_region_stop(RegionGrid g, const double* __restrict__ values,
+                                                    const double* __restrict__ dist,
+                                                    const double* __restrict__ state,
+                                                    const long long* __restrict__ pick, long long* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double cstar = state[0];
+    const long long i = *pick;
+    if (i == LLONG_MAX) return;                            // (out stays -1, -1)
+    int64_t ijk[SL_D];
+    unravel(g, i, ijk);
+    long long y = -1;
+    if (!on_boundary(g, ijk)) {
+        double low = INF;
+        neighbours(g, ijk, [&](int64_t u) {
+            const double vu = values[u];
+            if (vu < cstar && dist[u] == cstar && vu < low) { low = vu; y = (long long)u; }
+        });
+        if (y >= 0) {                                      // a descent onto the boundary is dropped
+            int64_t yk[SL_D];
+            unravel(g, y, yk);
+            if (on_boundary(g, yk)) y = -2;
         }
+        out[0] = i;
+        out[1] = y;
+    } else {
+        out[0] = -1;                                       // x* on the boundary: dropped
+        out[1] = -1;
     }
 }
 
@@ -181,8 +200,8 @@ extern "C" int sl_lyapunov_region(sl_ctx* ctx, const double* d_values, int64_t s
     if (!d_values || !d_work || !d_region || start < 0 || start >= g.nindex)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_lyapunov_region: bad argument");
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    // scratch: [c_ub, changed] + the two stop nodes
-    const size_t need = 4 * sizeof(double);
+    // scratch: [c_ub, changed] + the two stop nodes + the picked last pop
+    const size_t need = 5 * sizeof(double);
     if (need > ctx->scratch_bytes) {
         if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
         ctx->d_scratch = nullptr;
@@ -219,10 +238,12 @@ extern "C" int sl_lyapunov_region(sl_ctx* ctx, const double* d_values, int64_t s
     }
     hipLaunchKernelGGL(k_region_bound, dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream, g, d_values, d_work,
                        state, true);                       // the fixpoint: descents count now
-    long long none[2] = {-1, -1};
+    long long none[3] = {-1, -1, LLONG_MAX};
     SL_HIP_CHECK(ctx, hipMemcpyAsync(stop, none, sizeof(none), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_region_stop, dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream, g, d_values, d_work,
-                       state, stop);
+    hipLaunchKernelGGL(k_region_stop_pick, dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream, g, d_values, d_work,
+                       state, stop + 2);
+    hipLaunchKernelGGL(k_region_stop, dim3(1), dim3(64), 0, ctx->stream, g, d_values, d_work, state,
+                       stop + 2, stop);
     hipLaunchKernelGGL(k_region_mark, dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream, g.nindex, d_work, state,
                        stop, d_region);
     SL_HIP_CHECK(ctx, hipGetLastError());

@@ -99,17 +99,22 @@ __global__ __launch_bounds__(SL_BLOCK) void k_state_membership(const SlDevModel 
     for (int64_t i = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; i < count;
          i += (int64_t)gridDim.x * SL_BLOCK) {
         int64_t flat = 0;
+        bool nan = false;
         for (int k = 0; k < d; ++k) {
             double x = points[i * d + k];
+            nan = nan || (x != x);             // a NaN posterior maps nowhere (the reference raises in
+                                               // ravel_multi_index): not inside, and no look-up
             const double lo = M.m.grid.offset[k], hi = M.m.grid.upper[k];
             x = x < lo ? lo : x;                                               // np.clip
             x = x > hi ? hi : x;
             const double inv = 1.0 / M.m.grid.unit_maxes[k];
             const double s = (x - lo) * inv;
-            const int64_t ijk = (int64_t)rint(s);                              // np.rint: half to even
+            int64_t ijk = nan ? 0 : (int64_t)rint(s);                          // np.rint: half to even
+            const int64_t last = M.m.grid.num_points[k] - 1;
+            ijk = ijk < 0 ? 0 : (ijk > last ? last : ijk);                     // (rounding at the upper limit)
             flat = flat * M.m.grid.num_points[k] + ijk;
         }
-        const bool safe = (safe_bits[flat >> 6] >> (flat & 63)) & 1ull;
+        const bool safe = !nan && ((safe_bits[flat >> 6] >> (flat & 63)) & 1ull);
         inout[i] = (inout[i] && safe) ? 1 : 0;
     }
 }

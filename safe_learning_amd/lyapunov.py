@@ -26,6 +26,30 @@ from .configuration import config
 __all__ = ['Lyapunov', 'smallest_boundary_value', 'get_safe_sample', 'perturb_actions',
            'get_lyapunov_region']
 
+def _digest(array):
+    """128-bit content digest of an array's bytes (xxh3 at several GB/s when the xxhash package is
+    there, blake2b otherwise): how in-place edits of ``initial_safe_set`` and ``safe_set`` are
+    noticed - the reference reads both afresh on every call (``lyapunov.py:500-510``)."""
+    data = np.ascontiguousarray(array)
+    view = memoryview(data.reshape(-1).view(np.uint8)) if data.size else b''
+    try:
+        import xxhash
+        return xxhash.xxh3_128_intdigest(view)
+    except ImportError:                                  # pragma: no cover - image has xxhash
+        import hashlib
+        return hashlib.blake2b(view, digest_size=16).digest()
+
+
+def _frozen(array):
+    """True for an ndarray nobody can edit in place through NumPy: read-only, and so is every array
+    it is a view of.  Such a mask is identified by object identity; a writable one by its digest."""
+    while isinstance(array, np.ndarray):
+        if array.flags.writeable:
+            return False
+        array = array.base
+    return array is None
+
+
 _U64_MAX = (1 << 64) - 1
 _I64_MAX = (1 << 63) - 1
 _KEY_NONE = (_U64_MAX, _I64_MAX)
@@ -79,6 +103,7 @@ class Lyapunov(object):
             self._safe_host[initial_set] = True
         self._safe_host_valid = True
         self._safe_dev_valid = False
+        self._safe_host_digest = None
         self.update_values()
 
     # ---- engine plumbing -----------------------------------------------------------------
@@ -117,6 +142,8 @@ class Lyapunov(object):
         self._d_safe_full = None        # all shards' mask words, gathered by update_safe_set
         self._init_version = None
         self._init_object = None
+        self._safe_host_digest = None   # digest of the host mask when it last equalled the device's
+        self.mask_uploads = 0           # host -> device copies of grid-sized masks (tests, bench)
 
     def _bare_init(self, discretization, fun):
         """Value-only instance used by ``smallest_boundary_value``."""
@@ -146,13 +173,36 @@ class Lyapunov(object):
                                                 device=self._ctx.torch_device)
             self._values_stale = True
         if self._values_stale:
-            self._upload_model()
+            # implicit values are those of the function as it was at update_values() (a copy of
+            # its d x d matrix): the reference's array does not follow later edits of the function
+            snapshot = getattr(self, '_implicit_snapshot', None)
+            fun = snapshot[0] if (self._values_implicit and snapshot is not None) else self.lyapunov_function
+            self._builder.upload(self.policy, self.dynamics, fun, self._lipschitz_lyapunov,
+                                 self._lipschitz_dynamics, self.tau)
             self._ctx.values(self._lo, self._hi, self._d_values_buffer)
             self._values_stale = False
+            if fun is not self.lyapunov_function:
+                self._upload_model()
         return self._d_values_buffer
 
+    def _implicit_signature(self):
+        """What the kernels' recomputed keys depend on (closed-form V: its matrix and sign)."""
+        fun = self._lyapunov_function
+        matrix = getattr(fun, 'matrix', None)
+        return (type(fun).__name__, bool(getattr(fun, 'negate', False)),
+                None if matrix is None else np.asarray(matrix).tobytes())
+
     def _values_arg(self):
-        """What the passes get as ``d_values``: None when the keys are recomputed in the kernels."""
+        """What the passes get as ``d_values``: None when the keys are recomputed in the kernels.
+
+        ``values`` are the numbers of the last ``update_values()`` (``lyapunov.py:305-322``): if the
+        closed-form function was edited IN PLACE since then (same object, other matrix), the keys
+        the kernels would recompute are no longer those numbers - V is written down from the
+        snapshot taken at ``update_values()`` and the passes read the array."""
+        snapshot = getattr(self, '_implicit_snapshot', None)
+        if self._values_implicit and snapshot is not None and self._implicit_signature() != snapshot[1]:
+            self._d_values
+            self._values_implicit = False
         return None if self._values_implicit else self._d_values
 
     # ---- reference attribute surface -----------------------------------------------------
@@ -167,7 +217,7 @@ class Lyapunov(object):
         # model, write them down with the old function before the model changes.
         old = getattr(self, '_lyapunov_function', None)
         if old is not None and fun is not old and getattr(self, '_values_implicit', False):
-            self._d_values
+            self._d_values                   # (from the snapshot of update_values(), see there)
             self._values_implicit = False
         self._lyapunov_function = fun
 
@@ -179,6 +229,7 @@ class Lyapunov(object):
     def initial_safe_set(self, value):
         self._initial_safe_set = value
         self._init_version = None
+        self._init_object = None
 
     def lipschitz_dynamics(self, states):
         """Lipschitz constant of the dynamics at ``states`` (``lyapunov.py:227-244``): the scalar,
@@ -273,7 +324,13 @@ class Lyapunov(object):
     @property
     def safe_set(self):
         """``bool[nindex]`` mask, the same array object across calls (``lyapunov.py:187, 598-606``).
-        A local read on every rank (``update_safe_set`` gathers the shards' mask words)."""
+        A local read on every rank (``update_safe_set`` gathers the shards' mask words).
+
+        Reading does not give up the device copy: the array's digest is kept, and the next call
+        that needs the mask on the device (``update_safe_set(can_shrink=False)``,
+        ``get_safe_sample``) compares it - an array the caller edited in place is packed and
+        uploaded again, an untouched one (the notebooks' loop looks at the set after every update)
+        costs one hash of the host array instead of a 268 MB round trip at 128^4."""
         if not self._safe_host_valid:
             import torch
             n = self.discretization.nindex
@@ -283,8 +340,8 @@ class Lyapunov(object):
             self._ctx.bits_to_bytes(n, words, d_bytes)
             self._safe_host[:] = d_bytes[:n].cpu().numpy().astype(bool)
             self._safe_host_valid = True
-            # the host array may now be edited by the caller: it becomes the truth again
-            self._safe_dev_valid = False
+            # the caller may edit the array from now on: remember what the device copy equals
+            self._safe_host_digest = _digest(self._safe_host)
         return self._safe_host
 
     @safe_set.setter
@@ -292,6 +349,24 @@ class Lyapunov(object):
         self._safe_host[:] = value
         self._safe_host_valid = True
         self._safe_dev_valid = False
+        self._safe_host_digest = None
+
+    def _safe_device_current(self):
+        """Is the device copy of the safe set still the truth?  (False: the host array is - it was
+        assigned, or edited in place since it was downloaded.)"""
+        if self._safe_dev_valid and self._safe_host_valid:
+            if self._safe_host_digest is None or _digest(self._safe_host) != self._safe_host_digest:
+                self._safe_dev_valid = False
+                self._safe_host_digest = None
+        return self._safe_dev_valid
+
+    def _sync_safe_to_device(self):
+        """This rank's words of the previous safe set on the device (``lyapunov.py:507-510``)."""
+        if not self._safe_device_current():
+            self._upload_mask(self._safe_host, self._d_safe)
+            self._d_safe_full = None            # (collective runs: gathered again by the next update)
+            self._safe_dev_valid = True
+            self._safe_host_digest = _digest(self._safe_host)
 
     @property
     def _refinement(self):
@@ -347,26 +422,34 @@ class Lyapunov(object):
         if count == 0:
             return
         chunk = np.ascontiguousarray(host_mask[self._lo:self._hi]).view(np.uint8)
+        self.mask_uploads += 1
         d_bytes = torch.from_numpy(chunk).to(self._ctx.torch_device)
         self._ctx.bytes_to_bits(count, d_bytes, d_bits)
 
     def _refresh_init_bits(self):
+        """Bit words of the initial safe set on the device, uploaded again whenever the set has
+        changed - ALSO when it was edited in place: the reference reads ``initial_safe_set`` afresh
+        on every call (``lyapunov.py:500-506, 604-606``).  A writable array (or a list) is
+        identified by a digest of its content, computed on every call (xxh3: 0.15 ms per MB); an
+        array that nobody can write to (``mask.flags.writeable = False``, no writable base) by
+        object identity - the way to keep a 268 MB mask at 128^4 from being hashed by every
+        update."""
         init = self._initial_safe_set
         if init is None:
-            version = 'none'
+            version = ('none',)
+        elif _frozen(init) and init is self._init_object:
+            return
         else:
             arr = np.asarray(init)
-            # large masks are identified by object identity (re-assign ``initial_safe_set`` after
-            # editing one in place); small ones also by content
-            checksum = int(np.count_nonzero(arr)) if arr.size <= (1 << 20) else -1
-            version = (arr.shape, arr.dtype.str, checksum)
-        # the cached object is held strongly and compared by identity: an id() could be recycled
-        if version == self._init_version and init is self._init_object:
-            return
+            version = (arr.shape, arr.dtype.str, _digest(arr))
+            # the cached object is held strongly and compared by identity: an id() could be recycled
+            if version == self._init_version and init is self._init_object:
+                return
         if init is None:
+            if self._init_version == version:
+                return
             self._d_init.zero_()
         else:
-            arr = np.asarray(init)
             if arr.dtype == bool and arr.shape == (self.discretization.nindex,):
                 mask = arr
             else:
@@ -385,8 +468,11 @@ class Lyapunov(object):
         read.  ``gather=True`` (sharded grids): gather all shards now, collectively, so that a
         later read of ``values`` on ONE rank only is a local read (the lazy gather behind the
         attribute is a collective and must otherwise be reached by every rank)."""
+        import copy
         self._upload_model()
         self._values_implicit = self._ctx.values_implicit()
+        self._implicit_snapshot = ((copy.deepcopy(self._lyapunov_function), self._implicit_signature())
+                                   if self._values_implicit else None)
         self._values_stale = True
         if not self._values_implicit:
             self._d_values                   # computes this rank's shard now
@@ -406,8 +492,8 @@ class Lyapunov(object):
         self._refinement_dev = None
         self._upload_model()
         self._refresh_init_bits()
-        if not can_shrink and not self._safe_dev_valid:          # lyapunov.py:507-510
-            self._upload_mask(self._safe_host, self._d_safe)
+        if not can_shrink:                                       # lyapunov.py:507-510
+            self._sync_safe_to_device()
         engine = _HipShardEngine(self)
         stats = {}
         self.c_max = prefix_rule(engine, self.discretization.nindex, int(config.gp_batch_size),
@@ -415,6 +501,7 @@ class Lyapunov(object):
         self.safe_count = stats['safe']       # cells in the safe set (all ranks), no mask copy
         self._safe_host_valid = False
         self._safe_dev_valid = True
+        self._safe_host_digest = None
         if self._collective:
             # shards start at multiples of 64 cells, so their mask words concatenate (4 MB per
             # rank at 128^4 over 8 GPUs); afterwards ``safe_set`` is a local read on every rank
@@ -435,8 +522,8 @@ class Lyapunov(object):
         size but its own shard."""
         self._upload_model()
         self._refresh_init_bits()
-        if not can_shrink and not self._safe_dev_valid:          # lyapunov.py:507-510
-            self._upload_mask(self._safe_host, self._d_safe)
+        if not can_shrink:                                       # lyapunov.py:507-510
+            self._sync_safe_to_device()
         engine = _HipAdaptiveEngine(self, can_shrink)
         stats = {}
         self.c_max = adaptive_rule(engine, self.discretization.nindex, int(config.gp_batch_size),
@@ -446,6 +533,7 @@ class Lyapunov(object):
         self._refinement_host = None
         self._safe_host_valid = False
         self._safe_dev_valid = True
+        self._safe_host_digest = None
         if self._collective:
             self._d_safe_full = dist_utils.allgather_equal(
                 self._d_safe, -(-self.discretization.nindex // 64), out=self._safe_full_buffer())
@@ -781,8 +869,9 @@ def _safe_words_device(lyapunov):
     import torch
     n = lyapunov.discretization.nindex
     dev = lyapunov._ctx.torch_device
-    if lyapunov._safe_host_valid and not lyapunov._safe_dev_valid:
-        d_bytes = torch.from_numpy(lyapunov._safe_host.view(np.uint8)).to(dev)
+    if not lyapunov._safe_device_current() or (lyapunov._collective and lyapunov._d_safe_full is None):
+        lyapunov.mask_uploads += 1
+        d_bytes = torch.from_numpy(lyapunov.safe_set.view(np.uint8)).to(dev)
         words = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
         lyapunov._ctx.bytes_to_bits(n, d_bytes, words)
         return words

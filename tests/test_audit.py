@@ -141,3 +141,20 @@ def test_gp4_audit_rejects(streams, extra, what, tmp_path):
 def test_gp4_audit_allows_scratch_and_lane_reads_outside_the_streams(tmp_path):
     extra = ["\tscratch_load_dword v1, off, off", "\tv_readlane_b32 s4, v200, 3"] * 40
     assert not audit_gp4.audit(gp_listing([gp_stream()] * 2, extra, tmp_path), min_loops=2)[1]
+
+
+def test_gp4_audit_rejects_a_copy_into_an_mfma_source(tmp_path):
+    """Round 5: where the ways out of the diagonal stream joined, the compiler copied the k_x
+    fragments into other registers right in front of the first MFMA group of the blocks below -
+    the inline-asm MFMA read the registers' old contents (wrong |a|^2 on the GPU).  A vector-ALU
+    write of an A / B source fewer than two issue slots ahead of the MFMA is refused."""
+    copy = "\tv_mov_b64_e32 v[4:5], v[20:21]"
+    for between in ([], ["\ts_waitcnt lgkmcnt(0)"], ["\ts_nop 0"]):
+        found = audit_gp4.audit(gp_listing([gp_stream(inside=[copy] + between)] * 2, [], tmp_path), min_loops=2)[1]
+        assert any("MFMA source written right in front" in p for p in found), (between, found)
+    for between in (["\ts_nop 1"], ["\tds_read_b128 v[40:43], v60", "\ts_waitcnt lgkmcnt(0)"]):
+        assert not audit_gp4.audit(gp_listing([gp_stream(inside=[copy] + between)] * 2, [], tmp_path),
+                                   min_loops=2)[1], between
+    # a copy into a register that the next MFMAs do not read is none of the audit's business
+    other = "\tv_mov_b64_e32 v[40:41], v[20:21]"
+    assert not audit_gp4.audit(gp_listing([gp_stream(inside=[other])] * 2, [], tmp_path), min_loops=2)[1]

@@ -207,9 +207,11 @@ def test_c5_cartpole_64_bellman_sweeps():
     orl.value_function = ovf2
     u = opol(x)
     ref = orl.future_values(x, actions=u)[:, 0]
-    ok = ~ambiguous_points(opol, x) & ~ambiguous_points(ovf2, odynamics(x, u)[0])
-    exclusions.report("C5 64^4 policy evaluation (greedy table at its own vertices)", ok,
-                      "own vertices, full size")
+    label = "C5 64^4 policy evaluation (greedy table at its own vertices)"
+    # vertices where the greedy table has several admissible values: one of them (nothing left out)
+    amb = exclusions.check_own_vertices(label, orl, opol, x, evaluated[idx])
+    ok = ~amb & ~ambiguous_points(ovf2, odynamics(x, u)[0])
+    exclusions.report(label, ok | amb, "successor")
     assert_allclose(evaluated[idx][ok], ref[ok], rtol=1e-9, atol=1e-12)
 
     # residual of the optimality sweeps decays monotonically (gamma-contraction)

@@ -145,10 +145,16 @@ def _worker(rank, world, port, results, backend="gloo"):
         vf.parameters = ovf.parameters.copy()
         nxt = orl.dynamics(x, orl.policy(x))
         nxt = nxt[0] if isinstance(nxt, tuple) else nxt
-        ok = ~test_gpu_rl.ambiguous_points(orl.policy, x) & ~test_gpu_rl.ambiguous_points(ovf, nxt)
-        if not exclusions.within("two ranks: value_iteration sweep %d" % sweep, ok, "own vertices"):
-            failures.append(("rl", "exclusions", float(1 - ok.mean())))
         res = rl.value_iteration()
+        try:                                    # ambiguous vertices of the policy table: membership
+            amb = exclusions.check_own_vertices("two ranks: value_iteration sweep %d" % sweep, orl,
+                                                orl.policy, x, vf._host_parameters())
+        except AssertionError as exc:
+            failures.append(("rl", "membership", str(exc)))
+            amb = test_gpu_rl.ambiguous_points(orl.policy, x)
+        ok = ~amb & ~test_gpu_rl.ambiguous_points(ovf, nxt)
+        if not exclusions.within("two ranks: value_iteration sweep %d" % sweep, ok | amb, "successor"):
+            failures.append(("rl", "exclusions", float(1 - ok.mean())))
         orl.value_iteration()
         if not np.allclose(vf._host_parameters()[ok], ovf.parameters[ok], rtol=1e-9, atol=1e-12):
             failures.append(("rl", "value_iteration", sweep))
@@ -175,10 +181,16 @@ def _worker(rank, world, port, results, backend="gloo"):
     rl.policy.parameters = orl.policy.parameters.copy()
     vf.parameters = ovf.parameters.copy()
     nxt = orl.dynamics(x, orl.policy(x))
-    ok = ~test_gpu_rl.ambiguous_points(orl.policy, x) & ~test_gpu_rl.ambiguous_points(ovf, nxt[0])
-    if not exclusions.within("two ranks: 4x4x4 policy evaluation", ok, "own vertices"):
-        failures.append(("rl", "exclusions", float(1 - ok.mean())))
     rl.value_iteration()
+    try:
+        amb = exclusions.check_own_vertices("two ranks: 4x4x4 policy evaluation", orl, orl.policy, x,
+                                            vf._host_parameters())
+    except AssertionError as exc:
+        failures.append(("rl", "membership", str(exc)))
+        amb = test_gpu_rl.ambiguous_points(orl.policy, x)
+    ok = ~amb & ~test_gpu_rl.ambiguous_points(ovf, nxt[0])
+    if not exclusions.within("two ranks: 4x4x4 policy evaluation", ok | amb, "successor"):
+        failures.append(("rl", "exclusions", float(1 - ok.mean())))
     orl.value_iteration()
     if "k_bellman4_policy" not in rl._ctx.last_kernel():
         failures.append(("rl", "policy kernel", rl._ctx.last_kernel()))

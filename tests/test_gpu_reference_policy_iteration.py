@@ -55,6 +55,10 @@ FIXTURE = np.load(os.path.join(GOLDEN_DIR, "reference_policy_iteration.npz"))
 INDEX = json.loads(str(FIXTURE["_index"]))
 NAMES = [entry["scenario"]["name"] for entry in INDEX]
 RTOL, ATOL = 1e-9, 1e-12
+# successor states within 1e-9 cells of a grid line of the value table (rounding decides the cell) or
+# ambiguous for the VALUE table: still left out; the policy table's ambiguous vertices (up to 41 %
+# of these small tables) are membership-checked since round 5
+FACE_LIMIT = 0.25
 
 
 def _on_table_face(table, points, eps=1e-9):
@@ -90,8 +94,12 @@ def test_engine_tables_equal_the_reference_run(entry):
         lyap = sl.Lyapunov(vgrid, lyap_value, dynamics, case["lf"], lv, case["tau"], policy)
 
     # the oracle twin: only for the exclusion masks
-    opolicy, odynamics, oreward, ovalue, _ = GENERATOR.build_oracle_leaves(scenario)
+    opolicy, odynamics, oreward, ovalue, (olyap_value, olv) = GENERATOR.build_oracle_leaves(scenario)
     orl = oracle.PolicyIteration(opolicy, odynamics, oreward, ovalue, gamma=scenario["gamma"])
+    olyap = None
+    if scenario["lyapunov"]:
+        olyap = oracle.Lyapunov(oracle.GridWorld(scenario["limits"], scenario["value_points"]), olyap_value,
+                                odynamics, case["lf"], olv, case["tau"], opolicy)
     x = ovalue.discretization.all_points
 
     record, compared = 0, 0
@@ -100,11 +108,16 @@ def test_engine_tables_equal_the_reference_run(entry):
         if kind == "vi":
             for _ in range(step[1]):
                 want = FIXTURE["%s/record%d" % (name, record)]
-                ok = ~ambiguous_points(opolicy, x)
-                ok &= ~_on_table_face(ovalue, _mean(odynamics(x, opolicy(x))))
+                label = "reference run %s record %d" % (name, record)
                 rl.value_iteration()
                 got = value._host_parameters()
-                exclusions.report("reference run %s record %d" % (name, record), ok, "own vertices")
+                # Vertices at which the policy table has several admissible values (SciPy's answer
+                # depends on its search history): the engine's AND the reference run's value have
+                # to be the future value under one of them.  Everything else is compared.
+                amb = exclusions.check_own_vertices(label, orl, opolicy, x, got, also=want,
+                                                    rtol=RTOL, atol=ATOL)
+                ok = ~amb & ~_on_table_face(ovalue, _mean(odynamics(x, opolicy(x))))
+                exclusions.report(label, ok | amb, "successor", limit=FACE_LIMIT)
                 assert_allclose(got[ok], want[ok], rtol=RTOL, atol=ATOL,
                                 err_msg="%s record %d" % (name, record))
                 compared += int(ok.sum())
@@ -159,12 +172,18 @@ def test_engine_tables_equal_the_reference_run(entry):
                 else:
                     actions = opolicy(points)
                 ok = ~_on_table_face(ovalue, _mean(odynamics(points, actions)))
-                if "actions" not in arg:
-                    ok &= ~ambiguous_points(opolicy, points)
                 got = rl.future_values(states, **arg)
-                exclusions.report("reference run %s record %d" % (name, record), ok,
-                                  "successor" if "actions" in arg else "own vertices")
+                label = "reference run %s record %d" % (name, record)
                 tolerance = 1e-8 if "lyapunov" in arg else RTOL
+                amb = np.zeros(len(points), dtype=bool)
+                if "actions" not in arg:
+                    extra = {}
+                    if "lyapunov" in arg:
+                        extra = dict(lyapunov=olyap, lagrange_multiplier=arg.get("lagrange_multiplier", 1.))
+                    amb = exclusions.check_own_vertices(label, orl, opolicy, points, got, also=want,
+                                                        rtol=tolerance, atol=1e-11, **extra)
+                    ok &= ~amb
+                exclusions.report(label, ok | amb, "successor", limit=FACE_LIMIT)
                 assert_allclose(got[ok], want[ok], rtol=tolerance, atol=1e-11,
                                 err_msg="%s record %d" % (name, record))
                 compared += int(ok.sum())

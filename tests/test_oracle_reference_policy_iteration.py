@@ -104,3 +104,38 @@ def test_scenarios_are_not_vacuous():
     rl.value_iteration()
     plain = rl.future_values(value.discretization.all_points)
     assert np.max(np.abs(plain - penalised)) > 1e-3
+
+
+@pytest.mark.parametrize("entry", INDEX, ids=NAMES)
+def test_reference_values_at_ambiguous_vertices_are_admissible(entry):
+    """Where a piecewise-constant policy table is read at its own vertices, the ``%`` of
+    ``functions.py:1116-1124`` wraps the query into a corner shared by several unit-cell simplices
+    and SciPy's answer depends on its search history.  ``tests/exclusions.py`` enumerates the
+    admissible answers (one per containing simplex); the GPU tests demand that the engine's value is
+    one of them.  Here the enumeration itself is checked against the reference run: at every
+    ambiguous vertex of every recorded sweep the REFERENCE's value is in the set."""
+    import exclusions
+    scenario = _scenario(entry)
+    name, case = scenario["name"], scenario["case"]
+    policy, dynamics, reward, value, (lyap_value, lv) = GENERATOR.build_oracle_leaves(scenario)
+    rl = oracle.PolicyIteration(policy, dynamics, reward, value, gamma=scenario["gamma"])
+    x = value.discretization.all_points
+    record, checked = 0, 0
+    for step in scenario["steps"]:
+        kind = step[0]
+        if kind == "vi":
+            for _ in range(step[1]):
+                want = FIXTURE["%s/record%d" % (name, record)]
+                amb = exclusions.check_own_vertices("%s record %d" % (name, record), rl, policy, x, want,
+                                                    also=want, rtol=1e-9, atol=1e-12)
+                checked += int(amb.sum())
+                value.parameters = want.copy()
+                record += 1
+        elif kind == "dpo":
+            policy.parameters = FIXTURE["%s/record%d" % (name, record)].copy()
+            record += 1
+        else:
+            record += 1
+    assert record == entry["records"]
+    if name in ("pendulum_analytic", "pendulum_gp_constraint", "random_1_pendulum_gp"):
+        assert checked > 20                      # (a third of these tables' vertices are ambiguous)

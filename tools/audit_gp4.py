@@ -19,6 +19,45 @@ def _touches_owned(code, owned):
     return False
 
 
+def _vregs(text):
+    out = set()
+    for mm in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        if mm.group(3) is not None:
+            out.add(int(mm.group(3)))
+        else:
+            out.update(range(int(mm.group(1)), int(mm.group(2)) + 1))
+    return out
+
+
+def mfma_sources_written_too_late(body, slots_needed=2):
+    """The MFMAs are inline asm: the compiler's hazard recogniser does not look inside, and the
+    hardware does not interlock a vector-ALU write of an A / B source register with an FP64 MFMA
+    that reads it fewer than ``slots_needed`` issue slots later (round 5: register copies that the
+    compiler placed where control flow joined in front of an MFMA group - the MFMA read the old
+    register contents).  Returns the offending (producer, MFMA) pairs of a kernel body."""
+    code = [l.split(";")[0].strip() for l in body if not l.strip().startswith(";;")]
+    code = [c for c in code if c and not c.startswith(".") and not c.endswith(":")]
+    close = []
+    for i, c in enumerate(code):
+        if not c.startswith("v_mfma_f64_4x4x4"):
+            continue
+        ops = c.split(None, 1)[1].split(", ")
+        sources = _vregs(ops[1]) | _vregs(ops[2])
+        slots = 0
+        for back in range(1, slots_needed + 2):
+            if i - back < 0 or slots >= slots_needed:
+                break
+            prev = code[i - back]
+            if prev.startswith("s_nop"):
+                slots += int(prev.split()[1]) + 1
+                continue
+            if prev.startswith("v_") and not prev.startswith("v_mfma") and " " in prev:
+                if _vregs(prev.split(None, 1)[1].split(", ")[0]) & sources:
+                    close.append("%s -> %s" % (prev, c))
+            slots += 1
+    return close
+
+
 def audit(path, prefix="_Z11k_gp_sweep4", min_loops=8, owned=256):
     with open(path) as f:
         text = f.read()
@@ -92,6 +131,9 @@ def audit(path, prefix="_Z11k_gp_sweep4", min_loops=8, owned=256):
             problems.append("%s: %d v_readlane / v_writelane in one MFMA stream" % (name, lane_worst))
         if mfma == 0:
             problems.append("%s: no MFMA found" % name)
+        late = mfma_sources_written_too_late(body)
+        if late:
+            problems.append("%s: MFMA source written right in front of it: %s" % (name, late[:2]))
     if not report:
         problems.append("no %s kernel found in %s" % (prefix, path))
     return report, problems
