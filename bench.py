@@ -337,8 +337,24 @@ def run_rank(args, rank, world, local_rank, backend):
         per_rank_all = gathered.reshape(world, -1).cpu().tolist()
         elapsed = max(r[0] for r in per_rank_all)
         observed_world = dist.get_world_size()
+        # what every rank actually ran: its kernel, its device, its share of the grid
+        mine = {"rank": rank, "kernel": obj._ctx.last_kernel(), "cells": int(cells_per_launch),
+                "device": int(torch.cuda.current_device()), "range": [int(obj._lo), int(obj._hi)]}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
     else:
         per_rank_all, observed_world = [per_rank], 1
+        ranks_info = [{"rank": 0, "kernel": obj._ctx.last_kernel(), "cells": int(cells_per_launch),
+                       "device": int(torch.cuda.current_device()), "range": [int(obj._lo), int(obj._hi)]}]
+    # --gpus N has to be what ran: N ranks, the grid cut into N shards, the same kernel on each
+    if observed_world != world or (args.gpus and world != args.gpus and os.environ.get("WORLD_SIZE")):
+        raise SystemExit("bench.py: --gpus %d but %d rank(s) in the process group (WORLD_SIZE=%s)"
+                         % (args.gpus, observed_world, os.environ.get("WORLD_SIZE")))
+    if sum(r["cells"] for r in ranks_info) != obj.discretization.nindex:
+        raise SystemExit("bench.py: the ranks' shards hold %d cells, the grid has %d"
+                         % (sum(r["cells"] for r in ranks_info), obj.discretization.nindex))
+    if len({r["kernel"].split("<")[0] for r in ranks_info if r["cells"] > 0}) > 1:
+        raise SystemExit("bench.py: the ranks ran different kernels: %r" % [r["kernel"] for r in ranks_info])
 
     # ---- everything below is outside the timed region --------------------------------------
     if kind == "lyapunov":
@@ -425,7 +441,10 @@ def run_rank(args, rank, world, local_rank, backend):
                             "collective_ms": max(r[2] for r in per_rank_all),
                             "per_rank_collective_ms": [r[2] for r in per_rank_all],
                             "per_rank_ms_per_step": [r[3] for r in per_rank_all],
-                            "per_rank_kernel_ms": [r[1] for r in per_rank_all]}, **extra),
+                            "per_rank_kernel_ms": [r[1] for r in per_rank_all],
+                            "per_rank_cells": [r["cells"] for r in ranks_info],
+                            "per_rank_kernel": [r["kernel"].split("(")[0].strip() for r in ranks_info],
+                            "per_rank_device": [r["device"] for r in ranks_info]}, **extra),
         }
         if end_to_end_ms is not None:
             out["end_to_end_ms"] = end_to_end_ms      # incl. bits->bytes and the bool[N] D2H
@@ -434,12 +453,16 @@ def run_rank(args, rank, world, local_rank, backend):
             fin = float(np.mean(finalize_ms)) * len(finalize_ms) / max(args.steps, 1)   # per step
             out["roofline"]["finalize_ms"] = fin
             out["roofline"]["step_kernels_ms"] = avg_ms + fin
-            if out["roofline"]["bound"] == "hbm":
+            if "bytes_per_check" in out["roofline"]:       # (GB/s of the whole step, analytic dynamics)
                 out["roofline"]["step_achieved"] = (out["roofline"]["bytes_per_check"] * cells_per_launch
                                                     / ((avg_ms + fin) * 1e-3) / 1e9)
                 out["roofline"]["step_frac"] = out["roofline"]["step_achieved"] / HBM_PEAK_GBPS
                 out["roofline"]["values_implicit"] = bool(getattr(obj, "_values_implicit", False))
         out["roofline"]["kernel"] = obj._ctx.last_kernel()    # what the library launched (sl_last_kernel)
+        if out["roofline"]["kernel"].startswith("k_gp_small") and out["roofline"]["bound"] == "mfma":
+            # <= 256 training points: as many FP64 exponentials as GEMM flops per cell - the vector
+            # ALU's issue slots are the roof (profiles/pmc_valu.json), the matrix-pipe share stays beside it
+            out["roofline"] = valu_roof(args, out["roofline"])
         # a build whose code audit failed compiles the 4x4x4 kernels out with only a warning
         # (safe_learning_amd/_build.py): the headline lines must not silently run on the fallbacks
         expected = {"C4": "k_gp_sweep4", "C3": "k_gp_sweep4", "C5": "k_bellman4"}.get(args.config)
@@ -501,10 +524,10 @@ def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
                 if pmc.get("source_sha256") == pmc_traffic.kernel_source_sha():
                     traffic, source = pmc["bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 " \
                         "FETCH_SIZE x2 + WRITE_SIZE of this command on this version of sl_gp4.hip, " \
-                        "separate passes, tools/profile_r04.sh; not this run)"
+                        "separate passes, tools/profile_r05.sh; not this run)"
                 else:
                     source = "profiles/pmc_traffic.json was measured on another version of sl_gp4.hip: " \
-                        "re-run tools/profile_r04.sh"
+                        "re-run tools/profile_r05.sh"
         except (OSError, ValueError, KeyError):
             pass
         return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -516,13 +539,48 @@ def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
     # generated from the index); the kernel moves 8 B + 2 bits
     bytes_per_check = 10.0
     achieved = bytes_per_check * cells_per_launch / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": None,
-            "kernel_ms": avg_ms, "bytes_per_check": bytes_per_check,
-            "note": "the bit-exactness contract (one rounding per multiply and per add, no FMA) keeps the "
-                    "FP64-VALU floor above the byte floor: ~95 operations per cart-pole cell with linear "
-                    "dynamics (k_det_rows shares the row prefixes of the ordered sums; ~165 per cell when "
-                    "every cell starts from scratch, ~600 with the Euler dynamics) against 10 bytes"}
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": None,
+           "kernel_ms": avg_ms, "bytes_per_check": bytes_per_check,
+           "note": "the bit-exactness contract (one rounding per multiply and per add, no FMA) keeps the "
+                   "FP64-VALU floor above the byte floor: ~95 operations per cart-pole cell with linear "
+                   "dynamics (k_det_rows shares the row prefixes of the ordered sums; ~165 per cell when "
+                   "every cell starts from scratch, ~600 with the Euler dynamics) against 10 bytes"}
+    return valu_roof(args, out)
+
+
+def valu_roof(args, out):
+    """The deterministic sweeps and k_gp_small are bound by vector-ALU ISSUE, not by bytes or the
+    matrix pipe: report that roof - the measured issue utilisation of the dominant kernel, from the
+    PMC passes of this command (profiles/pmc_valu.json, tools/pmc_valu.py; tied to the kernel
+    sources by a sha256, a stale entry is not reported) - and keep the byte / matrix-pipe figure
+    as `<bound>_frac` beside it."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_valu.json")) as f:
+            entry = json.load(f).get(args.config)
+    except (OSError, ValueError):
+        entry = None
+    if not entry or args.num_points or args.n_gp:
+        return out
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_valu
+    if entry.get("source_sha256") != pmc_valu.sources_sha(entry["kernel"]):
+        out["valu_note"] = "profiles/pmc_valu.json[%s] was measured on other kernel sources: re-run " \
+                           "tools/profile_r05.sh" % args.config
+        return out
+    old_bound = out["bound"]
+    out[old_bound + "_achieved"], out[old_bound + "_frac"] = out["achieved"], out["frac"]
+    out[old_bound + "_peak"], out[old_bound + "_unit"] = out["peak"], out["unit"]
+    out.update(bound="valu", achieved=entry["valu_issue_utilisation"], peak=1.0, frac=entry["valu_issue_utilisation"],
+               unit="share of the SIMDs' cycles issuing a vector-ALU instruction "
+                    "(SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024))",
+               valu_kernel=entry["kernel"],
+               valu_source="profiles/pmc_valu.json (rocprofv3 counter passes of this command on these kernel "
+                           "sources, tools/profile_r05.sh; not this run)")
+    for key in ("fp64_share_of_valu_instructions", "mfma_busy", "waves_waiting"):
+        if key in entry:
+            out[key] = entry[key]
+    return out
 
 
 # ---------------------------------------------------------------------------------------------

@@ -493,23 +493,32 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
     uint64_t best_v = ~0ull;
     int64_t best_i = INT64_MAX;
     int staged_head = -1;
-    // Seeds of the Gaussian sequences, [chunk][wavefront][lane][e_0, rho_0] per workgroup: a panel
-    // of 256 rows walks over every chunk of the panels before it again (40 chunk generations per
-    // tile for 16 different chunks at n = 1024).  The first generation of a chunk keeps
+    // Seeds of the Gaussian sequences, [run][chunk][wavefront][lane][e_0, rho_0] per workgroup: a
+    // panel of 256 rows walks over every chunk of the panels before it again (40 chunk generations
+    // per tile for 16 different chunks at n = 1024).  The first generation of a chunk keeps
     // (e_0, rho_0) - the two exponentials and the distance sums, two thirds of its instructions -
-    // in this L2-resident scratch and the later ones only run the recurrence from them: the same
-    // lane reads back its own 16 bytes, the products are the same products, the k_x values
-    // bit for bit the same.  (Measured: 0.5 % of the sweep, profiles/r04_summary.md section 2.)
-    double* seed_w = seeds ? seeds + (((size_t)blockIdx.x * seed_chunks) * W + wave) * 128 + 2 * lane : nullptr;
-    // (tiles with kinks: the seeds of the runs 1 .. RUNS - 1 in further copies of that array)
-    const size_t seed_run = (size_t)gridDim.x * seed_chunks * W * 128;
+    // in this scratch and the later ones only run the recurrence from them: the same lane reads
+    // back its own 16 bytes, the products are the same products, the k_x values bit for bit the
+    // same.  (Measured: 0.5 % of the sweep, profiles/r04_summary.md section 2.)  Tiles with kinks
+    // keep one pair per run.  Round 5: the workgroup's slice is a buffer resource and a seed pair
+    // is addressed by a scalar offset (chunk, run, wavefront) + 16 lane: no 64-bit pointer per lane
+    // to carry through (or spill around) the MFMA streams; the same for the training inputs and
+    // alpha' below.
+    const bool use_seeds = seeds != nullptr;
+    const int seed_run_bytes = seed_chunks * W * 1024;          // one run's seeds of this workgroup
+    __amdgpu_buffer_rsrc_t rs_seed = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(seeds + (size_t)blockIdx.x * RUNS * seed_chunks * W * 128), 0, 0x7fffffff, 0x27000);
+    const int seed_wave = wave * 1024;
 
     // Tiles are drawn from a counter: a tile whose cells cross a saturation kink of the policy
     // generates its k_x chunks at twice the cost (a fifth of the headline workload's tiles), and
     // with a fixed tile list per workgroup the unlucky workgroups finish last (measured: 2 % of
     // the sweep, profiles/r04_gp4_tickets_ab.txt).
-    for (;;) {
-        if (tid == 0) *next_tile = (int64_t)atomicAdd(ticket, 1ull);
+    // (Few tiles per workgroup - small grids, C2's 1024 tiles on 512 workgroups: the counter hands
+    // one workgroup three tiles and another one, and the sweep lasts as long as the three; a fixed
+    // round-robin list is the better balance there: ticket == nullptr.)
+    for (int64_t round = 0;; ++round) {
+        if (tid == 0) *next_tile = ticket ? (int64_t)atomicAdd(ticket, 1ull) : (int64_t)blockIdx.x + round * gridDim.x;
         __syncthreads();
         const int64_t tile = *next_tile;       // rewritten after the barriers of the tile
         if (tile >= ntiles) break;
@@ -524,9 +533,12 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
             const SlGpHeadDev& hd = gp.head[h];
             const int n_pad = hd.n_pad, dout = hd.dout;
             const double variance = hd.variance;
-            const double* __restrict__ xs_glob = hd.xs;
             __amdgpu_buffer_rsrc_t rsrc =
                 __builtin_amdgcn_make_buffer_rsrc((void*)hd.mpack, 0, 0x7fffffff, 0x27000);
+            __amdgpu_buffer_rsrc_t rs_xs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)hd.xs, 0, 0x7fffffff, 0x27000);
+            __amdgpu_buffer_rsrc_t rs_alpha =
+                __builtin_amdgcn_make_buffer_rsrc((void*)hd.alpha, 0, 0x7fffffff, 0x27000);
             if (staged_head != h) {
                 __syncthreads();
                 if (!XSG)
@@ -541,6 +553,9 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                 double xg[SL_P], u[SL_M];
                 int64_t gidx = tile_base + 16 * wave + lcol;
                 gidx = gidx < hi ? gidx : hi - 1;
+                // (opaque: the decode of the index stays here - hoisted out of the loop over the
+                // heads its results were spilled to scratch at every tile)
+                asm volatile("" : "+v"(gidx));
                 sl_cell_state(M, d, gidx, points, xg);
                 sl_policy_any<false>(M, nd, aux.tri, gidx, xg, u);
                 sl_append_action(nd, u, xg);
@@ -647,12 +662,16 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                 auto load_xv = [&]() {
 #pragma unroll
                     for (int q = 0; q < SL_P; ++q)
-                        if (q < p) xv[q] = XSG ? xs_glob[q * n_pad + j] : xs_l[q * n_pad + j];
+                        if (q < p)
+                            xv[q] = XSG ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                              rs_xs, lane * 8, (q * n_pad + 64 * ch) * 8, 0))
+                                        : xs_l[q * n_pad + j];
                 };
                 if (runs == 1u) {                  // one affine run: e_{c+1} = e_c rho_c, rho_{c+1} = rho_c Q
                     double e, rho;
-                    if (seed_w && ch < first_new) {
-                        const sl_d2 sd = *reinterpret_cast<const sl_d2*>(seed_w + (size_t)ch * (W * 128));
+                    if (use_seeds && ch < first_new) {
+                        const sl_d2 sd = __builtin_bit_cast(sl_d2, __builtin_amdgcn_raw_buffer_load_b128(
+                            rs_seed, lane * 16, ch * (W * 1024) + seed_wave, 0));
                         e = sd.x;
                         rho = sd.y;
                     } else {
@@ -668,11 +687,12 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                         }
                         exp_pair(-0.5 * z, fmin(bj - 0.5 * a2, 700.0), e, rho);
                         e = variance * e;
-                        if (seed_w && keep) {
+                        if (use_seeds && keep) {
                             sl_d2 sd;
                             sd.x = e;
                             sd.y = rho;
-                            *reinterpret_cast<sl_d2*>(seed_w + (size_t)ch * (W * 128)) = sd;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sl_u4, sd), rs_seed, lane * 16,
+                                                                   ch * (W * 1024) + seed_wave, 0);
                         }
                     }
                     // slot (c + wswz) & 15 with wswz 0 or 4: two bases, immediate offsets
@@ -685,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                         rho *= qstep;
                     }
                 } else if (!direct) {              // a few runs: the recurrence restarts at each
-                    const bool reuse = seed_w && ch < first_new;
+                    const bool reuse = use_seeds && ch < first_new;
                     if (!reuse) load_xv();
                     unsigned m = runs;
                     for (int r = 0; m; ++r) {
@@ -694,11 +714,12 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                         const int c1 = m ? __builtin_ctz(m) : 16;
                         const double* at = cin + (16 * wave + c0) * SL_P;
                         const double* rc = runc + (wave * RUNS + r) * RUNC;
-                        // run r of a chunk: its seeds sit `seed_run` doubles behind those of run r - 1
-                        double* sp = seed_w ? seed_w + (size_t)ch * (W * 128) + (size_t)r * seed_run : nullptr;
+                        // run r of a chunk: its seeds sit one run's seeds behind those of run r - 1
+                        const int sp = r * seed_run_bytes + ch * (W * 1024) + seed_wave;
                         double e, rho;
                         if (reuse) {
-                            const sl_d2 sd = *reinterpret_cast<const sl_d2*>(sp);
+                            const sl_d2 sd = __builtin_bit_cast(sl_d2, __builtin_amdgcn_raw_buffer_load_b128(
+                                rs_seed, lane * 16, sp, 0));
                             e = sd.x;
                             rho = sd.y;
                         } else {
@@ -713,11 +734,12 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                             }
                             exp_pair(-0.5 * z, fmin(bj - 0.5 * rc[SL_P], 700.0), e, rho);
                             e = variance * e;
-                            if (seed_w && keep) {
+                            if (use_seeds && keep) {
                                 sl_d2 sd;
                                 sd.x = e;
                                 sd.y = rho;
-                                *reinterpret_cast<sl_d2*>(sp) = sd;
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sl_u4, sd), rs_seed,
+                                                                       lane * 16, sp, 0);
                             }
                         }
                         const double qr = rc[SL_P + 1];
@@ -799,8 +821,20 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                 if (with_mean) {
                     // two call sites: the LDS copy of alpha' is read with ds_read (a common
                     // pointer would make every access a flat load that waits on both counters)
-                    if (alpha_doubles > 0) mean_fetch(ch, alpha_l, 4, mi);
-                    else mean_fetch(ch, hd.alpha, dout, mi);
+                    if (alpha_doubles > 0) {
+                        mean_fetch(ch, alpha_l, 4, mi);
+                    } else {
+                        // alpha' from L2 through the head's buffer resource: one lane offset, the
+                        // row of the slab in the scalar operand
+                        const int voff = (lk * dout + (low < dout ? low : 0)) * 8;
+#pragma unroll
+                        for (int s2 = 0; s2 < 8; ++s2) {
+                            mi.a0[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                rs_alpha, voff, (64 * ch + 8 * s2) * dout * 8, 0));
+                            mi.a1[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                rs_alpha, voff, (64 * ch + 8 * s2 + 4) * dout * 8, 0));
+                        }
+                    }
                 }
                 if (!(skip & 1)) generate(ch, buf, first_new, keep);
                 if (with_mean) {
@@ -1023,7 +1057,10 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
     const char* env_seeds = getenv("SL_GP4_SEEDS");           // 0: every generation from scratch
     double* seeds = (env_seeds && atoi(env_seeds) == 0) ? nullptr : ctx->d_gp4_seeds + head_bytes / sizeof(double);
     unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ctx->d_gp4_seeds);
-    SL_HIP_CHECK(ctx, hipMemsetAsync(ticket, 0, head_bytes, ctx->stream));
+    const char* env_ticket = getenv("SL_GP4_TICKETS");          // 0 / 1 force the list / the counter
+    const bool counter = env_ticket ? atoi(env_ticket) != 0 : ntiles >= 4 * blocks;
+    if (counter) SL_HIP_CHECK(ctx, hipMemsetAsync(ticket, 0, head_bytes, ctx->stream));
+    else ticket = nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(gp4::W * 64), lds, ctx->stream, model,
                        ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,
                        ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, d_points, skip, seeds,

@@ -94,6 +94,8 @@ class Lyapunov(object):
         self._lipschitz_lyapunov = lipschitz_lyapunov
         self.adaptive = adaptive
         self._refinement_host = None
+        self._pending = None
+        self._safe_count = 0
         self.c_max = 0.
         self.feed_dict = _CMaxView(self)
         self.initial_safe_set = initial_set
@@ -220,6 +222,42 @@ class Lyapunov(object):
             self._d_values                   # (from the snapshot of update_values(), see there)
             self._values_implicit = False
         self._lyapunov_function = fun
+
+    @property
+    def c_max(self):
+        """Level of the safe set, ``values[order[max_index]]`` (``lyapunov.py:590-595``).
+
+        One process, ``can_shrink=True``: ``update_safe_set`` returns as soon as its kernels are
+        enqueued - the mask is complete on the device, and the one number the HOST needs from the
+        64-byte result record is fetched here, on the first read (a sweep of C2's 65 536 cells is
+        0.3 ms: a synchronous copy and the host code behind it were a fifth of the step)."""
+        self._resolve_pending()
+        return self._c_max
+
+    @c_max.setter
+    def c_max(self, value):
+        self._pending = None
+        self._c_max = value
+
+    @property
+    def safe_count(self):
+        """Cells of the safe set (all ranks) without a copy of the mask."""
+        self._resolve_pending()
+        return self._safe_count
+
+    @safe_count.setter
+    def safe_count(self, value):
+        self._safe_count = value
+
+    def _resolve_pending(self):
+        pending, self._pending = getattr(self, '_pending', None), None
+        if pending is None:
+            return
+        folded, n, batch = pending
+        stats = {}
+        self._upload_model()           # (the no-failure quirk runs select passes over the keys)
+        self._c_max = prefix_rule_finish(_HipShardEngine(self), folded, n, batch, True, stats)
+        self._safe_count = stats['safe']
 
     @property
     def initial_safe_set(self):
@@ -393,6 +431,7 @@ class Lyapunov(object):
         hands the discretization object to the dynamics); this is what its docstring describes,
         evaluated by the same sweep kernel as ``update_safe_set``."""
         import torch
+        self._resolve_pending()              # (the sweep below reuses the result record)
         own_policy = self.policy
         self.policy = policy
         try:
@@ -423,7 +462,10 @@ class Lyapunov(object):
             return
         chunk = np.ascontiguousarray(host_mask[self._lo:self._hi]).view(np.uint8)
         self.mask_uploads += 1
-        d_bytes = torch.from_numpy(chunk).to(self._ctx.torch_device)
+        import warnings
+        with warnings.catch_warnings():          # (a read-only mask is only read here)
+            warnings.simplefilter("ignore", UserWarning)
+            d_bytes = torch.from_numpy(chunk).to(self._ctx.torch_device)
         self._ctx.bytes_to_bits(count, d_bytes, d_bits)
 
     def _refresh_init_bits(self):
@@ -495,10 +537,15 @@ class Lyapunov(object):
         if not can_shrink:                                       # lyapunov.py:507-510
             self._sync_safe_to_device()
         engine = _HipShardEngine(self)
-        stats = {}
-        self.c_max = prefix_rule(engine, self.discretization.nindex, int(config.gp_batch_size),
-                                 can_shrink, stats)
-        self.safe_count = stats['safe']       # cells in the safe set (all ranks), no mask copy
+        stats, deferred = {}, ([] if (can_shrink and not self._collective) else None)
+        self._pending = None                  # (an unread c_max of the previous update is history)
+        n, batch = self.discretization.nindex, int(config.gp_batch_size)
+        c_max = prefix_rule(engine, n, batch, can_shrink, stats, defer=deferred)
+        if deferred:
+            self._pending = (deferred[0], n, batch)    # c_max / safe_count: read on demand
+        else:
+            self.c_max = c_max
+            self.safe_count = stats['safe']   # cells in the safe set (all ranks), no mask copy
         self._safe_host_valid = False
         self._safe_dev_valid = True
         self._safe_host_digest = None
@@ -520,6 +567,7 @@ class Lyapunov(object):
         batch of the reference's loop judged in parallel, rows exchanged between the owner of a cell
         and the owner of its sorted position with two all-to-alls; no rank holds anything of grid
         size but its own shard."""
+        self._resolve_pending()
         self._upload_model()
         self._refresh_init_bits()
         if not can_shrink:                                       # lyapunov.py:507-510
@@ -579,6 +627,8 @@ class _HipShardEngine(object):
         """``count`` gathered records (device) -> one: lexmin / lexmax of the keys, sums of the
         counters (``sl_fold_results``)."""
         ly = self.lyap
+        if count == 1:              # one shard: the fold of one record is that record (no launch)
+            return records
         ly._ctx.fold_results(records, count, ly._d_folded)
         return ly._d_folded
 
@@ -592,13 +642,14 @@ class _HipShardEngine(object):
             start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record()
         keep = None if keep_state is None else keep_state[_hip.S_KEY_V:_hip.S_KEY_V + 2]
+        # (the record the pass reads and the one it writes are two buffers)
+        out = ly._d_folded if folded.data_ptr() == ly._d_result.data_ptr() else ly._d_result
         ly._ctx.lyap_finalize_dev(ly._lo, ly._hi, ly._values_arg(), ly._d_init,
-                                  self.prior if use_prior else None, folded, keep, ly._d_safe,
-                                  ly._d_result)
+                                  self.prior if use_prior else None, folded, keep, ly._d_safe, out)
         if events is not None:
             stop.record()
             events.append((start, stop))
-        return ly._d_result
+        return out
 
     def select_begin(self, k, batch, folded, n):
         ly = self.lyap
@@ -632,7 +683,7 @@ def _host_words(tensor):
     return [int(v) for v in tensor.detach().cpu().numpy().reshape(-1)]
 
 
-def prefix_rule(engine, n, batch, can_shrink, stats=None):
+def prefix_rule(engine, n, batch, can_shrink, stats=None, defer=None):
     """The safe-set rule of ``lyapunov.py:512-606`` over sharded cells; returns ``c_max``.
 
     ``engine`` owns one contiguous shard (the HIP engine in production, a NumPy stand-in in the
@@ -640,9 +691,22 @@ def prefix_rule(engine, n, batch, can_shrink, stats=None):
     all-gather of the 64-byte records -> fold (device) -> streaming pass that reads ``key*`` from
     the folded record -> all-gather -> fold -> ONE 64-byte copy to the host.  ``can_shrink=False``
     or the no-failure ``c_max`` quirk add a device-resident radix select (sixteen 2 KiB SUM
-    all-reduces) and one more copy."""
+    all-reduces) and one more copy.
+
+    ``defer`` (a list; one process, ``can_shrink=True``): the device part only - the folded record is
+    appended and ``None`` returned; :func:`prefix_rule_finish` reads it when somebody asks for
+    ``c_max`` (the safe set itself is complete on the device: nothing of it is decided on the host)."""
     folded = engine.fold(*dist_utils.gather_records(engine.sweep(can_shrink)))
     folded = engine.fold(*dist_utils.gather_records(engine.finalize(folded, None, use_prior=False)))
+    if defer is not None and can_shrink:
+        defer.append(folded)
+        return None
+    return prefix_rule_finish(engine, folded, n, batch, can_shrink, stats)
+
+
+def prefix_rule_finish(engine, folded, n, batch, can_shrink, stats=None):
+    """The host's part of :func:`prefix_rule`: one 64-byte record -> ``c_max`` (and, for
+    ``can_shrink=False`` after a failure, the pass that keeps the later batches' previous state)."""
     row = _host_words(folded)
     star = (dist_utils.u64(row[_hip.R_FAIL_V]), row[_hip.R_FAIL_I])
     below = row[_hip.R_BELOW]

@@ -52,7 +52,7 @@ def test_reference_faithful_leg_small():
 
 def test_traffic_measurement_belongs_to_the_shipped_kernel():
     """roofline.traffic is read from profiles/pmc_traffic.json (separate rocprofv3 counter passes,
-    tools/profile_r04.sh): the file records the sha256 of sl_gp4.hip it was measured on, and a kernel
+    tools/profile_r05.sh): the file records the sha256 of sl_gp4.hip it was measured on, and a kernel
     edit without a new measurement fails here (bench.py then reports traffic = null)."""
     import json
     sys.path.insert(0, os.path.join(ROOT, "tools"))

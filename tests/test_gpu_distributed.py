@@ -28,14 +28,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, results, backend="gloo"):
+def _worker(rank, world, port, results, backend="gloo", device_per_rank=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if world == 1:
         os.environ["SL_FORCE_COLLECTIVES"] = "1"
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(rank % torch.cuda.device_count() if device_per_rank else 0)
     dist.init_process_group(backend, rank=rank, world_size=world)
     import safe_learning_amd as sl
     from safe_learning_amd.benchmarks import build_lyapunov
@@ -218,13 +218,52 @@ def test_rccl_collectives_world_one():
     assert results[0] == [], results[0]
 
 
-def _abi_comm_worker(rank, world, results):
+def test_rccl_one_gpu_per_rank():
+    """The whole scenario list over RCCL with ONE GPU PER RANK - prefix rule, adaptive rule with its
+    all-to-alls, the value-iteration all-gather, get_safe_sample.  Skipped on a one-GPU box; the
+    driver's 8-GPU node runs it with min(8, devices) ranks, the first time RCCL moves a byte between
+    two devices for this package."""
+    devices = torch.cuda.device_count()
+    if devices < 2:
+        pytest.skip("needs at least two GPUs (found %d)" % devices)
+    world = min(devices, 8)
+    port = _free_port()
+    results = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(world, port, results, "nccl", True), nprocs=world, join=True)
+    for rank in range(world):
+        assert results[rank] == [], (rank, results[rank])
+
+
+def test_c_abi_rccl_collectives_one_gpu_per_rank():
+    """sl_comm_init & co. between devices: the unique id of rank 0 handed to the others (the host
+    application's job: here a manager dict)."""
+    devices = torch.cuda.device_count()
+    if devices < 2:
+        pytest.skip("needs at least two GPUs (found %d)" % devices)
+    world = min(devices, 8)
+    manager = mp.get_context("spawn").Manager()
+    results, shared = manager.dict(), manager.dict()
+    mp.spawn(_abi_comm_worker, args=(world, results, shared), nprocs=world, join=True)
+    for rank in range(world):
+        assert results[rank] is True, rank
+
+
+def _abi_comm_worker(rank, world, results, shared=None):
     """The RCCL entry points of the C ABI (no torch.distributed): communicator of `world` ranks."""
+    import time
     sys.path.insert(0, ROOT)
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(rank % torch.cuda.device_count() if world > 1 else 0)
     from safe_learning_amd import _hip
     ctx = _hip.Context()
-    uid = _hip.Context.comm_unique_id()
+    if world == 1:
+        uid = _hip.Context.comm_unique_id()
+    elif rank == 0:
+        uid = _hip.Context.comm_unique_id()
+        shared["uid"] = bytes(uid)
+    else:
+        while "uid" not in shared:
+            time.sleep(0.05)
+        uid = shared["uid"]
     assert len(uid) == 128
     ctx.comm_init(uid, rank, world)
     dev = ctx.torch_device
@@ -239,10 +278,11 @@ def _abi_comm_worker(rank, world, results):
     full = torch.empty(1000 * world, dtype=torch.float64, device=dev)
     ctx.allgather(shard, full, shard.numel() * 8)
     ctx.synchronize()
-    ok = (rec.cpu().tolist() == [5, 7, 3, 2, 9, 11, 4, 6]
+    # (identical records on every rank: the keys fold to themselves, the two counters add up)
+    ok = (rec.cpu().tolist() == [5, 7, 3, 2, 9, 11, 4 * world, 6 * world]
           and torch.equal(hist.cpu(), torch.arange(256, dtype=torch.int64) * world)
           and res.cpu().tolist() == [0.25, 3.5]
-          and torch.equal(full.cpu()[:1000], shard.cpu()))
+          and torch.equal(full.cpu(), shard.cpu().repeat(world)))
     # errors: a second communicator on the same context, collectives after destroy
     try:
         ctx.comm_init(uid, rank, world)

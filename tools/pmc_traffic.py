@@ -47,7 +47,7 @@ def main():
            "note": "L2<->fabric bytes per launch of the GP sweep kernel: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                    "(KiB units, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes): L2 misses "
                    "of the inverse Cholesky factor's fragments served by the Infinity Cache (an upper bound "
-                   "of the HBM reads) + mask words and set-up scratch; profiles/r04_summary.md."}
+                   "of the HBM reads) + mask words and set-up scratch; profiles/README.md."}
     with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(out)
