@@ -385,6 +385,14 @@ SL_API int  sl_state_membership(sl_ctx* ctx, int64_t count, const double* d_poin
  * counting as largest (np.argmax, lyapunov.py:783, 789), -1 if there is none; d_out[1] = rows seen. */
 SL_API int  sl_argmax_masked(sl_ctx* ctx, int64_t count, const double* d_values, const uint8_t* d_mask,
                       int64_t* d_out);
+/* discrete_policy_optimization with a safety constraint (reinforcement_learning.py:266-278): d_best[i]
+ * = np.argmax_a of d_q[i][a] with the actions that are not allowed at vertex i counted as -inf (first
+ * maximiser wins, NaN largest, nothing allowed -> 0).  d_allowed_bits[a * words_per_action + (i >> 6)]
+ * bit (i & 63): action a may be taken at vertex i - e.g. the `negative` words of one sl_lyap_sweep
+ * per action with that action as the policy (NULL: no constraint).  The [count, A] table of action
+ * values stays on the device. */
+SL_API int  sl_argmax_rows_masked(sl_ctx* ctx, int64_t count, int n_actions, const double* d_q,
+                           const uint64_t* d_allowed_bits, int64_t words_per_action, int32_t* d_best);
 
 /* get_lyapunov_region (lyapunov.py:59-139): the region around the node `start` (flat index on the
  * model's grid) that the reference's priority-queue flood of the function values visits before it

@@ -115,7 +115,7 @@ EXPORTS = [
     "sl_sort_pairs", "sl_partition_by_digit", "sl_gather_rows", "sl_adaptive_pack", "sl_adaptive_dest",
     "sl_adaptive_sort_keys", "sl_adaptive_analyse", "sl_adaptive_apply", "sl_adaptive_scatter",
     "sl_index_to_state", "sl_perturb_pairs", "sl_rows_sort_key", "sl_rows_duplicate_flags",
-    "sl_sample_bounds", "sl_state_membership", "sl_argmax_masked", "sl_lyapunov_region",
+    "sl_sample_bounds", "sl_state_membership", "sl_argmax_masked", "sl_argmax_rows_masked", "sl_lyapunov_region",
     "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_eval_points",
     "sl_comm_unique_id", "sl_comm_init", "sl_comm_destroy", "sl_allreduce_result", "sl_allgather",
     "sl_allreduce_sum_u64", "sl_allreduce_max_f64",
@@ -193,6 +193,7 @@ def load_library():
     lib.sl_sample_bounds.argtypes = [vp, i64, C.c_int, C.c_int, vp, vp, vp, C.c_double, vp, vp]
     lib.sl_state_membership.argtypes = [vp, i64, vp, vp, vp]
     lib.sl_argmax_masked.argtypes = [vp, i64, vp, vp, vp]
+    lib.sl_argmax_rows_masked.argtypes = [vp, i64, C.c_int, vp, vp, i64, vp]
     lib.sl_lyapunov_region.argtypes = [vp, vp, i64, vp, vp, C.POINTER(C.c_int)]
     lib.sl_bits_to_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sl_bytes_to_bits.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -475,6 +476,11 @@ class Context(object):
     def argmax_masked(self, count, d_values, d_mask, d_out):
         self.check(self.lib.sl_argmax_masked(self.handle, count, _ptr(d_values), _ptr(d_mask),
                                              _ptr(d_out)), "sl_argmax_masked")
+
+    def argmax_rows_masked(self, count, n_actions, d_q, d_allowed_bits, words_per_action, d_best):
+        self.check(self.lib.sl_argmax_rows_masked(self.handle, count, n_actions, _ptr(d_q),
+                                                  _ptr(d_allowed_bits), words_per_action, _ptr(d_best)),
+                   "sl_argmax_rows_masked")
 
     def lyapunov_region(self, d_values, start, d_work, d_region):
         """-> relaxation passes used (``sl_lyapunov_region``)."""

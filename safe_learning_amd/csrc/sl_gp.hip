@@ -670,6 +670,19 @@ int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
     if (other_kernels && sl_gp_small_supports(ctx, model))
         return sl_gp_small_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
                                   d_dbg, d_points);
+    // 193 .. 256 training points per head (capacity exactly one 256-row panel of k_gp_sweep4): the
+    // factor no longer fits LDS, k_gp_small waits for its fragments from L2 (2.0 ms at 256 points on
+    // 1024^2 cells, 0.6 ms at 128) while k_gp_sweep4 prefetches them two slab pairs ahead - fast-path
+    // models with RBF heads take it on ONE panel (SL_GP4_ONE_PANEL=0: keep k_gp_small).
+    if (ctx->gp_cfg == 0 && !other_kernels && sl_gp4_supports(model)) {
+        bool one_panel = true;
+        for (int h = 0; h < ctx->h_gp.nheads; ++h) one_panel = one_panel && ctx->gp_heads[h].n_pad == 256;
+        const char* env = getenv("SL_GP4_ONE_PANEL");
+        if (env && env[0] == '0') one_panel = false;
+        if (one_panel)
+            return sl_gp4_sweep_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
+                                       d_dbg, d_points);
+    }
     // small training sets (one head, capacity <= 256 points): a wavefront per 64-cell tile
     if (ctx->gp_cfg == 0 && sl_gp_small_supports(ctx, model))
         return sl_gp_small_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,

@@ -243,6 +243,43 @@ extern "C" int sl_state_membership(sl_ctx* ctx, int64_t count, const double* d_p
     return SL_OK;
 }
 
+// best[i] = np.argmax over the actions of q[i][:] with the actions that are not allowed at vertex i
+// set to -inf (reinforcement_learning.py:266-278): the first index wins, a NaN counts as largest,
+// all actions ruled out -> index 0.  allowed[a] is a bit mask over the vertices (bit i of word i >> 6).
+__global__ __launch_bounds__(SL_BLOCK) void k_argmax_rows_masked(int64_t count, int n_actions,
+                                                                 const double* __restrict__ q,
+                                                                 const uint64_t* __restrict__ allowed,
+                                                                 int64_t words, int32_t* __restrict__ best) {
+    const double NEG_INF = -__builtin_inf();
+    for (int64_t i = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * SL_BLOCK) {
+        double top = 0.0;
+        int at = -1;
+        for (int a = 0; a < n_actions; ++a) {
+            double v = q[i * n_actions + a];
+            if (allowed && !((allowed[(int64_t)a * words + (i >> 6)] >> (i & 63)) & 1ull)) v = NEG_INF;
+            const bool vn = v != v, tn = top != top;
+            if (at < 0 || (vn && !tn) || (!vn && !tn && v > top)) { top = v; at = a; }
+        }
+        best[i] = at < 0 ? 0 : at;
+    }
+}
+
+extern "C" int sl_argmax_rows_masked(sl_ctx* ctx, int64_t count, int n_actions, const double* d_q,
+                                     const uint64_t* d_allowed_bits, int64_t words_per_action,
+                                     int32_t* d_best) {
+    if (!ctx || count < 0 || n_actions < 1 || !d_best || (count && !d_q) ||
+        (d_allowed_bits && words_per_action * 64 < count))
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_argmax_rows_masked: bad argument");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (count) {
+        hipLaunchKernelGGL(k_argmax_rows_masked, dim3(sl_grid_blocks(count)), dim3(SL_BLOCK), 0, ctx->stream,
+                           count, n_actions, d_q, d_allowed_bits, words_per_action, d_best);
+        SL_HIP_CHECK(ctx, hipGetLastError());
+    }
+    return SL_OK;
+}
+
 extern "C" int sl_argmax_masked(sl_ctx* ctx, int64_t count, const double* d_values, const uint8_t* d_mask,
                                 int64_t* d_out) {
     if (!ctx || count < 0 || !d_out || (count && !d_values))

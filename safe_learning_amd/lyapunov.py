@@ -424,12 +424,11 @@ class Lyapunov(object):
         """``lyapunov.py:290-303``."""
         return self.safe_set[self.discretization.state_to_index(state)]
 
-    def safety_constraint(self, policy, include_initial=True):
-        """``bool[nindex]``: where the decrease condition holds under ``policy`` - a per-vertex
-        action array ``[nindex, m]`` or a policy spec (``lyapunov.py:378-406``).  The reference
-        method cannot run as written (it compares with the bound method ``self.threshold`` and
-        hands the discretization object to the dynamics); this is what its docstring describes,
-        evaluated by the same sweep kernel as ``update_safe_set``."""
+    def decrease_bits(self, policy, include_initial=True):
+        """Device bit words (int64, this rank's shard) of the cells where the decrease condition
+        holds under ``policy`` - a per-vertex action array ``[nindex, m]`` or a policy spec - OR-ed
+        with the initial safe set if asked for.  One sweep of the engine's kernel; the object's own
+        policy, safe set and ``c_max`` are left alone."""
         import torch
         self._resolve_pending()              # (the sweep below reuses the result record)
         own_policy = self.policy
@@ -443,15 +442,27 @@ class Lyapunov(object):
         finally:
             self.policy = own_policy
             self._upload_model()
+        if include_initial and self._initial_safe_set is not None:
+            d_neg |= self._d_init
+        return d_neg
+
+    def safety_constraint(self, policy, include_initial=True):
+        """``bool[nindex]``: where the decrease condition holds under ``policy`` - a per-vertex
+        action array ``[nindex, m]`` or a policy spec (``lyapunov.py:378-406``).  The reference
+        method cannot run as written (it compares with the bound method ``self.threshold`` and
+        hands the discretization object to the dynamics); this is what its docstring describes,
+        evaluated by the same sweep kernel as ``update_safe_set``.
+
+        ``PolicyIteration.discrete_policy_optimization(actions, constraint=lyapunov)`` uses the
+        device form (:meth:`decrease_bits`, one sweep per action) and never builds this array."""
+        import torch
+        d_neg = self.decrease_bits(policy, include_initial)
         count = self._hi - self._lo
         d_bytes = torch.empty(max(-(-count // 8) * 8, 8), dtype=torch.uint8,
                               device=self._ctx.torch_device)
         self._ctx.bits_to_bytes(count, d_neg, d_bytes)
         sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
-        mask = dist_utils.allgather_concat(d_bytes[:count], sizes).cpu().numpy().astype(bool)
-        if include_initial and self._initial_safe_set is not None:
-            mask[self._initial_safe_set] = True
-        return mask
+        return dist_utils.allgather_concat(d_bytes[:count], sizes).cpu().numpy().astype(bool)
 
     # ---- device helpers ------------------------------------------------------------------
     def _upload_mask(self, host_mask, d_bits):
@@ -651,16 +662,37 @@ class _HipShardEngine(object):
             events.append((start, stop))
         return out
 
-    def select_begin(self, k, batch, folded, n):
+    def _many(self, slot):
+        """State / histogram rows of select number ``slot`` of a multi-k select (one block each, so
+        that the histograms of all k are ONE tensor for the all-reduce)."""
+        import torch
         ly = self.lyap
-        ly._ctx.select_begin(ly._d_select, k, batch, folded, n)
-        return ly._d_select
+        have = getattr(self, '_many_states', None)
+        if have is None or have.shape[0] <= slot:
+            rows = max(8, 2 * (slot + 1))
+            states = torch.zeros((rows, _hip.SELECT_WORDS), dtype=torch.int64, device=ly._ctx.torch_device)
+            hists = torch.zeros((rows, 256), dtype=torch.int64, device=ly._ctx.torch_device)
+            if have is not None:
+                states[:have.shape[0]] = have
+            self._many_states, self._many_hists = states, hists
+        return self._many_states[slot], self._many_hists[slot]
 
-    def select_hist(self, which, byte, state):
+    def select_begin(self, k, batch, folded, n, slot=None):
+        ly = self.lyap
+        state = ly._d_select if slot is None else self._many(slot)[0]
+        ly._ctx.select_begin(state, k, batch, folded, n)
+        return state
+
+    def select_hist(self, which, byte, state, slot=None):
         """Local 256-bin histogram of one radix-select pass (int64[256], device)."""
         ly = self.lyap
-        ly._ctx.select_hist(ly._lo, ly._hi, ly._values_arg(), which, byte, state, ly._d_hist)
-        return ly._d_hist
+        hist = ly._d_hist if slot is None else self._many(slot)[1]
+        ly._ctx.select_hist(ly._lo, ly._hi, ly._values_arg(), which, byte, state, hist)
+        return hist
+
+    def stack_hists(self, hists):
+        """The histograms of a multi-k pass as one tensor (they are rows of one block)."""
+        return self._many_hists[:len(hists)]
 
     def select_digit(self, which, byte, hist, state):
         self.lyap._ctx.select_digit(which, byte, hist, state)
@@ -677,6 +709,23 @@ def select_kth(engine, k, batch, folded, n):
             hist = dist_utils.allreduce_sum_(engine.select_hist(which, byte, state))
             engine.select_digit(which, byte, hist, state)
     return state
+
+
+def select_kth_many(engine, ks, batch, folded, n):
+    """:func:`select_kth` for several ranks ``ks`` at once -> list of select states.  The sixteen
+    passes of all selects run in lockstep and the histograms of one pass travel in ONE all-reduce
+    (``len(ks)`` x 2 KiB): sixteen collectives for the ``world - 1`` splitters of the adaptive
+    branch instead of sixteen per splitter (112 serialized all-reduces at world 8)."""
+    states = [engine.select_begin(k, batch, folded, n, slot=r) for r, k in enumerate(ks)]
+    if not states:
+        return states
+    for which in (0, 1):
+        for byte in range(7, -1, -1):
+            hists = [engine.select_hist(which, byte, state, slot=r) for r, state in enumerate(states)]
+            block = dist_utils.allreduce_sum_(engine.stack_hists(hists))
+            for r, state in enumerate(states):
+                engine.select_digit(which, byte, block[r], state)
+    return states
 
 
 def _host_words(tensor):
@@ -781,8 +830,9 @@ class _HipAdaptiveEngine(object):
         ly = self.lyap
         shard = _HipShardEngine(ly)
         states = self._empty(max(len(positions), 1), _hip.SELECT_WORDS)
-        for r, k in enumerate(positions):
-            states[r].copy_(select_kth(shard, k, 1, ly._d_folded, n))
+        # one multi-k select: its states are rows of one block
+        for r, state in enumerate(select_kth_many(shard, list(positions), 1, ly._d_folded, n)):
+            states[r].copy_(state)
         return states[:len(positions)]
 
     def partition(self, rows, splitters):

@@ -218,6 +218,24 @@ class PolicyIteration(object):
                                                          return_values)
         want_q = return_values or constraint is not None
         _, argmax, q, _ = self._sweep(self.policy, action_space, want_q=want_q)
+        from .lyapunov import Lyapunov
+        if isinstance(constraint, Lyapunov):
+            # The constraint is the Lyapunov decrease condition itself (what the reference's
+            # Lyapunov.safety_constraint describes, lyapunov.py:378-406): an action is ruled out at a
+            # vertex where the condition fails under it (and the vertex is not in the initial safe
+            # set).  One decrease sweep per action writes a bit mask, the arg-max over the rows of the
+            # action-value table with those masks runs in a kernel: neither the [N, A] table nor the
+            # masks leave the device (sl_argmax_rows_masked).
+            if not _same_grid(constraint.discretization, self.discretization):
+                raise ValueError('the Lyapunov constraint lives on another grid than the value function')
+            count = self._hi - self._lo
+            allowed = torch.stack([constraint.decrease_bits(ConstantFunction(action))
+                                   for action in action_space]).contiguous()
+            argmax = torch.empty_like(argmax)
+            # (both contexts enqueue on torch's current stream: the masks are complete when read)
+            self._ctx.argmax_rows_masked(count, n_act, q, allowed, allowed.shape[1], argmax)
+            self._adopt_greedy_policy(action_space, argmax)
+            return self._gather(q, n_act).reshape(-1, n_act) if return_values else None
         q_all = None
         if want_q:
             q_all = self._gather(q, n_act).reshape(-1, n_act)

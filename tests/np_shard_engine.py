@@ -86,7 +86,7 @@ class NumpyShardEngine(object):
         out[7] = int(self.safe.sum())
         return out
 
-    def select_begin(self, k, batch, folded, n):
+    def select_begin(self, k, batch, folded, n, slot=None):
         """sl_select_begin: [prefix, remaining, key.vbits, key.index, rank, none, 0, 0]."""
         rank = k if k >= 0 else (int(folded[6]) // batch + 1) * batch
         none = int(rank < 0 or rank >= n)
@@ -94,7 +94,7 @@ class NumpyShardEngine(object):
         words[1], words[3], words[4], words[5] = rank, KEY_NONE[1], rank, none
         return torch.from_numpy(words.copy())
 
-    def select_hist(self, which, byte, state):
+    def select_hist(self, which, byte, state, slot=None):
         words = state.numpy()
         if words[5]:
             return torch.zeros(256, dtype=torch.int64)
@@ -108,6 +108,9 @@ class NumpyShardEngine(object):
             take &= (key & himask) == (prefix & himask)
         digits = ((key[take] >> shift) & np.uint64(0xFF)).astype(np.int64)
         return torch.from_numpy(np.bincount(digits, minlength=256).astype(np.int64))
+
+    def stack_hists(self, hists):
+        return torch.stack(hists)
 
     def select_digit(self, which, byte, hist, state):
         """sl_select_digit on the all-reduced histogram (in place on ``state``)."""
@@ -153,8 +156,8 @@ class NumpyAdaptiveEngine(object):
         return torch.from_numpy(rows)
 
     def splitters(self, positions, n):
-        from safe_learning_amd.lyapunov import select_kth
-        states = [select_kth(self.shard, k, 1, None, n).clone() for k in positions]
+        from safe_learning_amd.lyapunov import select_kth_many
+        states = [state.clone() for state in select_kth_many(self.shard, list(positions), 1, None, n)]
         return torch.stack(states) if states else torch.zeros((0, 8), dtype=torch.int64)
 
     def partition(self, rows, splitters):

@@ -1096,3 +1096,31 @@ def test_gp4_sequence_seeds_are_bit_identical(sl, monkeypatch):
         states = np.stack(np.meshgrid(*[np.linspace(-1, 1, k) for k in case["num_points"]], indexing="ij"), -1)
         u = states.reshape(-1, case["d"]) @ np.asarray(case["K"]).T
         assert (np.abs(u) > 1).any() and (np.abs(u) < 1).any()
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("pendulum", dict(num_points=48, n_gp=200, tau_scale=0.01)),
+    ("pendulum", dict(num_points=[40, 64], n_gp=256, tau_scale=0.01)),
+    ("cartpole", dict(num_points=[5, 6, 5, 32], n_gp=230, tau_scale=0.0)),
+    ("cartpole", dict(num_points=7, n_gp=200, tau_scale=0.0, stack=True)),
+])
+def test_one_panel_training_sets_run_on_the_4x4x4_kernel(sl, name, kw, monkeypatch):
+    """193 ... 256 training points per head = exactly one 256-row panel: k_gp_sweep4 (whose factor
+    fragments are prefetched from L2) instead of k_gp_small (whose factor no longer fits LDS) - the
+    same records as the oracle's and, bit for bit in the masks, as k_gp_small's."""
+    from gp_cases import INFORMED, TIGHT
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = cases.make_case(name, **dict(kw, **(TIGHT if name == "cartpole" else INFORMED)))
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    _, neg, rec = _engine_records(lyap)
+    assert lyap._ctx.last_kernel().startswith("k_gp_sweep4<"), lyap._ctx.last_kernel()
+    ref_rec, ref_neg = _oracle_all(olyap)
+    assert_allclose(rec[:, 2:], ref_rec[:, 2:], rtol=1e-7, atol=1e-12)
+    assert_allclose(rec[:, :2], ref_rec[:, :2], rtol=1e-7, atol=1e-12)
+    flips, _ = _check_masks(neg, ref_neg, rec, ref_rec)
+    _compare_safe_sets(lyap, olyap, flips, neg)
+    monkeypatch.setenv("SL_GP4_ONE_PANEL", "0")
+    _, neg_small, rec_small = _engine_records(lyap)
+    assert lyap._ctx.last_kernel().startswith("k_gp_small<"), lyap._ctx.last_kernel()
+    assert_allclose(rec, rec_small, rtol=1e-9, atol=1e-13)
+    _check_masks(neg, neg_small, rec, rec_small, allowed=0)

@@ -630,3 +630,72 @@ def test_policy_evaluation_ragged_rows_on_4x4x4(sl, name, kw, nv, na, monkeypatc
         v_part, _, _, _ = rl._sweep(np.ascontiguousarray(table), None)
         assert "k_bellman4_policy" in rl._ctx.last_kernel()
         assert_array_equal(v_part[:hi - lo].cpu().numpy(), results["1"][0][lo:hi, 0])
+
+
+@pytest.mark.parametrize("name,kw,nv,na", [
+    # (oracle side: 26 % / 29 % / 12 % / 16 % of the (vertex, action) pairs are allowed, 45 % ... 72 %
+    # of the vertices allow nothing, the greedy policy changes at 76 % ... 87 % of the vertices)
+    ("pendulum", dict(n_gp=70, tau_scale=0.0, gp="informed"), [21, 24], 7),
+    ("pendulum", dict(dynamics="analytic", tau_scale=0.0), 19, 5),
+    ("cartpole", dict(n_gp=90, tau_scale=0.0, gp="tight"), [4, 4, 3, 16], 9),
+    ("cartpole", dict(dynamics="analytic", tau_scale=0.0), [5, 4, 5, 8], 9),
+])
+def test_discrete_policy_optimization_with_a_lyapunov_constraint(sl, name, kw, nv, na):
+    """``discrete_policy_optimization(actions, constraint=lyapunov)``: an action is ruled out at a
+    vertex where the Lyapunov decrease condition fails under it (``reinforcement_learning.py:266-278``
+    with the slack of ``Lyapunov.safety_constraint``, ``lyapunov.py:378-406``).  Engine: one decrease
+    sweep per action into bit masks + a masked arg-max kernel, nothing of size [N, A] leaves the
+    device.  Oracle: the reference's loop with the slack as a Python callback."""
+    from gp_cases import INFORMED, TIGHT
+    from safe_learning_amd.benchmarks import build_lyapunov
+    kw = dict(kw)
+    kw.update({"informed": INFORMED, "tight": TIGHT, None: {}}[kw.pop("gp", None)])
+    case = cases.make_case(name, num_points=nv, **kw)
+    rl, orl, vf, ovf = _rl_pair(sl, case, nv)
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    actions = np.linspace(-1, 1, na)[:, None]
+    grid, ogrid = vf.discretization, ovf.discretization
+    rl.policy = sl.Triangulation(grid, np.zeros((grid.nindex, 1)))
+    orl.policy = oracle.Triangulation(ogrid, np.zeros((ogrid.nindex, 1)))
+    x = orl.state_space
+    init = np.zeros(len(x), dtype=bool)
+    init[cases.initial_safe_mask(case)] = True
+
+    near = np.zeros(len(x), dtype=bool)      # vertices where rounding may decide the condition
+
+    def slack(action_array):
+        own = olyap.policy
+        olyap.policy = lambda states: np.asarray(action_array)[:len(states)]
+        try:
+            decrease, threshold = olyap._decrease_and_threshold(x)
+        finally:
+            olyap.policy = own
+        scale = np.maximum(np.abs(decrease), np.abs(threshold))
+        near[:] |= (np.abs(decrease - threshold) <= 1e-9 * np.maximum(scale, 1e-300))[:, 0] & ~init
+        holds = np.less(decrease, threshold)[:, 0] | init
+        return np.where(holds, 1.0, -1.0)
+
+    q = rl.discrete_policy_optimization(actions, constraint=lyap, return_values=True)
+    oq, obest = orl.discrete_policy_optimization(actions, constraint=slack)
+    assert np.isinf(oq).any() and not np.isinf(oq).all(), "the constraint must rule something out"
+    ok_q = np.ones_like(oq, dtype=bool)
+    for a, action in enumerate(actions):
+        nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))
+        nxt = nxt[0] if isinstance(nxt, tuple) else nxt
+        ok_q[:, a] = ~ambiguous_points(ovf, nxt)
+    got_q = q.cpu().numpy()                           # (unconstrained action values, as in the oracle's table where finite)
+    finite = np.isfinite(oq)
+    assert_allclose(got_q[ok_q & finite], oq[ok_q & finite], rtol=1e-9, atol=1e-12)
+    best = rl.policy._host_parameters()[:, 0]
+    obest_val = orl.policy.parameters[:, 0]
+    masked = np.where(finite, oq, -np.inf)
+    top2 = np.sort(masked, axis=1)[:, -2:]
+    with np.errstate(invalid="ignore"):
+        tie = np.abs(top2[:, 1] - top2[:, 0]) <= 1e-9 * np.abs(top2[:, 1])
+    tie |= ~np.isfinite(top2[:, 1])                   # nothing allowed: index 0 on both sides anyway
+    differs = best != obest_val
+    assert near.mean() < 0.01
+    assert not np.any(differs & ok_q.all(axis=1) & ~tie & ~near)
+    # the constraint changed the greedy policy somewhere
+    rl.discrete_policy_optimization(actions)
+    assert (rl.policy._host_parameters()[:, 0] != best).any()
