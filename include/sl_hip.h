@@ -279,6 +279,15 @@ SL_API int  sl_lyap_finalize_dev(sl_ctx* ctx, int64_t lo, int64_t hi, const doub
                           const sl_sweep_result* d_folded, const sl_key* d_keep,
                           uint64_t* d_safe_bits, sl_sweep_result* d_result);
 
+/* The refinement array N(x) of lyapunov.py:220-225 through a NON-adaptive update with
+ * can_shrink = False (lyapunov.py:507-510, 531, 585-587, 601-606), in place on this range's cells:
+ *   ref_i <- init_i ? 1 : key_i < key* ? (negative_i ? 1 : ref_i) : (key_i >= key_keep ? ref_i : 0)
+ * with key* = d_folded->fail, key_keep = *d_keep (NULL: no failure, nothing is cleared), d_neg_bits the
+ * sweep's `negative` words.  Only needed when an adaptive update left values other than 0 / 1. */
+SL_API int  sl_refinement_carry(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values,
+                         const uint64_t* d_init_bits, const uint64_t* d_neg_bits,
+                         const sl_sweep_result* d_folded, const sl_key* d_keep, int64_t* d_refinement);
+
 /* Radix select of the k-th smallest (V, index) key over all ranks (0-based; what
  * values[order[k]] of lyapunov.py:512, 590-595 reads) with its state in device memory. */
 typedef struct sl_select_state {

@@ -110,7 +110,7 @@ EXPORTS = [
     "sl_last_kernel",
     "sl_model_set", "sl_gp_set_head", "sl_gp_set_head_kernel", "sl_gp_append_point", "sl_gp_configure", "sl_tri_set", "sl_tri_set_table",
     "sl_network_set", "sl_values", "sl_lyap_sweep", "sl_lyap_finalize", "sl_select_pass",
-    "sl_values_implicit", "sl_fold_results", "sl_lyap_finalize_dev", "sl_select_begin",
+    "sl_values_implicit", "sl_fold_results", "sl_lyap_finalize_dev", "sl_refinement_carry", "sl_select_begin",
     "sl_select_hist", "sl_select_digit",
     "sl_sort_pairs", "sl_partition_by_digit", "sl_gather_rows", "sl_adaptive_pack", "sl_adaptive_dest",
     "sl_adaptive_sort_keys", "sl_adaptive_analyse", "sl_adaptive_apply", "sl_adaptive_scatter",
@@ -172,6 +172,8 @@ def load_library():
     lib.sl_fold_results.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.sl_lyap_finalize_dev.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sl_refinement_carry.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sl_select_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
     lib.sl_select_hist.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]
@@ -385,6 +387,11 @@ class Context(object):
                                                  _ptr(d_init_bits), _ptr(d_prev_bits), _ptr(d_folded),
                                                  _ptr(d_keep), _ptr(d_safe_bits), _ptr(d_result)),
                    "sl_lyap_finalize_dev")
+
+    def refinement_carry(self, lo, hi, d_values, d_init_bits, d_neg_bits, d_folded, d_keep, d_refinement):
+        self.check(self.lib.sl_refinement_carry(self.handle, lo, hi, _ptr(d_values), _ptr(d_init_bits),
+                                                _ptr(d_neg_bits), _ptr(d_folded), _ptr(d_keep),
+                                                _ptr(d_refinement)), "sl_refinement_carry")
 
     def select_begin(self, d_state, k, batch, d_folded, n_total):
         self.check(self.lib.sl_select_begin(self.handle, _ptr(d_state), k, batch, _ptr(d_folded),

@@ -142,6 +142,45 @@ __global__ __launch_bounds__(SL_BLOCK) void k_reduce_finalize_dev(
     }
 }
 
+// Refinement N(x) after a NON-adaptive update that must not shrink (lyapunov.py:507-510, 531,
+// 585-587, 601-606): the loop writes 1 where the decrease condition holds, 0 from the first failure
+// to the end of its batch, and leaves every other cell what an earlier ADAPTIVE update made it -
+//   ref_i <- init_i ? 1 : key_i < key* ? (negative_i ? 1 : ref_i) : (key_i >= key_keep ? ref_i : 0).
+template <int DT>
+__global__ __launch_bounds__(SL_BLOCK) void k_refinement_carry(
+    const SlDevModel M_arg, int64_t lo, int64_t hi, const double* __restrict__ values,
+    const uint8_t* __restrict__ init_bytes, const uint8_t* __restrict__ neg_bytes,
+    const sl_sweep_result* __restrict__ folded, const sl_key* __restrict__ keep_ptr,
+    int64_t* __restrict__ refinement) {
+    SlDevModel M = M_arg;
+    constants_to_vgprs<DT>(M);
+    const sl_key star = folded->fail;
+    sl_key keep;
+    keep.vbits = ~0ull; keep.index = INT64_MAX;
+    if (keep_ptr) keep = *keep_ptr;
+    SlRowValues<DT> row;
+    const int64_t span = (int64_t)SL_BLOCK * CPT;
+    for (int64_t base = lo + (int64_t)blockIdx.x * span; base < hi; base += (int64_t)gridDim.x * span) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * CPT;
+        if (i0 >= hi) continue;
+        const unsigned init8 = init_bytes ? init_bytes[(i0 - lo) >> 3] : 0u;
+        const unsigned neg8 = neg_bytes[(i0 - lo) >> 3];
+        double v8[CPT];
+        row.eight(M, values, lo, hi, i0, v8);
+        for (int c = 0; c < CPT; ++c) {
+            const int64_t idx = i0 + c;
+            if (idx >= hi) break;
+            const uint64_t vb = sl_vbits_fast(v8[c]);
+            const bool below = sl_key_less(vb, idx, star.vbits, star.index);
+            const bool later = !sl_key_less(vb, idx, keep.vbits, keep.index);
+            const int64_t old = refinement[idx - lo];
+            int64_t now = below ? (((neg8 >> c) & 1u) ? 1 : old) : (later ? old : 0);
+            if ((init8 >> c) & 1u) now = 1;
+            refinement[idx - lo] = now;
+        }
+    }
+}
+
 // records[count] -> out: the reductions of lyapunov.py:512-606 over the shards
 __global__ void k_fold_records(const sl_sweep_result* __restrict__ records, int count,
                                sl_sweep_result* __restrict__ out) {
@@ -328,6 +367,37 @@ extern "C" int sl_lyap_finalize_dev(sl_ctx* ctx, int64_t lo, int64_t hi, const d
     }
     hipLaunchKernelGGL(k_reduce_finalize_dev, dim3(1), dim3(SL_BLOCK), 0, ctx->stream,
                        ctx->d_partials, ctx->d_partial_counts, blocks, d_folded, d_result);
+    SL_HIP_CHECK(ctx, hipGetLastError());
+    return SL_OK;
+}
+
+extern "C" int sl_refinement_carry(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_values,
+                                  const uint64_t* d_init_bits, const uint64_t* d_neg_bits,
+                                  const sl_sweep_result* d_folded, const sl_key* d_keep,
+                                  int64_t* d_refinement) {
+    if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_refinement_carry: NULL context");
+    if (lo < 0 || hi < lo || ((lo & 63) && hi != lo) || !d_folded || !d_neg_bits || !d_refinement)
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_refinement_carry: bad argument");
+    int dt = 0;
+    int rc = dim_variant(ctx, d_values, "sl_refinement_carry", &dt);
+    if (rc) return rc;
+    if (hi == lo) return SL_OK;
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const int blocks = blocks_for(ctx, hi - lo);
+    const uint8_t* init_bytes = reinterpret_cast<const uint8_t*>(d_init_bits);
+    const uint8_t* neg_bytes = reinterpret_cast<const uint8_t*>(d_neg_bits);
+#define SL_CARRY(D_)                                                                                \
+    hipLaunchKernelGGL(k_refinement_carry<D_>, dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream,        \
+                       ctx->h_model, lo, hi, d_values, init_bytes, neg_bytes, d_folded, d_keep,     \
+                       d_refinement)
+    switch (dt) {
+        case 1: SL_CARRY(1); break;
+        case 2: SL_CARRY(2); break;
+        case 3: SL_CARRY(3); break;
+        case 4: SL_CARRY(4); break;
+        default: SL_CARRY(0); break;
+    }
+#undef SL_CARRY
     SL_HIP_CHECK(ctx, hipGetLastError());
     return SL_OK;
 }

@@ -541,6 +541,11 @@ class Lyapunov(object):
         one GPU sweep, the sequential refinement bookkeeping runs on the host like the reference's."""
         if self.adaptive and max_refinement > 1:
             return self._update_safe_set_adaptive(can_shrink, max_refinement, safety_factor)
+        # N(x) of an earlier ADAPTIVE update survives a non-adaptive one that must not shrink
+        # (lyapunov.py:507-510): carried on the device below; otherwise N(x) is 1 on the safe set
+        carry = None if can_shrink else self._refinement_shard()
+        if carry is not None:
+            carry = carry.clone()
         self._refinement_host = None
         self._refinement_dev = None
         self._upload_model()
@@ -557,6 +562,12 @@ class Lyapunov(object):
         else:
             self.c_max = c_max
             self.safe_count = stats['safe']   # cells in the safe set (all ranks), no mask copy
+        if carry is not None:
+            keep = stats.get('keep')
+            self._ctx.refinement_carry(self._lo, self._hi, self._values_arg(), self._d_init, self._d_neg,
+                                       stats['folded'],
+                                       None if keep is None else keep[_hip.S_KEY_V:_hip.S_KEY_V + 2], carry)
+            self._refinement_dev = carry
         self._safe_host_valid = False
         self._safe_dev_valid = True
         self._safe_host_digest = None
@@ -764,6 +775,7 @@ def prefix_rule_finish(engine, folded, n, batch, can_shrink, stats=None):
     safe = row[_hip.R_SAFE]
     failed = star != _KEY_NONE
 
+    keep = None
     if failed and not can_shrink:
         # cells after the batch that contains the first failure keep their previous state
         # (lyapunov.py:585-587 never touches later batches): key_keep = the key at sorted position
@@ -775,6 +787,7 @@ def prefix_rule_finish(engine, folded, n, batch, can_shrink, stats=None):
     if stats is not None:
         stats['safe'] = safe
         stats['below'] = below
+        stats['folded'], stats['keep'] = folded, keep      # (device: key* and key_keep of the update)
 
     # c_max = values[order[max_index]], max_index as in lyapunov.py:590
     if failed:

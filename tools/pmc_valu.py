@@ -21,6 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # sources whose change invalidates an entry, per kernel family
 SOURCES = {"k_det": ["sl_det_rows.hip", "sl_kernels.hip", "sl_model.h", "sl_common.h"],
+           "k_bellman": ["sl_bellman4.hip", "sl_bellman.hip", "sl_model.h", "sl_common.h"],
            "k_gp_small": ["sl_gp_small.hip", "sl_model.h", "sl_common.h"],
            "k_finalize": ["sl_level.hip", "sl_model.h", "sl_common.h"]}
 

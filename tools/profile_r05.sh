@@ -38,14 +38,20 @@ rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_a $OUT/pmc_b $OUT/pmc_e
 fi
 if [[ " $parts " == *" valu "* ]]; then
 # 4. the kernels whose roof is vector-ALU issue: utilisation + FP64 share -> profiles/pmc_valu.json
-for spec in "C4-lin k_det_rows" "C4-det k_det_sweep" "C2-table-det k_det" "C2-table k_gp_small" "C2-table-large k_gp_small" "C2-table-stack k_gp_small" "C2-notebook k_gp_small"; do
-  set -- $spec; cfg=$1; sub=$2
+# (key of the entry, bench.py configuration, kernel-name substring; C5-lookup: is k_bellman_lookup bound
+# by vector-ALU issue - then fusing it behind the GEMM cannot overlap the two, both use the FP64 pipe -
+# or by the latency of its gathers?)
+for spec in "C4-lin C4-lin k_det_rows" "C4-det C4-det k_det_sweep" "C2-table-det C2-table-det k_det" "C2-table C2-table k_gp_small" \
+            "C2-table-large C2-table-large k_gp_small" "C2-table-stack C2-table-stack k_gp_small" "C2-notebook C2-notebook k_gp_small" \
+            "C5-lookup C5 k_bellman_lookup"; do
+  set -- $spec; key=$1; cfg=$2; sub=$3
+  extra=""; [ $cfg = C5 ] && extra="--max-sweeps 12"
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES \
-      -d $OUT/v_$cfg -o p -- python bench.py --config $cfg --steps 6 --warmup 2 --no-cpu-baseline > $OUT/v_$cfg.log 2>&1
+      -d $OUT/v_$key -o p -- python bench.py --config $cfg --steps 6 --warmup 2 --no-cpu-baseline $extra > $OUT/v_$key.log 2>&1
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 \
-      -d $OUT/w_$cfg -o q -- python bench.py --config $cfg --steps 6 --warmup 2 --no-cpu-baseline > $OUT/w_$cfg.log 2>&1
-  python tools/pmc_valu.py $cfg $sub $(db $OUT/v_$cfg) $(db $OUT/w_$cfg) > $OUT/valu_$cfg.json 2>&1
-  rm -rf $OUT/v_$cfg $OUT/w_$cfg
+      -d $OUT/w_$key -o q -- python bench.py --config $cfg --steps 6 --warmup 2 --no-cpu-baseline $extra > $OUT/w_$key.log 2>&1
+  python tools/pmc_valu.py $key $sub $(db $OUT/v_$key) $(db $OUT/w_$key) > $OUT/valu_$key.json 2>&1
+  rm -rf $OUT/v_$key $OUT/w_$key
 done
 cp profiles/pmc_valu.json $OUT/pmc_valu.json
 fi
