@@ -61,3 +61,37 @@ def test_traffic_measurement_belongs_to_the_shipped_kernel():
         pmc = json.load(handle)
     assert pmc["source_sha256"] == pmc_traffic.kernel_source_sha()
     assert pmc["bytes_per_launch"] > 2.2e9            # at least the algorithmic bytes
+
+
+def test_valu_measurements_belong_to_the_shipped_kernels():
+    """roofline.bound = "valu" (the deterministic sweeps, k_gp_small) reads the vector-ALU issue
+    utilisation from profiles/pmc_valu.json (rocprofv3 counter passes, tools/profile_r05.sh +
+    tools/pmc_valu.py).  Every entry records the sha256 of the sources of its kernel family: an edit
+    without a new measurement fails here (bench.py then falls back to the byte / matrix-pipe figure
+    and says why)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_valu
+    with open(os.path.join(ROOT, "profiles", "pmc_valu.json")) as handle:
+        table = json.load(handle)
+    assert {"C4-lin", "C4-det", "C2-table-large"} <= set(table)
+    for key, entry in table.items():
+        assert entry["source_sha256"] == pmc_valu.sources_sha(entry["kernel"]), key
+        assert 0.0 < entry["valu_issue_utilisation"] <= 1.0, key
+
+
+def test_valu_roof_replaces_the_byte_roof_only_with_a_matching_measurement(tmp_path, monkeypatch):
+    import json
+    import bench
+    args = bench.parse_args(["--config", "C4-lin"])
+    base = {"bound": "hbm", "achieved": 2400.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.3, "traffic": None,
+            "bytes_per_check": 10.0}
+    out = bench.valu_roof(args, dict(base))
+    assert out["bound"] == "valu" and out["hbm_frac"] == 0.3 and 0 < out["frac"] <= 1
+    # another shape than the measured one, or a stale entry: the byte roof stays
+    assert bench.valu_roof(bench.parse_args(["--config", "C4-lin", "--num-points", "64"]), dict(base))["bound"] == "hbm"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_valu
+    monkeypatch.setattr(pmc_valu, "sources_sha", lambda kernel: "other")
+    stale = bench.valu_roof(args, dict(base))
+    assert stale["bound"] == "hbm" and "valu_note" in stale
