@@ -367,7 +367,11 @@ def run_rank(args, rank, world, local_rank, backend):
             dyn = case["dynamics"]
             extra["gp_hyper"] = {"signal_std": float(np.sqrt(dyn["variance"])),
                                  "noise_std": float(np.sqrt(dyn["noise_variance"])),
-                                 "lengthscale": float(np.ravel(dyn["lengthscales"])[0])}
+                                 "lengthscale": float(np.ravel(dyn["lengthscales"])[0]),
+                                 "variant": args.gp_variant or "informed",
+                                 "note": "default = the 'informed' set (not SURVEY 8d's literal 0.05 / 0.01 / 0.5 "
+                                         "with the full tau, under which one cell of 2.7e8 passes): same cost per "
+                                         "cell, a mask that is not vacuous; --gp-variant survey runs the literal set"}
         # cells that pass the decrease check (popcount of the mask words of all ranks)
         neg = obj._d_neg[:(cells_per_launch + 63) // 64]
         cnt = torch.tensor([int(_popcount(neg))], dtype=torch.int64, device="cuda")

@@ -1,7 +1,10 @@
 #!/bin/bash
 # Round-5 profiles of the shipped kernels (run on the GPU box through gpurun; the summaries land in
 # gpurun_out/r05_prof and are copied into profiles/ by hand).  Counters in their own passes, never
-# together with a trace (gpurun refuses the combination).
+# together with a trace (gpurun refuses the combination).  EVERY rocprofv3 runs under `timeout`: an
+# unsupported counter combination makes rocprofv3 abort inside the application and then hang in its
+# own signal handler (round 5, call 6: 49 GPU-minutes lost to the TCC_EA0_RDREQ_* pass below, which is
+# therefore gone - the memory-side counters that exist are listed in profiles/r05_rocprofv3_memory_counters.txt).
 #   tools/profile_r05.sh [headline] [valu] [c5]        (default: all three parts)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
@@ -12,29 +15,21 @@ B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 db() { find $1 -name "*_results.db" | head -1; }
 if [[ " $parts " == *" headline "* ]]; then
 # 1. kernel trace + stats of the default bench command (C4)
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1
+timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $B > $OUT/trace.log 2>&1
 python tools/kernel_stats.py $(db $OUT/trace) > $OUT/r05_kernel_stats.md 2>&1
 # 2. fabric traffic of the headline launch (128^4): FETCH_SIZE and WRITE_SIZE in separate passes
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+timeout -k 5 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+timeout -k 5 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 python tools/pmc_traffic.py $(db $OUT/pmc_fetch) $(db $OUT/pmc_write) > $OUT/pmc_traffic.log 2>&1
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 python tools/pmc_dump.py k_gp_sweep $(find $OUT/pmc_fetch $OUT/pmc_write -name "*_results.db") > $OUT/r05_pmc_128.txt 2>&1
-# 2b. what the L2's memory-side interface can tell apart (64^4): request sizes, "DRAM" destination (this
-#     rocprofv3 has no Infinity-Cache / memory-controller counter: gpurun_out/r05/memory_counters.txt),
-#     L2 hit rate
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum \
-    -d $OUT/pmc_ea_rd -o p -- $B --num-points 64 > $OUT/pmc_ea_rd.log 2>&1
-rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum \
-    -d $OUT/pmc_ea_wr -o p -- $B --num-points 64 > $OUT/pmc_ea_wr.log 2>&1
-python tools/pmc_dump.py k_gp_sweep $(find $OUT/pmc_ea_rd $OUT/pmc_ea_wr -name "*_results.db") > $OUT/r05_pmc_l2_64.txt 2>&1
 # 3. matrix-pipe counters at 48^4
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES \
+timeout -k 5 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES \
     -d $OUT/pmc_a -o p -- $B --num-points 48 > $OUT/pmc_a.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM \
+timeout -k 5 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM \
     -d $OUT/pmc_b -o p -- $B --num-points 48 > $OUT/pmc_b.log 2>&1
 python tools/pmc_dump.py k_gp_sweep $(find $OUT/pmc_a $OUT/pmc_b -name "*_results.db") > $OUT/r05_pmc_48.txt 2>&1
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_a $OUT/pmc_b $OUT/pmc_ea_rd $OUT/pmc_ea_wr
+rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_a $OUT/pmc_b
 fi
 if [[ " $parts " == *" valu "* ]]; then
 # 4. the kernels whose roof is vector-ALU issue: utilisation + FP64 share -> profiles/pmc_valu.json
@@ -46,9 +41,9 @@ for spec in "C4-lin C4-lin k_det_rows" "C4-det C4-det k_det_sweep" "C2-table-det
             "C5-lookup C5 k_bellman_lookup"; do
   set -- $spec; key=$1; cfg=$2; sub=$3
   extra=""; [ $cfg = C5 ] && extra="--max-sweeps 12"
-  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES \
+  timeout -k 5 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES \
       -d $OUT/v_$key -o p -- python bench.py --config $cfg --steps 6 --warmup 2 --no-cpu-baseline $extra > $OUT/v_$key.log 2>&1
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 \
+  timeout -k 5 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 \
       -d $OUT/w_$key -o q -- python bench.py --config $cfg --steps 6 --warmup 2 --no-cpu-baseline $extra > $OUT/w_$key.log 2>&1
   python tools/pmc_valu.py $key $sub $(db $OUT/v_$key) $(db $OUT/w_$key) > $OUT/valu_$key.json 2>&1
   rm -rf $OUT/v_$key $OUT/w_$key
@@ -56,9 +51,9 @@ done
 cp profiles/pmc_valu.json $OUT/pmc_valu.json
 fi
 if [[ " $parts " == *" c5 "* ]]; then
-rocprofv3 --kernel-trace --stats -d $OUT/trace_c5 -o t -- python bench.py --config C5 --steps 8 --warmup 2 --no-cpu-baseline --max-sweeps 12 > $OUT/trace_c5.log 2>&1
+timeout -k 5 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_c5 -o t -- python bench.py --config C5 --steps 8 --warmup 2 --no-cpu-baseline --max-sweeps 12 > $OUT/trace_c5.log 2>&1
 python tools/kernel_stats.py $(db $OUT/trace_c5) > $OUT/r05_C5_kernel_stats.md 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 \
+timeout -k 5 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 \
     -d $OUT/pmc_c5 -o p -- python bench.py --config C5 --steps 8 --warmup 2 --no-cpu-baseline --max-sweeps 12 > $OUT/pmc_c5.log 2>&1
 python tools/pmc_dump.py k_bellman $(db $OUT/pmc_c5) > $OUT/r05_C5_pmc.txt 2>&1
 rm -rf $OUT/trace_c5 $OUT/pmc_c5
