@@ -494,6 +494,14 @@ class Lyapunov(object):
             return
         else:
             arr = np.asarray(init)
+            if arr.nbytes > (1 << 24) and not getattr(self, '_warned_large_mask', False):
+                import warnings
+                self._warned_large_mask = True
+                warnings.warn("initial_safe_set is a writable array of %d MB: its content is hashed on every "
+                              "update_safe_set (about 0.15 ms per MB) so that in-place edits are noticed like "
+                              "in the reference; make it read-only (mask.flags.writeable = False) to have it "
+                              "identified by object identity instead" % (arr.nbytes >> 20), RuntimeWarning,
+                              stacklevel=3)
             version = (arr.shape, arr.dtype.str, _digest(arr))
             # the cached object is held strongly and compared by identity: an id() could be recycled
             if version == self._init_version and init is self._init_object:
