@@ -1102,9 +1102,18 @@ def get_safe_sample(lyapunov, perturbations=None, limits=None, positive=False,
     safe_states = kernels.states(safe_idx)
     safe_actions = None
     if perturbations is None:
-        host_states = safe_states.cpu().numpy()
-        mesh = np.meshgrid(host_states, actions, indexing='ij')
-        state_actions = torch.from_numpy(np.column_stack([m.ravel() for m in mesh])).to(safe_states.device)
+        # lyapunov.py:737-741: every safe state with every row of ``actions`` (a meshgrid of the two
+        # RAVELLED arrays, i.e. one state and one action dimension - the 1-D examples)
+        grid_actions = np.asarray(actions, dtype=np.float64)
+        if d == 1 and grid_actions.size == grid_actions.reshape(-1, 1).shape[0]:
+            # state-major pairs on the device: the pairs of perturb_actions around a zero baseline
+            # (0 + a = a exactly), without limits - no clipping, no duplicate removal
+            zero = torch.zeros((len(safe_states), 1), dtype=torch.float64, device=safe_states.device)
+            state_actions = kernels.pairs(safe_states, zero, grid_actions.reshape(-1, 1), None)
+        else:
+            host_states = safe_states.cpu().numpy()
+            mesh = np.meshgrid(host_states, actions, indexing='ij')
+            state_actions = torch.from_numpy(np.column_stack([m.ravel() for m in mesh])).to(safe_states.device)
     else:
         safe_actions = _evaluate.policy(lyapunov.policy, safe_states)
         state_actions = kernels.pairs(safe_states, safe_actions, perturbations, limits)

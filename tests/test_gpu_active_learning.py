@@ -129,3 +129,41 @@ def test_appended_inputs_are_bit_identical_to_a_fresh_upload(sl):
     assert_array_equal(xs, xs_ref)
     assert_array_equal(xs, (lyap.dynamics.X / 0.37).T)
     assert np.any(xs != (lyap.dynamics.X * (1.0 / 0.37)).T)   # the two roundings do differ
+
+
+def _one_dimensional_gp_case(n_cells=201, n_gp=25):
+    """A 1-D grid with a GP model of x+ = 1.25 x + 0.6 u and a policy that saturates at +-0.3 (the
+    shape of ``1d_example.ipynb``): the level set stops where the saturated control no longer
+    contracts - 139 of 201 cells are safe."""
+    rng = np.random.default_rng(3)
+    true = np.array([[1.25, 0.6]])
+    X = rng.uniform(-1, 1, (n_gp, 2))
+    Y = X @ true.T + rng.normal(0, 0.002, (n_gp, 1))
+    return dict(name="1d-gp", stack=False, d=1, m=1, limits=[[-1., 1.]], num_points=[n_cells],
+                K=np.array([[-0.9]]), saturate=(-0.3, 0.3), P=np.array([[1.]]),
+                lv=("abs_linear", 2 * np.array([[1.]])), lf=1.8, tau=0.2 / (n_cells - 1),
+                initial_radius=0.1,
+                dynamics={"kind": "gp", "X": X, "Y": Y, "variance": 0.02 ** 2,
+                          "lengthscales": np.full(2, 1.0), "noise_variance": 0.002 ** 2,
+                          "prior": np.array([[1.2, 0.5]]), "beta": 2.0})
+
+
+@pytest.mark.parametrize("positive", [True, False])
+def test_get_safe_sample_over_an_action_grid(sl, positive):
+    """``get_safe_sample(lyapunov, perturbations=None, actions=grid)`` (``lyapunov.py:737-741``): every
+    safe state with every action of a grid - in the engine the pairs are built on the device (the
+    safe states used to travel to the host and back for the meshgrid)."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = _one_dimensional_gp_case()
+    lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
+    lyap.update_safe_set()
+    olyap.update_safe_set()
+    assert_array_equal(lyap.safe_set, olyap.safe_set)
+    assert cases.initial_safe_mask(case).sum() + 10 < olyap.safe_set.sum() < 190
+    actions = np.linspace(-1, 1, 21)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        pair, bound = sl.get_safe_sample(lyap, None, None, positive=positive, actions=actions)
+        opair, obound = oracle.get_safe_sample(olyap, None, None, positive=positive, actions=actions)
+    assert_array_equal(pair, opair)
+    assert_allclose(bound, obound, rtol=1e-7)
