@@ -298,6 +298,8 @@ def run_rank(args, rank, world, local_rank, backend):
         cells_per_launch = obj._hi - obj._lo
     elif kind == "policy":
         obj, actions = build_policy_iteration(case)
+        if args.successor_cache == "off":
+            obj.successor_cache(0)
         for _ in range(3):
             obj.value_iteration(actions)
         obj.discrete_policy_optimization(actions)
@@ -309,6 +311,35 @@ def run_rank(args, rank, world, local_rank, backend):
         units = obj.discretization.nindex * len(actions)
         step = lambda: obj.value_iteration(actions)          # noqa: E731
         cells_per_launch = obj._hi - obj._lo
+        if args.successor_cache == "off":
+            obj.successor_cache(0)
+        else:
+            # (i) the recomputing sweep - what every sweep cost before the successor cache and what the
+            # first sweep of a loop still costs: a few sweeps with the cache switched off, HIP
+            # events around the kernels; (ii) the loop as a user runs it, from V = 0: the first
+            # sweep locates the successors and fills the cache, the timed steps below and the
+            # convergence run behind them are served from it
+            obj.successor_cache(0)
+            obj.value_iteration(actions)
+            barrier()
+            obj.sweep_events = []
+            t0 = time.perf_counter()
+            for _ in range(3):
+                obj.value_iteration(actions)
+            barrier()
+            un_ms = 1e3 * (time.perf_counter() - t0) / 3
+            un_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in obj.sweep_events]))
+            obj.sweep_events = None
+            extra["uncached_sweep"] = {"ms_per_sweep": un_ms, "kernel_ms": un_kernel_ms,
+                                       "kernel": obj._ctx.last_kernel()}
+            obj.successor_cache(-1)
+            obj.value_function.parameters = np.zeros((obj.discretization.nindex, 1))
+            barrier()
+            loop_t0 = time.perf_counter()
+            obj.value_iteration(actions)
+            barrier()
+            extra["first_sweep_ms"] = 1e3 * (time.perf_counter() - loop_t0)
+            extra["first_sweep_kernel"] = obj._ctx.last_kernel()
 
     from safe_learning_amd import distributed as dist_utils
     for _ in range(args.warmup):
@@ -386,7 +417,7 @@ def run_rank(args, rank, world, local_rank, backend):
         end_to_end_ms = 1e3 * (time.perf_counter() - t1)
         assert int(mask.sum()) == extra["safe_cells"]
         if args.config in ("C2", "C4") and extra["safe_cells"] <= extra["initial_cells"] \
-                and not os.environ.get("SL_GP4_SKIP") and args.gp_variant != "survey":
+                and not args.diagnostic and args.gp_variant != "survey":
             # (attribution runs skip phases; SURVEY 8d's literal hyper-parameters are known to
             # let one cell of 2.7e8 pass - that variant exists to show the cost is the same)
             raise SystemExit("bench.py: degenerate workload - the level set did not grow (%d safe "
@@ -401,6 +432,8 @@ def run_rank(args, rank, world, local_rank, backend):
         # sweeps to convergence at max|dV| <= 1e-6 max|V| (SURVEY 8d metric iii), continuing from
         # the table the timed sweeps left
         sweeps, rel, last, monotone = args.warmup + args.steps, float("inf"), float("inf"), True
+        if args.successor_cache != "off":
+            sweeps += 1                               # the filling sweep
         while sweeps < args.max_sweeps:
             res = obj.value_iteration(actions)
             sweeps += 1
@@ -412,6 +445,12 @@ def run_rank(args, rank, world, local_rank, backend):
                 break
         extra.update(sweeps_to_convergence=sweeps, relative_residual=rel,
                      residual_monotone=bool(monotone), converged=bool(rel <= 1e-6))
+        if args.successor_cache != "off":
+            # wall clock of the whole loop from V = 0: filling sweep + warm-up + timed steps + the rest
+            torch.cuda.synchronize()
+            extra["time_to_convergence_s"] = time.perf_counter() - loop_t0
+            extra["steady_sweep_ms"] = 1e3 * elapsed / args.steps
+            extra["successor_cache"] = obj.successor_cache_info
 
     if rank == 0:
         d = case["d"]
@@ -450,9 +489,20 @@ def run_rank(args, rank, world, local_rank, backend):
                             "per_rank_kernel": [r["kernel"].split("(")[0].strip() for r in ranks_info],
                             "per_rank_device": [r["device"] for r in ranks_info]}, **extra),
         }
+        out["config"]["env_switches"] = env_switches()
+        diag = {k: os.environ[k] for k in REFUSED_ENV if os.environ.get(k)}
+        if diag:                                   # only reachable with --diagnostic
+            out["diagnostic"] = diag
+            out["metric"] = "DIAGNOSTIC (not a benchmark result): " + out["metric"]
         if end_to_end_ms is not None:
             out["end_to_end_ms"] = end_to_end_ms      # incl. bits->bytes and the bool[N] D2H
         out["roofline"] = roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world)
+        if "uncached_sweep" in extra:              # the recomputing sweep against ITS roof (the GEMM)
+            un = extra["uncached_sweep"]
+            flops = 2.0 * len(dyn["X"]) * 9 * d
+            un["roofline"] = {"bound": "mfma", "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "achieved": flops * cells_per_launch / (un["kernel_ms"] * 1e-3) / 1e12}
+            un["roofline"]["frac"] = un["roofline"]["achieved"] / FP64_MFMA_PEAK_TFLOPS
         if finalize_ms:
             fin = float(np.mean(finalize_ms)) * len(finalize_ms) / max(args.steps, 1)   # per step
             out["roofline"]["finalize_ms"] = fin
@@ -472,6 +522,15 @@ def run_rank(args, rank, world, local_rank, backend):
         expected = {"C4": "k_gp_sweep4", "C3": "k_gp_sweep4", "C5": "k_bellman4"}.get(args.config)
         forced = any(os.environ.get(k) for k in ("SL_GP_CFG", "SL_BELLMAN4", "SL_BELLMAN_MFMA"))
         forced = forced or args.num_points or args.n_gp      # other shapes may pick other kernels
+        if args.config == "C5" and args.successor_cache != "off" and not forced:
+            # the timed steps come from the cache; the recomputing sweep in front of them must have
+            # run on the 4x4x4 kernels
+            if not (out["roofline"]["kernel"].startswith("k_bellman_cached")
+                    and extra["uncached_sweep"]["kernel"].startswith(expected)
+                    and "k_bellman_lookup" in extra["first_sweep_kernel"]):
+                raise SystemExit("bench.py: C5 ran on %r / %r / %r" % (
+                    out["roofline"]["kernel"], extra["uncached_sweep"]["kernel"], extra["first_sweep_kernel"]))
+            expected = None
         if expected and not forced and not out["roofline"]["kernel"].startswith(expected):
             raise SystemExit("bench.py: %s ran on %r instead of %s* (library built without its "
                              "4x4x4 kernels?)" % (args.config, out["roofline"]["kernel"], expected))
@@ -495,6 +554,15 @@ def _popcount(words):
 def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
     """Achieved rate of the dominant kernel against the roofline that bounds it."""
     is_gp = dyn.get("kind") == "gp"
+    if kind == "policy" and args.successor_cache != "off":
+        # the vertex's own action and the vertex itself from the successor cache: two entries of
+        # 8 d + 5 bytes, the policy value (8) and its action index (1), old and new value (16)
+        bytes_per_vertex = 2 * (8.0 * d + 5) + 25
+        achieved = bytes_per_vertex * cells_per_launch / (avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": None,
+                "kernel_ms": avg_ms, "bytes_per_vertex": bytes_per_vertex,
+                "gathered_bytes_per_vertex": 2 * (d + 1) * 8.0}
     if kind == "policy":
         n = len(dyn["X"])
         flops = 2.0 * n * d                      # the mean of the vertex's own action
@@ -505,6 +573,17 @@ def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
                 "note": "algorithmic flops = the posterior mean of each vertex's own action; the "
                         "kernel computes the means of every distinct action of a 64-cell tile for all "
                         "of its cells (one quarter-block GEMM per distinct action, DESIGN 4.4)"}
+    if kind == "bellman" and args.successor_cache != "off":
+        # sweeps served from the successor cache (sl_succ.hip) stream it: per (vertex, action) pair
+        # 8 d weights + 4 (corner) + 1 (simplex) bytes, per vertex 8 (old value) + 8 (new value) +
+        # 4 (arg-max); the (d + 1) gathered table values per pair come out of L2 / Infinity Cache
+        # (134 MB table; SURVEY 8d counts them as cache resident)
+        bytes_per_vertex = 9 * (8.0 * d + 5) + 20
+        achieved = bytes_per_vertex * cells_per_launch / (avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": None,
+                "kernel_ms": avg_ms, "bytes_per_vertex": bytes_per_vertex,
+                "gathered_bytes_per_vertex": 9 * (d + 1) * 8.0}
     if kind == "bellman":
         n = len(dyn["X"])
         flops = 2.0 * n * 9 * d                  # one FP64 GEMM [cells x n] . [n x A*D]
@@ -613,6 +692,13 @@ def parse_args(argv=None):
     ap.add_argument("--n-gp", type=int, default=None)
     ap.add_argument("--family", default="cartpole", choices=["cartpole", "pendulum"])
     ap.add_argument("--max-sweeps", type=int, default=3000, help="C5: bound of the convergence run")
+    ap.add_argument("--successor-cache", default="on", choices=["on", "off"],
+                    help="C5 / C5-policy: serve the sweeps after the first from the successor cache "
+                         "(default) or recompute every sweep (the kernels of the first sweep)")
+    ap.add_argument("--diagnostic", action="store_true",
+                    help="allow SL_LIB_PATH / SL_GP4_SKIP / SL_BM_FLAGS / SL_B4P_FLAGS (development "
+                         "builds, timing attribution): the line is tagged 'diagnostic' and its metric "
+                         "renamed - not a benchmark result")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=0,
                     help="least number of cells of the CPU baseline sample (SURVEY 8d asks for 2^24 = "
@@ -626,8 +712,27 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+# Environment variables under which a bench line is not what the shipped library does: a development
+# library (SL_LIB_PATH, tools/build_variant.sh) may skip work (SL_GP4_SKIP, SL_BM_FLAGS, SL_B4P_FLAGS -
+# the shipped library does not read them).  The A/B switches of the shipped kernels are legitimate
+# runs but not the default path: they are listed in the line (config.env_switches).
+REFUSED_ENV = ("SL_LIB_PATH", "SL_GP4_SKIP", "SL_BM_FLAGS", "SL_B4P_FLAGS")
+AB_ENV = ("SL_GP_CFG", "SL_GP_SMALL", "SL_GP_SMALL_WAVES", "SL_DET_ROWS", "SL_GP4_ONE_PANEL", "SL_GP4_SEEDS",
+          "SL_GP4_TICKETS", "SL_BELLMAN_MFMA", "SL_BELLMAN4", "SL_BELLMAN4_POLICY", "SL_BELLMAN4_POLICY_CACHE",
+          "SL_BELLMAN4_RAGGED", "SL_BELLMAN4_QUARTER", "SL_BELLMAN4_SPLIT", "SL_BELLMAN4_ROUND",
+          "SL_BELLMAN4_SHARED", "SL_SUCC_CACHE", "SL_FORCE_COLLECTIVES")
+
+
+def env_switches():
+    return {k: os.environ[k] for k in AB_ENV if os.environ.get(k)}
+
+
 def main():
     args = parse_args()
+    bad = [k for k in REFUSED_ENV if os.environ.get(k)]
+    if bad and not args.diagnostic:
+        raise SystemExit("bench.py: %s set - a development library / work-skipping switches do not "
+                         "produce benchmark lines (--diagnostic runs them, tagged as such)" % ", ".join(bad))
     import torch
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is not None:                     # launched by torchrun: this process is one rank

@@ -428,6 +428,28 @@ SL_API int  sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uin
 SL_API int  sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const double* h_actions,
                       double* d_v_new, int32_t* d_argmax, double* d_q, double* d_stats);
 
+/* Successor cache of sl_bellman_sweep.  The next state of (vertex, action) - and where it falls in the
+ * value grid: rectangle, unit-cell simplex, barycentric weights - does not depend on the value table
+ * (reinforcement_learning.py:89-104; the table enters at :101 only), and a value-iteration loop
+ * repeats the sweep with the same dynamics and action set.  The first max sweep (n_actions > 0) over
+ * a range therefore keeps the located successors on the device (8 d + 5 bytes per pair: 6.2 GB for
+ * 64^4 vertices x 9 actions); later max sweeps over the same range with the same h_actions - and
+ * policy-evaluation sweeps (n_actions == 0) whose table policy takes one of those actions at every
+ * vertex - gather and combine from it.  Their results are bit-identical to the uncached kernels'.
+ * The cache is dropped by whatever changes a successor: sl_model_set with another grid / dynamics
+ * description, sl_gp_set_head[_kernel], sl_gp_append_point, sl_gp_configure with another head count,
+ * sl_tri_set(slot 0); sl_tri_set_table, the reward, gamma and the policy may change freely.
+ *   max_bytes < 0: default budget (a quarter of the device's memory); 0: no cache (frees it);
+ *   otherwise the largest allocation allowed - a sweep whose cache would not fit recomputes. */
+SL_API int  sl_successor_cache_configure(sl_ctx* ctx, int64_t max_bytes);
+typedef struct sl_successor_cache_stats {
+    int64_t bytes, max_bytes;     /* allocated / allowed                                         */
+    int64_t lo, hi;               /* vertex range of the cached sweep                            */
+    int32_t valid, n_actions;     /* 1: the next matching sweep is served from the cache         */
+    int64_t fills, hits, policy_hits;   /* sweeps that filled it / max sweeps / policy sweeps served */
+} sl_successor_cache_stats;
+SL_API int  sl_successor_cache_info(sl_ctx* ctx, sl_successor_cache_stats* out);
+
 /* ---- evaluation at arbitrary points (Function.__call__, lyapunov.py:265-288, 324-376) ------ */
 enum sl_eval_what {
     SL_EVAL_VALUE = 1,      /* V(x)                    out [n][1]                  */

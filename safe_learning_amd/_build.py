@@ -25,7 +25,8 @@ UNITS = [("sl_kernels", "sl_kernels.hip", []), ("sl_gp", "sl_gp.hip", []),
          ("sl_nn", "sl_nn.hip", []), ("sl_comm", "sl_comm.hip", []),
          ("sl_gp_small", "sl_gp_small.hip", []), ("sl_det_rows", "sl_det_rows.hip", []),
          ("sl_level", "sl_level.hip", []), ("sl_adaptive", "sl_adaptive.hip", []),
-         ("sl_sample", "sl_sample.hip", []), ("sl_region", "sl_region.hip", [])]
+         ("sl_sample", "sl_sample.hip", []), ("sl_region", "sl_region.hip", []),
+         ("sl_succ", "sl_succ.hip", [])]
 UNITS += [("sl_gp4_d%d" % dim, "sl_gp4.hip", GP4_FLAGS + ["-DSL_GP4_DIM=%d" % dim]) for dim in (1, 2, 3, 4)]
 LIB = os.path.join(HERE, "libslhip.so")
 
@@ -103,9 +104,14 @@ def build(verbose=False, force=False, run_audits=True, lib=None, only=None):
         return [hipcc] + flags + extra + ["-c", os.path.join(csrc, src), "-o",
                                           os.path.join(objdir, stem, stem + ".o")]
 
+    # a unit is recompiled when its source, a header or the flag set changed (force: all of them)
+    headers = [f for f in deps if f.endswith(".h")]
     jobs = []
     for stem, src, extra in UNITS:
         if only is not None and stem not in only:
+            continue
+        obj = os.path.join(objdir, stem, stem + ".o")
+        if not force and stamp_ok and not _newer(obj, headers + [os.path.join(csrc, src)]):
             continue
         cmd = compile_cmd(stem, src, extra)
         if verbose:

@@ -96,6 +96,13 @@ class Key(C.Structure):
     _fields_ = [("vbits", C.c_uint64), ("index", C.c_int64)]
 
 
+class SuccessorCacheStats(C.Structure):
+    """``sl_successor_cache_stats`` (include/sl_hip.h)."""
+    _fields_ = [("bytes", C.c_int64), ("max_bytes", C.c_int64), ("lo", C.c_int64), ("hi", C.c_int64),
+                ("valid", C.c_int32), ("n_actions", C.c_int32), ("fills", C.c_int64),
+                ("hits", C.c_int64), ("policy_hits", C.c_int64)]
+
+
 # sl_sweep_result as int64 words (a torch int64[8] tensor backs it on the device)
 RESULT_WORDS = 8
 R_FAIL_V, R_FAIL_I, R_LAST_V, R_LAST_I, R_MAX_V, R_MAX_I, R_BELOW, R_SAFE = range(8)
@@ -116,7 +123,8 @@ EXPORTS = [
     "sl_adaptive_sort_keys", "sl_adaptive_analyse", "sl_adaptive_apply", "sl_adaptive_scatter",
     "sl_index_to_state", "sl_perturb_pairs", "sl_rows_sort_key", "sl_rows_duplicate_flags",
     "sl_sample_bounds", "sl_state_membership", "sl_argmax_masked", "sl_argmax_rows_masked", "sl_lyapunov_region",
-    "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_eval_points",
+    "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_successor_cache_configure",
+    "sl_successor_cache_info", "sl_eval_points",
     "sl_comm_unique_id", "sl_comm_init", "sl_comm_destroy", "sl_allreduce_result", "sl_allgather",
     "sl_allreduce_sum_u64", "sl_allreduce_max_f64",
     "sl_debug_mfma", "sl_debug_mfma4", "sl_debug_fp64_rate", "sl_debug_gp_inputs",
@@ -201,6 +209,8 @@ def load_library():
     lib.sl_bytes_to_bits.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sl_bellman_sweep.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, c_double_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sl_successor_cache_configure.argtypes = [C.c_void_p, C.c_int64]
+    lib.sl_successor_cache_info.argtypes = [C.c_void_p, C.POINTER(SuccessorCacheStats)]
     lib.sl_eval_points.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sl_comm_unique_id.argtypes = [C.c_char_p]
     lib.sl_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
@@ -513,6 +523,19 @@ class Context(object):
         self.check(self.lib.sl_bellman_sweep(self.handle, lo, hi, n_act, pa, _ptr(d_v_new),
                                              _ptr(d_argmax), _ptr(d_q), _ptr(d_stats)),
                    "sl_bellman_sweep")
+
+    def successor_cache_configure(self, max_bytes):
+        """Budget of the Bellman sweeps' successor cache (``sl_successor_cache_configure``):
+        negative = default (a quarter of the device's memory), 0 = no cache."""
+        self.check(self.lib.sl_successor_cache_configure(self.handle, int(max_bytes)),
+                   "sl_successor_cache_configure")
+
+    def successor_cache_info(self):
+        """``sl_successor_cache_info`` as a dict."""
+        stats = SuccessorCacheStats()
+        self.check(self.lib.sl_successor_cache_info(self.handle, C.byref(stats)),
+                   "sl_successor_cache_info")
+        return {name: int(getattr(stats, name)) for name, _ in SuccessorCacheStats._fields_}
 
     def eval_points(self, what, n, d_points, d_out):
         self.check(self.lib.sl_eval_points(self.handle, what, n, _ptr(d_points), _ptr(d_out)),

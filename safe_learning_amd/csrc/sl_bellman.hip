@@ -10,13 +10,15 @@
 // wave-uniform addresses, i.e. scalar loads.
 #include "sl_common.h"
 
-#define SL_MAX_ACTIONS 16
 
 template <int AMAX, int DT, int MT>
 __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int n_actions,
     const double* __restrict__ actions, double* __restrict__ v_new, int32_t* __restrict__ argmax,
-    double* __restrict__ q_out, double* __restrict__ stats) {
+    double* __restrict__ q_out, double* __restrict__ stats, const SlSuccDev sc_in) {
+    // sc_in.w != 0 (max sweeps only): the located successors go to the successor cache (sl_succ.hip)
+    SlSuccDev sc = sc_in;
+    if (AMAX == 0) sc.w = nullptr;
     extern __shared__ __attribute__((aligned(16))) double smem[];   // E table [head][n_pad][A]
     __shared__ double red_max[SL_BLOCK / 64], red_sum[SL_BLOCK / 64];
     const SlDims nd = sl_dims<DT, MT>(M);
@@ -80,46 +82,9 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
                     sl_policy_any<true>(M, nd, aux.tri, idx, x, u);
                 }
                 sl_append_action(nd, u, x);
-                if (is_gp) {
-                    double prior[SL_D];
-                    sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
-#pragma unroll
-                    for (int k = 0; k < SL_D; ++k) if (k < d) nxt[k] = 0.0;
-                    for (int h = 0; h < gp.nheads; ++h) {
-                        const SlGpHeadDev& hd = gp.head[h];
-                        double xg[SL_P];
-#pragma unroll
-                        for (int qd = 0; qd < SL_P; ++qd) xg[qd] = (qd < p) ? x[qd] * hd.inv_ls[qd] : 0.0;
-#pragma unroll 4
-                        for (int j = 0; j < hd.n; ++j) {
-                            double z = 0.0;
-                            double xa[SL_P];
-#pragma unroll
-                            for (int qd = 0; qd < SL_P; ++qd) {
-                                xa[qd] = 0.0;
-                                if (qd < p) {
-                                    xa[qd] = hd.xs[qd * hd.n_pad + j];
-                                    const double dlt = xa[qd] - xg[qd];
-                                    z = fma(dlt, dlt, z);
-                                }
-                            }
-                            const double kx = hd.kernel ? sl_kernel_eval(*hd.kernel, p, xa, xg)
-                                                        : hd.variance * sl_exp_nonpos(-0.5 * z);
-#pragma unroll
-                            for (int k = 0; k < SL_D; ++k) {
-                                const int dd = k - hd.col0;
-                                if (k < d && dd >= 0 && dd < hd.dout)
-                                    nxt[k] = fma(kx, hd.alpha[j * hd.dout + dd], nxt[k]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < SL_D; ++k) if (k < d) nxt[k] = nxt[k] + prior[k];
-                } else {
-                    sl_dynamics_det<0>(M, nd, x, nxt);
-                }
+                sl_next_state_mean(M, gp, nd, x, nxt);
                 const double r = sl_quadratic(M.m.reward, p, x);
-                double v = sl_tri_value_fast<DT>(vt, nxt);
+                double v = sl_tri_value_fill<DT>(vt, nxt, sc, a, idx - lo);
                 if (M.m.value.negate) v = v * -1.0;
                 const double t = M.m.gamma * v;
                 const double q = r + t;                          // reinforcement_learning.py:104
@@ -178,7 +143,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
 #pragma unroll
                     for (int k = 0; k < (DT > 0 ? DT : SL_D); ++k) if (k < d) nxt[k] = mean[a][k] + prior[k];
                     const double r = sl_quadratic(M.m.reward, p, x);
-                    double v = sl_tri_value_fast<DT>(vt, nxt);
+                    double v = sl_tri_value_fill<DT>(vt, nxt, sc, a, idx - lo);
                     if (M.m.value.negate) v = v * -1.0;
                     const double t = M.m.gamma * v;
                     const double q = r + t;
@@ -187,6 +152,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_bellman(
                 }
             }
         }
+        if (ACTIONS) sl_tri_fill_only<DT>(vt, x, sc, A, idx - lo);
         v_new[idx - lo] = best_q;
         if (argmax) argmax[idx - lo] = best_a;
         // stats[0]: max |V_new - V_old| on the vertex table (convergence test of the examples);
@@ -304,9 +270,13 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
     const SlDevModel M, const SlGpDev gp, SlAux aux, SlBellmanPack pk, int64_t lo, int64_t hi,
     int n_actions, const double* __restrict__ actions, const double* __restrict__ pack,
     double* __restrict__ v_new, int32_t* __restrict__ argmax, double* __restrict__ q_out,
-    double* __restrict__ stats, int flags) {
+    double* __restrict__ stats, int flags, const SlSuccDev sc) {
+#ifndef SL_DIAG
+    flags = 0;                                 // the shipped kernel has no diagnostic switches: the tests fold
+#endif
     // flags (SL_BM_FLAGS, diagnostics): 1 no GEMM, 2 no (cell, action) epilogue, 4 workgroup
     // barriers instead of wavefront-local ordering
+    // sc.w != 0: the located successors go to the successor cache (sl_succ.hip)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red_max[SL_BM_WAVES], red_sum[SL_BM_WAVES];
     constexpr int SL_BM_SUB = SL_BM_SUB_OF(NCB * NH);
@@ -452,6 +422,8 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
                 sl_index_to_state(M.m.grid, M.gf, d, idx, x);
                 double best_q = 0.0;
                 int best_a = -1;
+                SlSuccDev sc_l = sc;
+                if (!live) sc_l.w = nullptr;
                 for (int ai = (flags & 2) ? apg : 0; ai < apg; ++ai) {
                     const int a = grp * apg + ai;
                     if (a < A) {
@@ -473,7 +445,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
                             }
                         }
                         const double r = sl_quadratic(M.m.reward, p, x);
-                        double v = sl_tri_value_fast<DT>(vt, nxt);
+                        double v = sl_tri_value_fill<DT>(vt, nxt, sc_l, a, idx - lo);
                         if (M.m.value.negate) v = v * -1.0;
                         const double tq = M.m.gamma * v;
                         const double q = r + tq;
@@ -489,6 +461,7 @@ __global__ __launch_bounds__(64 * SL_BM_WAVES) void k_bellman_mfma(
                     if (oa >= 0 && (best_a < 0 || oq > best_q)) { best_q = oq; best_a = oa; }
                 }
                 if (grp == 0 && live) {
+                    sl_tri_fill_only<DT>(vt, x, sc_l, A, idx - lo);
                     v_new[idx - lo] = best_q;
                     if (argmax) argmax[idx - lo] = best_a;
                     double v_old = vt.table[idx * vt.ncols];         // stats[1] is policy-mode only
@@ -736,8 +709,7 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
                         int32_t* d_argmax, double* d_q, double* d_stats, int* done) {
     *done = 0;
     const SlDevModel& M = ctx->h_model;
-    const char* env = getenv("SL_BELLMAN_MFMA");
-    if (env && env[0] == '0') return SL_OK;
+    if (ctx->env.bellman_mfma == 0) return SL_OK;
     const int nheads = ctx->h_gp.nheads;
     if (M.m.policy.m != 1 || nheads < 1 || nheads > SL_BM_HEADS) return SL_OK;
     const int variant = sl_dim_variant_of(M);
@@ -832,8 +804,13 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
         *done = 1;
         return SL_OK;
     }
-    const char* bm_env = getenv("SL_BM_FLAGS");
-    const int bm_flags = bm_env ? atoi(bm_env) : 0;
+    const int bm_flags = sl_diag_flags("SL_BM_FLAGS");  // (development builds only: 0 in the shipped library)
+    SlSuccDev fill;
+    memset(&fill, 0, sizeof(fill));
+    if (ctx->succ.filling && !(bm_flags & 2)) {
+        fill = sl_succ_view(ctx);
+        ctx->succ.filled = true;
+    }
 #define SL_BM_LAUNCH(D_, N_, H_)                                                                  \
     do {                                                                                          \
         auto kern = k_bellman_mfma<D_, N_, H_>;                                                   \
@@ -842,7 +819,7 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
                                               (int)lds));                                         \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * SL_BM_WAVES), lds, ctx->stream,          \
                            ctx->h_model, ctx->h_gp, aux, pk, lo, hi, n_actions, ctx->d_actions,   \
-                           pack, d_v_new, d_argmax, d_q, d_stats, bm_flags);                      \
+                           pack, d_v_new, d_argmax, d_q, d_stats, bm_flags, fill);                \
     } while (0)
 #define SL_BM_DIMS(N_)                                  \
     do {                                                \
@@ -863,6 +840,10 @@ static int bellman_mfma(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, doub
     *done = 1;
     return SL_OK;
 }
+
+static int bellman_sweep_uncached(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions,
+                                  const double* h_actions, double* d_v_new, int32_t* d_argmax,
+                                  double* d_q, double* d_stats, bool is_gp, bool other_kernels);
 
 extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions,
                                 const double* h_actions, double* d_v_new, int32_t* d_argmax,
@@ -902,6 +883,29 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
     SL_HIP_CHECK(ctx, hipMemsetAsync(d_stats, 0, 2 * sizeof(double), ctx->stream));
     ctx->last_kernel[0] = 0;
     if (hi == lo) return SL_OK;
+    // The successors of (vertex, action) do not depend on the value table
+    // (reinforcement_learning.py:89-104): a sweep over a range / action set / dynamics that an
+    // earlier max sweep located is served from the successor cache (sl_succ.hip); otherwise a max
+    // sweep fills it on its way (the kernels that can: k_bellman_lookup, k_bellman).
+    {
+        int done = 0;
+        int rc = sl_succ_sweep(ctx, lo, hi, n_actions, h_actions, d_v_new, d_argmax, d_q, d_stats, &done);
+        if (rc) return rc;
+        if (done) return SL_OK;
+    }
+    ctx->succ.filling = ctx->succ.filled = false;
+    if (n_actions > 0) ctx->succ.filling = sl_succ_begin_fill(ctx, lo, hi, n_actions, h_actions).w != nullptr;
+    const int rc_sweep = bellman_sweep_uncached(ctx, lo, hi, n_actions, h_actions, d_v_new, d_argmax, d_q,
+                                                d_stats, is_gp, other_kernels);
+    if (rc_sweep == SL_OK && ctx->succ.filling && ctx->succ.filled) sl_succ_commit(ctx);
+    ctx->succ.filling = ctx->succ.filled = false;
+    return rc_sweep;
+}
+
+static int bellman_sweep_uncached(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions,
+                                  const double* h_actions, double* d_v_new, int32_t* d_argmax,
+                                  double* d_q, double* d_stats, bool is_gp, bool other_kernels) {
+    const SlDevModel& M = ctx->h_model;
     size_t lds = 0;
     int amax = 0;
     if (n_actions > 0) {
@@ -937,7 +941,7 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
                                                   (int)lds));                                    \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(SL_BLOCK), lds, ctx->stream, ctx->h_model,   \
                            ctx->h_gp, aux, lo, hi, n_actions, ctx->d_actions, d_v_new, d_argmax, \
-                           d_q, d_stats);                                                        \
+                           d_q, d_stats, fill);                                                  \
     } while (0)
 #define SL_BELLMAN_DIMS(AM_)                                     \
     do {                                                        \
@@ -946,6 +950,13 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
         else if (variant == 1) SL_BELLMAN(AM_, 1, 1);           \
         else SL_BELLMAN(AM_, 0, 0);                             \
     } while (0)
+    // (DT = 0, the runtime-dimension flavour, locates through sl_tri_eval: nothing to cache)
+    SlSuccDev fill;
+    memset(&fill, 0, sizeof(fill));
+    if (ctx->succ.filling && variant != 0) {
+        fill = sl_succ_view(ctx);
+        ctx->succ.filled = true;
+    }
     sl_note_kernel(ctx, false, "k_bellman<actions<=%d, d=%d>", amax, variant);
     if (amax == 3) SL_BELLMAN_DIMS(3);
     else if (amax == 9) SL_BELLMAN_DIMS(9);

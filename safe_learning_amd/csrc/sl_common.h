@@ -12,6 +12,7 @@
 #include "sl_model.h"
 
 #define SL_BLOCK 256
+#define SL_MAX_ACTIONS 16                 // actions of a Bellman max sweep (sl_bellman_sweep)
 #define SL_MAX_GRID 2048
 
 struct SlGpHeadHost {
@@ -26,8 +27,40 @@ struct SlGpHeadHost {
     sl_gp_kernel h_kernel;
 };
 
+// Environment switches (A/B runs and the tests of the alternative kernels; none is needed in
+// production).  Read ONCE, by sl_ctx_create - a launch never calls getenv.  -1 = not set.
+struct SlEnv {
+    int gp_cfg = -1;                 // SL_GP_CFG=0..3: force a GP-sweep configuration
+    int gp_small = -1;               // SL_GP_SMALL=0: small training sets stay on k_gp_sweep
+    int gp_small_waves = -1;         // SL_GP_SMALL_WAVES=8
+    int det_rows = -1;               // SL_DET_ROWS=0: linear dynamics on k_det_sweep
+    int gp4_one_panel = -1;          // SL_GP4_ONE_PANEL=0: 193..256 points stay on k_gp_small
+    int gp4_seeds = -1;              // SL_GP4_SEEDS=0: every k_x chunk from the exponentials
+    int gp4_tickets = -1;            // SL_GP4_TICKETS=0/1: fixed tile list / tile counter
+    int bellman_mfma = -1;           // SL_BELLMAN_MFMA=0: Bellman sweeps on the FP64-VALU kernel
+    int bellman4 = -1, bellman4_policy = -1, bellman4_policy_cache = -1, bellman4_policy_verbose = -1;
+    int bellman4_ragged = -1, bellman4_quarter = -1, bellman4_split = -1, bellman4_round = -1;
+    int bellman4_shared = -1;        // SL_BELLMAN4*: see DESIGN.md "Environment switches"
+    int probe_blocks_per_cu = -1;    // SL_PROBE_BLOCKS_PER_CU (sl_debug_fp64_rate)
+    int succ_cache = -1;             // SL_SUCC_CACHE=0: no successor cache
+    // (The switches that make kernels SKIP work - SL_GP4_SKIP, SL_BM_FLAGS, SL_B4P_FLAGS: timing
+    // attribution, results meaningless - exist in development builds of a unit only, -DSL_DIAG by
+    // tools/build_variant.sh: sl_diag_flags below.  The shipped library cannot run a sweep that
+    // leaves work out.)
+};
+#ifdef SL_DIAG
+static inline int sl_diag_flags(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+#else
+static inline constexpr int sl_diag_flags(const char*) { return 0; }
+#endif
+void sl_env_read(SlEnv* env);
+
 struct sl_ctx {
     int device = 0;
+    SlEnv env;
     hipStream_t stream = nullptr;
     std::string error;
     bool model_set = false;
@@ -74,7 +107,52 @@ struct sl_ctx {
         int n_glob = 0;
         unsigned long long bits[64];
     } policy_cache;
+    // Successor cache of the Bellman sweeps (sl_succ.hip): where the next state of every (vertex,
+    // action) pair of [lo, hi) lies in the value grid - rectangle corner, unit-cell simplex and
+    // barycentric weights.  None of it depends on the value table
+    // (reinforcement_learning.py:89-104), so the sweeps after the first of a value-iteration loop
+    // only gather and combine.  Valid while dynamics_token (grid, dynamics description, GP heads,
+    // structure of the value triangulation) and the action set are what they were at fill time.
+    unsigned long long dynamics_token = 0;
+    struct SuccState {
+        bool enabled = true;               // SL_SUCC_CACHE=0 at sl_ctx_create, sl_successor_cache_configure
+        int64_t max_bytes = 0;             // budget (default: a quarter of the device's memory)
+        void* d = nullptr;                 // [A + 1][D][n] weights, [A + 1][n] corners, [A + 1][n] simplices
+        size_t bytes = 0;
+        bool valid = false;
+        int64_t lo = 0, hi = 0;
+        int n_actions = 0, d_state = 0, m = 0;
+        unsigned long long token = 0;
+        double actions[SL_MAX_ACTIONS * SL_MAX_ACTION_DIM];
+        // policy evaluation from the cache: the cached action of every vertex, under policy_token
+        void* d_select = nullptr;          // [n] policy values (double), [n] action index (int8)
+        size_t select_bytes = 0;
+        bool select_valid = false, select_usable = false;
+        int64_t select_misses = 0, select_lo = 0, select_hi = 0;
+        unsigned long long select_policy_token = 0, select_token = 0;
+        long long fills = 0, hits = 0, policy_hits = 0;     // sl_successor_cache_info
+        bool filling = false, filled = false;               // inside one sl_bellman_sweep
+    } succ;
 };
+
+// device view of the successor cache of n = hi - lo vertices (slot a < A: action a, slot A: the
+// vertex itself - the interpolated V(x_i) of the Bellman error)
+struct SlSuccDev {
+    double* w;                 // [(slot * D + j) * n + cell], j = 0 .. D-1: weights 1 .. D
+    int32_t* corner;           // [slot * n + cell]
+    uint8_t* simplex;          // [slot * n + cell]
+    const double* actions;     // [SL_MAX_ACTIONS] the action set the cache was filled for
+    int64_t n;
+    int32_t slots, d;
+};
+SlSuccDev sl_succ_view(const sl_ctx* ctx);
+// the cache to fill during this max sweep over [lo, hi) (w == nullptr: none - disabled, over the
+// budget, shapes the cache does not take); marks the cache invalid until sl_succ_commit
+SlSuccDev sl_succ_begin_fill(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const double* h_actions);
+void sl_succ_commit(sl_ctx* ctx);
+// *done = 1 when the sweep was served from the cache
+int sl_succ_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const double* h_actions,
+                  double* d_v_new, int32_t* d_argmax, double* d_q, double* d_stats, int* done);
 
 extern thread_local std::string g_sl_last_error;
 
@@ -345,6 +423,96 @@ __device__ __forceinline__ SlCellCheck sl_cell_check(const SlDevModel& M, int d,
     r.threshold = sl_threshold(M, d, lv_x, M.m.lipschitz.tau, x);
     r.negative = r.decrease < r.threshold;
     return r;
+}
+
+// A policy value rounded to 2^-40: the key under which the policy-evaluation kernels group the
+// values an interpolated table policy takes at its own vertices (sl_bellman4.hip, sl_succ.hip).
+__device__ __forceinline__ unsigned long long sl_b4_action_bits(double u) {
+    const double c = fabs(u) < 256.0 ? __builtin_rint(u * 0x1p40) * 0x1p-40 : u;
+    return (unsigned long long)__double_as_longlong(c + 0.0);
+}
+
+// sl_tri_value_fast that also leaves the located point in the successor cache (slot, cell) when
+// there is one to fill: the value is computed from the SAME located point either way.
+template <int DT>
+__device__ __forceinline__ double sl_tri_value_fill(const SlTri& vt, const double* z, const SlSuccDev& sc,
+                                                    int slot, int64_t cell) {
+    if constexpr (DT == 0) {
+        return sl_tri_eval(vt, z, 0, nullptr);
+    } else {
+        SlTriLoc<DT> loc;
+        double vals[DT + 1];
+        sl_tri_locate_fast<DT>(vt, z, loc);
+        sl_tri_gather<DT>(vt, loc, vals);
+        if (sc.w) {
+#pragma unroll
+            for (int j = 0; j < DT; ++j) sc.w[((int64_t)slot * DT + j) * sc.n + cell] = loc.w[j + 1];
+            sc.corner[(int64_t)slot * sc.n + cell] = (int32_t)loc.corner;
+            sc.simplex[(int64_t)slot * sc.n + cell] = (uint8_t)loc.simplex;
+        }
+        return sl_tri_combine<DT>(loc, vals);
+    }
+}
+// only the located point (the vertex itself: slot A)
+template <int DT>
+__device__ __forceinline__ void sl_tri_fill_only(const SlTri& vt, const double* z, const SlSuccDev& sc,
+                                                 int slot, int64_t cell) {
+    if constexpr (DT > 0) {
+        if (sc.w) {
+            SlTriLoc<DT> loc;
+            sl_tri_locate_fast<DT>(vt, z, loc);
+#pragma unroll
+            for (int j = 0; j < DT; ++j) sc.w[((int64_t)slot * DT + j) * sc.n + cell] = loc.w[j + 1];
+            sc.corner[(int64_t)slot * sc.n + cell] = (int32_t)loc.corner;
+            sc.simplex[(int64_t)slot * sc.n + cell] = (uint8_t)loc.simplex;
+        }
+    }
+}
+
+// Next state of one (x, u) pair, z = [x, u]: the GP posterior MEAN (reinforcement_learning.py:98-99;
+// one training point at a time, any kernel family) plus the prior mean, or the deterministic
+// dynamics.  The one-pair-at-a-time path of k_bellman and of the successor cache's policy misses.
+__device__ __forceinline__ void sl_next_state_mean(const SlDevModel& M, const SlGpDev& gp, SlDims nd,
+                                                   const double* x, double* nxt) {
+    const int d = nd.d, p = nd.p;
+    if (M.m.dynamics.kind == SL_DYN_GP) {
+        double prior[SL_D];
+        sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) if (k < d) nxt[k] = 0.0;
+        for (int h = 0; h < gp.nheads; ++h) {
+            const SlGpHeadDev& hd = gp.head[h];
+            double xg[SL_P];
+#pragma unroll
+            for (int qd = 0; qd < SL_P; ++qd) xg[qd] = (qd < p) ? x[qd] * hd.inv_ls[qd] : 0.0;
+#pragma unroll 4
+            for (int j = 0; j < hd.n; ++j) {
+                double z = 0.0;
+                double xa[SL_P];
+#pragma unroll
+                for (int qd = 0; qd < SL_P; ++qd) {
+                    xa[qd] = 0.0;
+                    if (qd < p) {
+                        xa[qd] = hd.xs[qd * hd.n_pad + j];
+                        const double dlt = xa[qd] - xg[qd];
+                        z = fma(dlt, dlt, z);
+                    }
+                }
+                const double kx = hd.kernel ? sl_kernel_eval(*hd.kernel, p, xa, xg)
+                                            : hd.variance * sl_exp_nonpos(-0.5 * z);
+#pragma unroll
+                for (int k = 0; k < SL_D; ++k) {
+                    const int dd = k - hd.col0;
+                    if (k < d && dd >= 0 && dd < hd.dout)
+                        nxt[k] = fma(kx, hd.alpha[j * hd.dout + dd], nxt[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SL_D; ++k) if (k < d) nxt[k] = nxt[k] + prior[k];
+    } else {
+        sl_dynamics_det<0>(M, nd, x, nxt);
+    }
 }
 
 // blocks of SL_BLOCK threads that walk `ncells` items with a grid stride

@@ -192,8 +192,6 @@ __global__ __launch_bounds__(SL_BLOCK) void k_det_rows(
 // quadratic V, L_v a scalar or |x G^T| (per column or as one norm), scalar L_f, 1..4 state
 // dimensions, a last axis of whole bytes (multiple of 8 cells), a range of whole mask words.
 bool sl_det_rows_supports(const SlDevModel& M, int64_t lo, int64_t hi) {
-    const char* env = getenv("SL_DET_ROWS");
-    if (env && env[0] == '0') return false;
     const int d = M.m.grid.d;
     if (d < 1 || d > 4 || M.m.policy.m != 1) return false;
     if (M.m.policy.kind != SL_POLICY_LINEAR || M.m.dynamics.kind != SL_DYN_LINEAR) return false;

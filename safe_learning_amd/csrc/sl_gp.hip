@@ -374,9 +374,8 @@ __global__ __launch_bounds__(W * 64) void k_gp_sweep(
 // =============================================================================================
 // host side
 // =============================================================================================
-static int choose_cfg(int n) {
-    const char* env = getenv("SL_GP_CFG");
-    if (env && env[0] >= '0' && env[0] <= '3') return env[0] - '0';
+static int choose_cfg(const sl_ctx* ctx, int n) {
+    if (ctx->env.gp_cfg >= 0) return ctx->env.gp_cfg;
     if (n <= 256) return 0;
     return 2;        // 64-cell tiles: half the Linv traffic per MFMA of cfg 1, measured fastest
 }
@@ -399,7 +398,7 @@ static int gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0, 
     for (int q = 0; q < p; ++q)
         if (!(h_lengthscales[q] > 0.0))
             return sl_fail(ctx, SL_ERR_INVALID, "sl_gp_set_head: lengthscale <= 0");
-    const int cfg = choose_cfg(n);
+    const int cfg = choose_cfg(ctx, n);
     const int rp = cfg_panel_rows(cfg);
     const int n_pad = ((n + rp - 1) / rp) * rp;
     const int nslab2 = n_pad / 8;
@@ -433,6 +432,7 @@ static int gp_set_head(sl_ctx* ctx, int head, int n, int p, int dout, int col0, 
     }
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ++ctx->dynamics_token;                         // successor cache: the posterior mean changes
     SlGpHeadHost& hh = ctx->gp_heads[head];
     if (hh.d_xs) (void)hipFree(hh.d_xs);
     if (hh.d_mpack) (void)hipFree(hh.d_mpack);
@@ -531,6 +531,7 @@ extern "C" int sl_gp_append_point(sl_ctx* ctx, int head, const double* h_x, cons
     if (n + 1 > hh.n_pad)
         return sl_fail(ctx, SL_ERR_UNSUPPORTED, "sl_gp_append_point: capacity %d of head %d is "
                                                 "exhausted (upload the head again)", hh.n_pad, head);
+    ++ctx->dynamics_token;                         // successor cache: the posterior mean changes
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     const size_t need = sizeof(double) * (size_t)(n + 1 + hh.p + hh.dout);
@@ -586,6 +587,7 @@ extern "C" int sl_gp_configure(sl_ctx* ctx, int nheads, double beta) {
                            "(training-set sizes too different)");
     }
     ctx->gp_cfg = cfg;
+    if (ctx->h_gp.nheads != nheads) ++ctx->dynamics_token;
     ctx->h_gp.nheads = nheads;
     ctx->h_gp.beta = beta;
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -677,8 +679,7 @@ int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
     if (ctx->gp_cfg == 0 && !other_kernels && sl_gp4_supports(model)) {
         bool one_panel = true;
         for (int h = 0; h < ctx->h_gp.nheads; ++h) one_panel = one_panel && ctx->gp_heads[h].n_pad == 256;
-        const char* env = getenv("SL_GP4_ONE_PANEL");
-        if (env && env[0] == '0') one_panel = false;
+        if (ctx->env.gp4_one_panel == 0) one_panel = false;
         if (one_panel)
             return sl_gp4_sweep_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
                                        d_dbg, d_points);
@@ -882,8 +883,8 @@ extern "C" int sl_debug_fp64_rate(sl_ctx* ctx, int which, int iters, double* h_o
     if (!ctx || !h_out || which < 0 || which > 8 || iters < 1)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_debug_fp64_rate: bad argument");
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const char* env = getenv("SL_PROBE_BLOCKS_PER_CU");
-    const int per_cu = (env && env[0] >= '1' && env[0] <= '8') ? env[0] - '0' : 2;
+    const int per_cu = (ctx->env.probe_blocks_per_cu >= 1 && ctx->env.probe_blocks_per_cu <= 8)
+                           ? ctx->env.probe_blocks_per_cu : 2;
     double* sink;
     long long* clocks;
     SL_HIP_CHECK(ctx, hipMalloc(&sink, sizeof(double)));

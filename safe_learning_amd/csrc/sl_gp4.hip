@@ -74,14 +74,8 @@ constexpr int RB = R * W;                  // row blocks per panel
 // cell for the rotated fragment reads to be conflict free; the shift between the row pairs and
 // the slab-pair skew leave the generation writes (lane = training point, 8 B, one cell per
 // instruction) with 2-way conflicts only.
-#ifndef SL_GP4_GRAM
-#define SL_GP4_GRAM 1
-#endif
 #ifndef SL_GP4_WRITE_SKEW
 #define SL_GP4_WRITE_SKEW 1
-#endif
-#ifndef SL_GP4_DIAG_SKIP
-#define SL_GP4_DIAG_SKIP 1                 // leave out the zero slab pairs of the diagonal blocks
 #endif
 constexpr int RUNS = 4;                    // affine runs per wavefront handled by the recurrence
 constexpr int RUNC = SL_P + 2;             // per (wavefront, run): step[SL_P], a^2, Q
@@ -134,15 +128,7 @@ __device__ __forceinline__ double acc_read() {
                  : "i"(N), "i"(N + 1));
     return __hiloint2double((int)hi, (int)lo);
 }
-// |a|^2 contributions of the panel: ssr[cb][rot] += acc(r, cb, rot)^2 over the row blocks
-template <int I = 0>
-__device__ __forceinline__ void acc_squares(double (&ssr)[CB][4]) {
-    const double v = acc_read<2 * I>();
-    ssr[(I / 4) % CB][I % 4] = fma(v, v, ssr[(I / 4) % CB][I % 4]);
-    if constexpr (I + 1 < NACC) acc_squares<I + 1>(ssr);
-}
-
-// The same sums on the matrix pipe: with an accumulator register as BOTH operands of a 4x4x4 MFMA
+// |a|^2 of the panel's rows on the matrix pipe: with an accumulator register as BOTH operands of a 4x4x4 MFMA
 // (lane (k, blk, low) holds a[row k of the register's four][cell low of its group]: the layout of
 // the B operand and, transposed, of the A operand) the product is the 4 x 4 Gram matrix of the
 // four rows, whose diagonal - lanes with k == low - is sum_k a[k][cell]^2.  Chained over the row
@@ -219,56 +205,37 @@ __device__ __forceinline__ void group(const sl_d2& av, const BFrag& b) {
 #undef SL_GP4_Y01
 #undef SL_GP4_Y23
 }
-// ---- slots inside the MFMA stream -------------------------------------------------------------------
-// rotation<> offers four issue slots behind the first MFMA pairs of every rotation (slot I = ((slab
-// pair * 4 + rotation) * 4 + k) of the chunk) to a filler object.  Round 3 measured the posterior
-// mean and the k_x generation of the next chunk cut into such pieces ("fillers", with the 512-row,
-// one-wavefront-per-SIMD shape of the workgroup): +0.7 %, and 2 % behind the two-workgroup shape that
-// ships, whose partner workgroup covers those phases (profiles/r03_summary.md) - the filler code and
-// the 512-row shape were removed in round 4; the slots stay empty.
-struct NoFill {
-    static constexpr bool has(int) { return false; }
-    template <int I> __device__ __forceinline__ void step() {}
-};
-
 // One rotation of a slab pair against the row blocks r >= R0, operand loads INSIDE the MFMA
 // stream: with one wavefront per SIMD every instruction issued between two groups is a bubble of
 // the matrix pipe (four ds_read_b128 in a row: 20-30 cycles per 130-cycle group), issued between
 // the MFMAs of a group it disappears in the 16-cycle shadow of the previous MFMA.  The first
 // group of the rotation carries the four k_x fragment reads of the NEXT rotation (two after each of
 // its first two MFMA pairs: at least four MFMAs old when the next rotation starts, also when the
-// rotation is a single group) and the filler pieces of slots I0 .. I0 + 3; group r carries the
+// rotation is a single group); group r carries the
 // buffer load of A fragment r of the slab pair two ahead in the rotation (r - R0) & 3, so every
 // fragment is requested once per slab pair.  sched_barrier pins the placement (the scheduler
 // would otherwise gather the loads in front of the group).
-template <int R0, int ROT, bool LOADA, int S2, class F, int RI = R0, int REND = R>
+template <int R0, int ROT, bool LOADA, int S2, int RI = R0, int REND = R>
 __device__ __forceinline__ void rotation(const AFrag& a, const BFrag& b, BFrag& bn, const double* kxn,
                                          AFrag& an, __amdgpu_buffer_rsrc_t rsrc,
-                                         const int (&rowoff)[R], int s2n, int lane, F& f) {
+                                         const int (&rowoff)[R], int s2n, int lane) {
     if constexpr (RI < REND) {
         constexpr bool LA = LOADA && ((RI - R0) & 3) == ROT;
         if constexpr (RI == R0) {
-            constexpr int I0 = (S2 * 4 + ROT) * 4;
             group<RI, ROT, 3>(a.v[RI], b);
             bn.v[0] = *reinterpret_cast<const sl_d2*>(kxn);
             bn.v[1] = *reinterpret_cast<const sl_d2*>(kxn + 128);
-            f.template step<I0>();
             __builtin_amdgcn_sched_barrier(0);
             group<RI, ROT, 4>(a.v[RI], b);
             bn.v[2] = *reinterpret_cast<const sl_d2*>(kxn + 256);
             bn.v[3] = *reinterpret_cast<const sl_d2*>(kxn + 384);
-            f.template step<I0 + 1>();
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (LA || F::has(I0 + 2) || F::has(I0 + 3)) {
+            if constexpr (LA) {
                 group<RI, ROT, 5>(a.v[RI], b);
-                if constexpr (LA)
-                    an.v[RI] = __builtin_bit_cast(
-                        sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[RI] + s2n * 1024, 0));
-                f.template step<I0 + 2>();
-                if constexpr (LA || F::has(I0 + 2)) __builtin_amdgcn_sched_barrier(0);
+                an.v[RI] = __builtin_bit_cast(
+                    sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[RI] + s2n * 1024, 0));
+                __builtin_amdgcn_sched_barrier(0);
                 group<RI, ROT, 6>(a.v[RI], b);
-                f.template step<I0 + 3>();
-                if constexpr (F::has(I0 + 3)) __builtin_amdgcn_sched_barrier(0);
             } else {
                 group<RI, ROT, 2>(a.v[RI], b);
             }
@@ -281,7 +248,7 @@ __device__ __forceinline__ void rotation(const AFrag& a, const BFrag& b, BFrag& 
         } else {
             group<RI, ROT>(a.v[RI], b);
         }
-        rotation<R0, ROT, LOADA, S2, F, RI + 1, REND>(a, b, bn, kxn, an, rsrc, rowoff, s2n, lane, f);
+        rotation<R0, ROT, LOADA, S2, RI + 1, REND>(a, b, bn, kxn, an, rsrc, rowoff, s2n, lane);
     }
 }
 __device__ __forceinline__ void load_b(BFrag& b, const double* kxs, int off) {
@@ -298,13 +265,13 @@ __device__ __forceinline__ void load_a(AFrag& a, __amdgpu_buffer_rsrc_t rsrc, co
         a.v[r] = __builtin_bit_cast(
             sl_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, rowoff[r] + s2abs * 1024, 0));
 }
-// the slab pairs S2 .. 7 of a chunk, unrolled (the filler slots are compile-time positions): four
+// the slab pairs S2 .. 7 of a chunk, unrolled: four
 // rotations each; `be` holds the fragments of rotation 0 on entry and those of the next slab
 // pair's rotation 0 on exit; A fragments two slab pairs ahead in three register sets
-template <int R0, int S2, class F>
+template <int R0, int S2>
 __device__ __forceinline__ void slab_pairs(AFrag (&a)[3], BFrag& be, BFrag& bo, const double* kxb,
                                            const int (&boff)[4], __amdgpu_buffer_rsrc_t rsrc,
-                                           const int (&rowoff)[R], int ch, int lane, F& f) {
+                                           const int (&rowoff)[R], int ch, int lane) {
     if constexpr (S2 < 8) {
         constexpr bool LOADA = S2 < 6;
         const double* kxs = kxb + S2 * KXS2;
@@ -312,11 +279,11 @@ __device__ __forceinline__ void slab_pairs(AFrag (&a)[3], BFrag& be, BFrag& bo, 
         const AFrag& ac = a[S2 % 3];
         AFrag& an = a[(S2 + 2) % 3];
         const int s2n = 8 * ch + S2 + 2;
-        rotation<R0, 0, LOADA, S2, F>(ac, be, bo, kxs + boff[1], an, rsrc, rowoff, s2n, lane, f);
-        rotation<R0, 1, LOADA, S2, F>(ac, bo, be, kxs + boff[2], an, rsrc, rowoff, s2n, lane, f);
-        rotation<R0, 2, LOADA, S2, F>(ac, be, bo, kxs + boff[3], an, rsrc, rowoff, s2n, lane, f);
-        rotation<R0, 3, LOADA, S2, F>(ac, bo, be, kxs_next + boff[0], an, rsrc, rowoff, s2n, lane, f);
-        slab_pairs<R0, S2 + 1, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f);
+        rotation<R0, 0, LOADA, S2>(ac, be, bo, kxs + boff[1], an, rsrc, rowoff, s2n, lane);
+        rotation<R0, 1, LOADA, S2>(ac, bo, be, kxs + boff[2], an, rsrc, rowoff, s2n, lane);
+        rotation<R0, 2, LOADA, S2>(ac, be, bo, kxs + boff[3], an, rsrc, rowoff, s2n, lane);
+        rotation<R0, 3, LOADA, S2>(ac, bo, be, kxs_next + boff[0], an, rsrc, rowoff, s2n, lane);
+        slab_pairs<R0, S2 + 1>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane);
     }
 }
 // The DIAGONAL block of a wavefront (row block R0 in chunk R0 of the panel's diagonal band): its 16
@@ -327,10 +294,10 @@ __device__ __forceinline__ void slab_pairs(AFrag (&a)[3], BFrag& be, BFrag& bo, 
 // wave-uniform test in front of every second one).  At n = 1024, 6 of the 136 (row block, chunk)
 // products of a tile are such zeros: 4.4 % of the MFMAs; measured 3.0 % of the sweep at 64^4
 // (profiles/r05_gp4_diag_ab.txt: the split itself, never leaving early, costs 0.5 %).
-template <int R0, int S2, class F>
+template <int R0, int S2>
 __device__ __forceinline__ void diag_pairs(AFrag (&a)[3], BFrag& be, BFrag& bo, const double* kxb,
                                            const int (&boff)[4], __amdgpu_buffer_rsrc_t rsrc,
-                                           const int (&rowoff)[R], int ch, int lane, F& f, int nz) {
+                                           const int (&rowoff)[R], int ch, int lane, int nz) {
     if constexpr (S2 < 8) {
         if constexpr (S2 >= 2 && S2 % 2 == 0) {
             if (S2 == nz) return;
@@ -341,18 +308,18 @@ __device__ __forceinline__ void diag_pairs(AFrag (&a)[3], BFrag& be, BFrag& bo, 
         const AFrag& ac = a[S2 % 3];
         AFrag& an = a[(S2 + 2) % 3];
         const int s2n = 8 * ch + S2 + 2;
-        rotation<R0, 0, LOADA, S2, F, R0, R0 + 1>(ac, be, bo, kxs + boff[1], an, rsrc, rowoff, s2n, lane, f);
-        rotation<R0, 1, LOADA, S2, F, R0, R0 + 1>(ac, bo, be, kxs + boff[2], an, rsrc, rowoff, s2n, lane, f);
-        rotation<R0, 2, LOADA, S2, F, R0, R0 + 1>(ac, be, bo, kxs + boff[3], an, rsrc, rowoff, s2n, lane, f);
-        rotation<R0, 3, LOADA, S2, F, R0, R0 + 1>(ac, bo, be, kxs_next + boff[0], an, rsrc, rowoff, s2n, lane, f);
-        diag_pairs<R0, S2 + 1, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f, nz);
+        rotation<R0, 0, LOADA, S2, R0, R0 + 1>(ac, be, bo, kxs + boff[1], an, rsrc, rowoff, s2n, lane);
+        rotation<R0, 1, LOADA, S2, R0, R0 + 1>(ac, bo, be, kxs + boff[2], an, rsrc, rowoff, s2n, lane);
+        rotation<R0, 2, LOADA, S2, R0, R0 + 1>(ac, be, bo, kxs + boff[3], an, rsrc, rowoff, s2n, lane);
+        rotation<R0, 3, LOADA, S2, R0, R0 + 1>(ac, bo, be, kxs_next + boff[0], an, rsrc, rowoff, s2n, lane);
+        diag_pairs<R0, S2 + 1>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, nz);
     }
 }
 // one chunk of 64 training points against the row blocks r >= R0 (DIAG: R0 is the diagonal block)
-template <int R0, bool DIAG, class F>
+template <int R0, bool DIAG>
 __device__ __forceinline__ void chunk(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
                                       const int (&rowoff)[R], int ch, int lane, const int (&boff)[4],
-                                      F& f, int nz) {
+                                      int nz) {
     AFrag a[3];
     BFrag be, bo;
     if constexpr (DIAG) {
@@ -368,7 +335,7 @@ __device__ __forceinline__ void chunk(__amdgpu_buffer_rsrc_t rsrc, const double*
             load_a<R0 + 1>(a[1], rsrc, rowoff, 8 * ch + 1, lane);
         }
         load_b(be, kxb, boff[0]);
-        diag_pairs<R0, 0, F>(ad, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f, nz);
+        diag_pairs<R0, 0>(ad, be, bo, kxb, boff, rsrc, rowoff, ch, lane, nz);
         if constexpr (R0 + 1 < R) {
             // The blocks below READ their first k_x fragments again.  (Handing them over from the
             // diagonal stream - its last rotation fetching slab pair 0 - made the compiler join the
@@ -378,39 +345,29 @@ __device__ __forceinline__ void chunk(__amdgpu_buffer_rsrc_t rsrc, const double*
             // tools/audit_gp4.py now refuses such a listing.)
             load_b(be, kxb, boff[0]);
             asm volatile("s_nop 1");
-            slab_pairs<R0 + 1, 0, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f);
+            slab_pairs<R0 + 1, 0>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane);
         }
     } else {
         load_a<R0>(a[0], rsrc, rowoff, 8 * ch, lane);
         load_a<R0>(a[1], rsrc, rowoff, 8 * ch + 1, lane);
         load_b(be, kxb, boff[0]);
-        slab_pairs<R0, 0, F>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane, f);
+        slab_pairs<R0, 0>(a, be, bo, kxb, boff, rsrc, rowoff, ch, lane);
     }
 }
 // q = chunk index relative to the panel's diagonal band.  Row block r of a wavefront has its
 // diagonal in chunk r of the band: blocks r >= q are active (the diagonal block's fragments are
 // zero above the diagonal: from slab pair nzd[q] on), blocks r < q lie above it; q < 0: every block
 // is active and full.
-template <class F>
 __device__ __forceinline__ void chunk_any(__amdgpu_buffer_rsrc_t rsrc, const double* kxb,
                                           const int (&rowoff)[R], int q, int ch, int lane,
-                                          const int (&boff)[4], F& f, const int (&nzd)[R]) {
-#if SL_GP4_DIAG_SKIP
-        switch (q) {
-            case 0: chunk<0, true, F>(rsrc, kxb, rowoff, ch, lane, boff, f, nzd[0]); break;
-            case 1: chunk<1, true, F>(rsrc, kxb, rowoff, ch, lane, boff, f, nzd[1]); break;
-            case 2: chunk<2, true, F>(rsrc, kxb, rowoff, ch, lane, boff, f, nzd[2]); break;
-            case 3: chunk<3, true, F>(rsrc, kxb, rowoff, ch, lane, boff, f, nzd[3]); break;
-            default: chunk<0, false, F>(rsrc, kxb, rowoff, ch, lane, boff, f, 8); break;
-        }
-#else
-        switch (q) {
-            case 1: chunk<1, false, F>(rsrc, kxb, rowoff, ch, lane, boff, f, 8); break;
-            case 2: chunk<2, false, F>(rsrc, kxb, rowoff, ch, lane, boff, f, 8); break;
-            case 3: chunk<3, false, F>(rsrc, kxb, rowoff, ch, lane, boff, f, 8); break;
-            default: chunk<0, false, F>(rsrc, kxb, rowoff, ch, lane, boff, f, 8); break;
-        }
-#endif
+                                          const int (&boff)[4], const int (&nzd)[R]) {
+    switch (q) {
+        case 0: chunk<0, true>(rsrc, kxb, rowoff, ch, lane, boff, nzd[0]); break;
+        case 1: chunk<1, true>(rsrc, kxb, rowoff, ch, lane, boff, nzd[1]); break;
+        case 2: chunk<2, true>(rsrc, kxb, rowoff, ch, lane, boff, nzd[2]); break;
+        case 3: chunk<3, true>(rsrc, kxb, rowoff, ch, lane, boff, nzd[3]); break;
+        default: chunk<0, false>(rsrc, kxb, rowoff, ch, lane, boff, 8); break;
+    }
 }
 
 // exp of two arguments (sl_exp_nonpos twice), the two dependent FMA chains written alternately: a
@@ -451,22 +408,28 @@ __device__ __forceinline__ double uniform(double v) {
 
 }  // namespace gp4
 
-// XSG: the scaled training inputs do not fit LDS and are read from L2 during generation.
-template <int DT, int MT, bool XSG>
+// (The scaled training inputs and alpha' are read from L2 through buffer resources: two workgroups
+// per CU leave no LDS for them beside the k_x buffers.)
+template <int DT, int MT>
 __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
     const SlDevModel M, const SlGpDev gp, SlAux aux, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
-    int xs_doubles, int alpha_doubles, const double* __restrict__ points, int skip,
-    double* __restrict__ seeds, int seed_chunks, unsigned long long* __restrict__ ticket) {
-    // skip: diagnostics (SL_GP4_SKIP): 1 no k_x generation, 2 no mean pass, 4 no per-cell check,
-    // 8 no MFMA chunks - timing attribution only, the results are then meaningless
+    const double* __restrict__ points, int skip_arg, double* __restrict__ seeds, int seed_chunks,
+    unsigned long long* __restrict__ ticket) {
+    // skip (SL_GP4_SKIP; development builds, -DSL_DIAG, only): 1 no k_x generation, 2 no mean pass,
+    // 4 no per-cell check, 8 no MFMA chunks - timing attribution, the results are then meaningless.
+    // The shipped kernel has no such switch: the tests fold to constants.
+#ifdef SL_DIAG
+    const int skip = skip_arg;
+#else
+    constexpr int skip = 0;
+    (void)skip_arg;
+#endif
     using namespace gp4;
     asm volatile("" ::: SL_ALL_AGPRS);           // the accumulator file belongs to the MFMA groups
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* xs_l = smem;                           // [p][n_pad]
-    double* alpha_l = xs_l + xs_doubles;           // [n_pad][dout] when it fits
-    double* kx_l = alpha_l + alpha_doubles;        // [2][KXBUF]
+    double* kx_l = smem;                           // [2][KXBUF]
     constexpr int PSS = W;                         // planes of |a|^2 partials: one per wavefront
     double* part_ss = kx_l + 2 * KXBUF;            // [W][C]
     double* cell_mean = part_ss + PSS * C;         // [C][SL_D]
@@ -492,7 +455,6 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
     const int wswz = 4 * ((lane & 3) >> 1);
     uint64_t best_v = ~0ull;
     int64_t best_i = INT64_MAX;
-    int staged_head = -1;
     // Seeds of the Gaussian sequences, [run][chunk][wavefront][lane][e_0, rho_0] per workgroup: a
     // panel of 256 rows walks over every chunk of the panels before it again (40 chunk generations
     // per tile for 16 different chunks at n = 1024).  The first generation of a chunk keeps
@@ -539,15 +501,6 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                 __builtin_amdgcn_make_buffer_rsrc((void*)hd.xs, 0, 0x7fffffff, 0x27000);
             __amdgpu_buffer_rsrc_t rs_alpha =
                 __builtin_amdgcn_make_buffer_rsrc((void*)hd.alpha, 0, 0x7fffffff, 0x27000);
-            if (staged_head != h) {
-                __syncthreads();
-                if (!XSG)
-                    for (int k = tid; k < p * n_pad; k += W * 64) xs_l[k] = hd.xs[k];
-                if (alpha_doubles > 0)             // alpha' zero-padded to four columns (Fill)
-                    for (int k = tid; k < n_pad * 4; k += W * 64)
-                        alpha_l[k] = (k & 3) < dout ? hd.alpha[(k >> 2) * dout + (k & 3)] : 0.0;
-                staged_head = h;
-            }
             // scaled GP input [x, policy(x)] / lengthscales of the 64 cells (lane = cell of block `wave`)
             if (lk == 0) {
                 double xg[SL_P], u[SL_M];
@@ -657,15 +610,13 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
             // keep: a later panel will want this chunk again
             auto generate = [&](int ch, int buf, int first_new, bool keep) {
                 double* kxw = kx_l + buf * KXBUF + wbase;
-                const int j = 64 * ch + lane;
                 double xv[SL_P];
                 auto load_xv = [&]() {
 #pragma unroll
                     for (int q = 0; q < SL_P; ++q)
                         if (q < p)
-                            xv[q] = XSG ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                              rs_xs, lane * 8, (q * n_pad + 64 * ch) * 8, 0))
-                                        : xs_l[q * n_pad + j];
+                            xv[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                                rs_xs, lane * 8, (q * n_pad + 64 * ch) * 8, 0));
                 };
                 if (runs == 1u) {                  // one affine run: e_{c+1} = e_c rho_c, rho_{c+1} = rho_c Q
                     double e, rho;
@@ -770,22 +721,12 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
             // rotation-0 k_x fragment of cell block `wave`.  Lane (k, blk, low) ends up with the
             // mean of output dd = k at cell 4 blk + low.  (As FP64-VALU work in the (k, cell)
             // lane mapping this cost 8 % of the sweep.)
-            // The pass comes in two parts around the generation of the same chunk: mean_fetch
-            // requests alpha' together with the inputs of the generation (one trip to L2 for
+            // The pass comes in two parts around the generation of the same chunk: alpha' is
+            // requested together with the inputs of the generation (one trip to L2 for
             // both), mean_run multiplies once the wavefront has written its k_x values - its
             // OWN values (lane = training point, the 16 cells of block `wave`): LDS serves a
             // wavefront's instructions in order, no workgroup barrier is needed in between.
             struct MeanIn { double a0[8], a1[8]; };
-            auto mean_fetch = [&](int ch, const double* __restrict__ alpha_src, int stride, MeanIn& mi) {
-                // Rows dd >= dout of A hold whatever a valid column holds: row dd of the product
-                // depends on row dd of A only, and the rows >= dout of the result are never read.
-                const double* ap = alpha_src + (64 * ch + lk) * stride + (low < dout ? low : 0);
-#pragma unroll
-                for (int s2 = 0; s2 < 8; ++s2) {
-                    mi.a0[s2] = ap[(8 * s2) * stride];
-                    mi.a1[s2] = ap[(8 * s2 + 4) * stride];
-                }
-            };
             auto mean_run = [&](int buf, const MeanIn& mi) {
                 const double* kxr = kx_l + buf * KXBUF + wave * 128 + own;
                 sl_d2 kx[8];
@@ -819,21 +760,17 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                 const bool with_mean = ch >= first_new && !(skip & 2);
                 MeanIn mi;
                 if (with_mean) {
-                    // two call sites: the LDS copy of alpha' is read with ds_read (a common
-                    // pointer would make every access a flat load that waits on both counters)
-                    if (alpha_doubles > 0) {
-                        mean_fetch(ch, alpha_l, 4, mi);
-                    } else {
-                        // alpha' from L2 through the head's buffer resource: one lane offset, the
-                        // row of the slab in the scalar operand
-                        const int voff = (lk * dout + (low < dout ? low : 0)) * 8;
+                    // alpha' from L2 through the head's buffer resource: one lane offset, the row
+                    // of the slab in the scalar operand.  Rows dd >= dout of A hold whatever a valid
+                    // column holds: row dd of the product depends on row dd of A only, and the rows
+                    // >= dout of the result are never read.
+                    const int voff = (lk * dout + (low < dout ? low : 0)) * 8;
 #pragma unroll
-                        for (int s2 = 0; s2 < 8; ++s2) {
-                            mi.a0[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                rs_alpha, voff, (64 * ch + 8 * s2) * dout * 8, 0));
-                            mi.a1[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                                rs_alpha, voff, (64 * ch + 8 * s2 + 4) * dout * 8, 0));
-                        }
+                    for (int s2 = 0; s2 < 8; ++s2) {
+                        mi.a0[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                            rs_alpha, voff, (64 * ch + 8 * s2) * dout * 8, 0));
+                        mi.a1[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                            rs_alpha, voff, (64 * ch + 8 * s2 + 4) * dout * 8, 0));
                     }
                 }
                 if (!(skip & 1)) generate(ch, buf, first_new, keep);
@@ -867,8 +804,7 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                     const int buf = ch & 1;
                     const int q = __builtin_amdgcn_readfirstlane(ch - CPP * pan);
                     const double* kxb = kx_l + buf * KXBUF;
-                    NoFill nf;
-                    if (!(skip & 8)) chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, nf, nzd);
+                    if (!(skip & 8)) chunk_any(rsrc, kxb, rowoff, q, ch, lane, boff, nzd);
                     if (ch + 1 < nchunks) produce(ch + 1, buf ^ 1, first_new_chunk, keep);
                     __syncthreads();
                 }
@@ -877,7 +813,6 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                 // one partial sum per cell, owned by one lane (no other wave touches the plane).
                 asm volatile("s_nop 15\n\ts_nop 15" ::: SL_ALL_AGPRS);   // MFMA results -> reads
                 double ssr[CB][4];
-#if SL_GP4_GRAM
                 acc_gram(ssr);
                 // retired before the stores read them
                 asm volatile("s_nop 15\n\ts_nop 7"
@@ -886,21 +821,6 @@ __global__ __launch_bounds__(256, 2) void k_gp_sweep4(
                                "+v"(ssr[2][0]), "+v"(ssr[2][1]), "+v"(ssr[2][2]), "+v"(ssr[2][3]),
                                "+v"(ssr[3][0]), "+v"(ssr[3][1]), "+v"(ssr[3][2]), "+v"(ssr[3][3]));
                 const bool owner = lk == low;          // the diagonal of the Gram matrices
-#else
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                    for (int rot = 0; rot < 4; ++rot) ssr[cb][rot] = 0.0;
-                acc_squares(ssr);
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                    for (int rot = 0; rot < 4; ++rot) {
-                        ssr[cb][rot] += __shfl_xor(ssr[cb][rot], 16, 64);
-                        ssr[cb][rot] += __shfl_xor(ssr[cb][rot], 32, 64);
-                    }
-                const bool owner = lane < 16;
-#endif
                 {
                     // one plane per wavefront (LDS is short): the four rotations of a lane belong
                     // to four different cells, and within a rotation the lanes hit distinct cells,
@@ -991,23 +911,12 @@ static size_t gp4_fixed_lds() {
            (2 * gp4::W + 2) * sizeof(uint64_t);
 }
 
-// true when the training inputs of every head fit LDS next to the fixed buffers
-static bool sl_gp4_xs_fit(sl_ctx* ctx, int p) {
-    int xs_max = 0;
-    for (int h = 0; h < ctx->h_gp.nheads; ++h) {
-        const int v = p * ctx->gp_heads[h].n_pad;
-        xs_max = v > xs_max ? v : xs_max;
-    }
-    return gp4_fixed_lds() + sizeof(double) * ((xs_max + 1) & ~1) <= 160 * 1024;
-}
-
-template <int DT, int MT, bool XSG>
+template <int DT, int MT>
 static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
                    const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
                    int* nblocks, double* d_dbg, const double* d_points) {
     const int64_t ntiles = (hi - lo + 63) / 64;
     const int p = model.in_dim;
-    int xs_doubles = 0, alpha_doubles = 0;
     for (int h = 0; h < ctx->h_gp.nheads; ++h) {
         if (ctx->gp_heads[h].p != p)
             return sl_fail(ctx, SL_ERR_INVALID, "GP head %d has input dim %d, model has %d", h,
@@ -1015,20 +924,12 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
         if (ctx->gp_heads[h].n_pad % gp4::RP)
             return sl_fail(ctx, SL_ERR_INVALID, "GP head %d: n_pad %d is not a multiple of %d", h,
                            ctx->gp_heads[h].n_pad, gp4::RP);
-        const int v = p * ctx->gp_heads[h].n_pad, a = ctx->gp_heads[h].n_pad * 4;   // alpha' padded to 4 columns
-        xs_doubles = v > xs_doubles ? v : xs_doubles;
-        alpha_doubles = a > alpha_doubles ? a : alpha_doubles;
     }
-    xs_doubles = XSG ? 0 : ((xs_doubles + 1) & ~1);          // keep the k_x buffers 16-byte aligned
-    alpha_doubles = (alpha_doubles + 1) & ~1;
-    size_t lds = gp4_fixed_lds() + sizeof(double) * xs_doubles;
-    alpha_doubles = 0;                                        // two workgroups per CU: 80 KB each
-    if (lds + sizeof(double) * alpha_doubles <= 160 * 1024) lds += sizeof(double) * alpha_doubles;
-    else alpha_doubles = 0;                                   // alpha' then comes from L2
-    if (lds > 80 * 1024)
-        return sl_fail(ctx, SL_ERR_UNSUPPORTED, "GP training set too large for LDS staging "
-                                                "(%zu bytes needed)", lds);
-    auto kern = k_gp_sweep4<DT, MT, XSG>;
+    const size_t lds = gp4_fixed_lds();                       // two workgroups per CU: < 80 KB each
+    static_assert(sizeof(double) * (2 * gp4::KXBUF + gp4::W * gp4::C + 2 * gp4::C * SL_D + gp4::C * SL_P +
+                                    gp4::W * gp4::RUNS * gp4::RUNC) + (2 * gp4::W + 2) * sizeof(uint64_t)
+                      <= 80 * 1024, "two workgroups of k_gp_sweep4 per CU");
+    auto kern = k_gp_sweep4<DT, MT>;
     SL_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t resident = (int64_t)ctx->num_cu * 2;
@@ -1036,8 +937,7 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
     if (blocks > SL_MAX_GRID) blocks = SL_MAX_GRID;
     *nblocks = (int)blocks;
     SlAux aux{ctx->d_tri, ctx->d_net};
-    const char* env = getenv("SL_GP4_SKIP");
-    const int skip = env ? atoi(env) : 0;
+    const int skip = sl_diag_flags("SL_GP4_SKIP");            // (development builds only: 0 otherwise)
     // scratch of the sequence seeds: [workgroup][chunk][wavefront][lane][2] (see the kernel)
     int seed_chunks = 0;
     for (int h = 0; h < ctx->h_gp.nheads; ++h) {
@@ -1054,20 +954,19 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
         SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_gp4_seeds, seed_bytes));
         ctx->gp4_seed_bytes = seed_bytes;
     }
-    const char* env_seeds = getenv("SL_GP4_SEEDS");           // 0: every generation from scratch
-    double* seeds = (env_seeds && atoi(env_seeds) == 0) ? nullptr : ctx->d_gp4_seeds + head_bytes / sizeof(double);
+    // SL_GP4_SEEDS=0: every generation from scratch (same k_x bit for bit: the test of that)
+    double* seeds = ctx->env.gp4_seeds == 0 ? nullptr : ctx->d_gp4_seeds + head_bytes / sizeof(double);
     unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ctx->d_gp4_seeds);
-    const char* env_ticket = getenv("SL_GP4_TICKETS");          // 0 / 1 force the list / the counter
-    const bool counter = env_ticket ? atoi(env_ticket) != 0 : ntiles >= 4 * blocks;
+    // SL_GP4_TICKETS=0 / 1 force the list / the counter
+    const bool counter = ctx->env.gp4_tickets >= 0 ? ctx->env.gp4_tickets != 0 : ntiles >= 4 * blocks;
     if (counter) SL_HIP_CHECK(ctx, hipMemsetAsync(ticket, 0, head_bytes, ctx->stream));
     else ticket = nullptr;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(gp4::W * 64), lds, ctx->stream, model,
                        ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,
-                       ctx->d_partials, d_dbg, xs_doubles, alpha_doubles, d_points, skip, seeds,
-                       seed_chunks, ticket);
+                       ctx->d_partials, d_dbg, d_points, skip, seeds, seed_chunks, ticket);
     SL_HIP_CHECK(ctx, hipGetLastError());
-    sl_note_kernel(ctx, false, "k_gp_sweep4<d=%d, m=%d, xs_global=%d> (%d-row panels, %d workgroup(s) per CU)",
-                   DT, MT, (int)XSG, gp4::RP, 2);
+    sl_note_kernel(ctx, false, "k_gp_sweep4<d=%d, m=%d> (%d-row panels, %d workgroup(s) per CU)",
+                   DT, MT, gp4::RP, 2);
     return SL_OK;
 }
 
@@ -1078,15 +977,13 @@ static int launch4(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,
     int sl_gp4_launch_d##D_(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t hi,          \
                             const uint64_t* d_init_bits, const double* d_values,                   \
                             uint64_t* d_neg_bits, int* nblocks, double* d_dbg,                     \
-                            const double* d_points, bool xsg) {                                    \
-        return xsg ? launch4<D_, 1, true>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,   \
-                                          nblocks, d_dbg, d_points)                                \
-                   : launch4<D_, 1, false>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits,  \
-                                           nblocks, d_dbg, d_points);                              \
+                            const double* d_points) {                                              \
+        return launch4<D_, 1>(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,      \
+                              d_dbg, d_points);                                                    \
     }
 #define SL_GP4_DIM_DECL(D_)                                                                        \
     int sl_gp4_launch_d##D_(sl_ctx*, const SlDevModel&, int64_t, int64_t, const uint64_t*,         \
-                            const double*, uint64_t*, int*, double*, const double*, bool);
+                            const double*, uint64_t*, int*, double*, const double*);
 SL_GP4_DIM_DECL(1) SL_GP4_DIM_DECL(2) SL_GP4_DIM_DECL(3) SL_GP4_DIM_DECL(4)
 #if !defined(SL_GP4_DIM) || SL_GP4_DIM == 1
 SL_GP4_DIM_ENTRY(1)
@@ -1105,10 +1002,9 @@ int sl_gp4_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
                         const uint64_t* d_init_bits, const double* d_values, uint64_t* d_neg_bits,
                         int* nblocks, double* d_dbg, const double* d_points) {
     const int variant = sl_dim_variant_of(model);
-    const bool xsg = true;                  // training inputs from L2 (no LDS left beside the k_x buffers)
 #define SL_GP4(D_)                                                                                 \
     return sl_gp4_launch_d##D_(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,     \
-                               d_dbg, d_points, xsg)
+                               d_dbg, d_points)
     switch (variant) {
         case 1: SL_GP4(1);
         case 2: SL_GP4(2);

@@ -313,8 +313,7 @@ static size_t lds_capacity(bool general) {
 // the heads' inputs / alpha' / the check's scratch fit LDS (a 6-D stack of six 256-point heads
 // does not: it stays on k_gp_sweep)
 bool sl_gp_small_supports(sl_ctx* ctx, const SlDevModel& model) {
-    const char* env = getenv("SL_GP_SMALL");
-    if (env && env[0] == '0') return false;
+    if (ctx->env.gp_small == 0) return false;
     if (ctx->h_gp.nheads < 1) return false;
     for (int k = 0; k < ctx->h_gp.nheads; ++k) {
         const SlGpHeadHost& h = ctx->gp_heads[k];
@@ -344,8 +343,7 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
         return sizeof(double) * (small + (with_tri ? tri : 0) + scratch_of(waves)) <= cap;
     };
     // the factor in LDS matters most, then the third wavefront per SIMD
-    const char* wenv = getenv("SL_GP_SMALL_WAVES");
-    const int wmax = wenv ? atoi(wenv) : WAVES_MAX;
+    const int wmax = ctx->env.gp_small_waves >= 0 ? ctx->env.gp_small_waves : WAVES_MAX;
     int waves = WAVES_MIN;
     bool alds = fits(WAVES_MIN, true);
     // (the runtime-dimension instantiations need all 256 registers: two wavefronts per SIMD)

@@ -46,6 +46,36 @@ int sl_fail(sl_ctx* ctx, int code, const char* fmt, ...) {
 // =============================================================================================
 extern "C" int sl_version(void) { return 100; }
 
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    if (!v || !v[0]) return -1;
+    const int i = atoi(v);
+    return i < 0 ? 0 : i;
+}
+
+void sl_env_read(SlEnv* e) {
+    e->gp_cfg = env_int("SL_GP_CFG");
+    if (e->gp_cfg > 3) e->gp_cfg = -1;
+    e->gp_small = env_int("SL_GP_SMALL");
+    e->gp_small_waves = env_int("SL_GP_SMALL_WAVES");
+    e->det_rows = env_int("SL_DET_ROWS");
+    e->gp4_one_panel = env_int("SL_GP4_ONE_PANEL");
+    e->gp4_seeds = env_int("SL_GP4_SEEDS");
+    e->gp4_tickets = env_int("SL_GP4_TICKETS");
+    e->bellman_mfma = env_int("SL_BELLMAN_MFMA");
+    e->bellman4 = env_int("SL_BELLMAN4");
+    e->bellman4_policy = env_int("SL_BELLMAN4_POLICY");
+    e->bellman4_policy_cache = env_int("SL_BELLMAN4_POLICY_CACHE");
+    e->bellman4_policy_verbose = env_int("SL_BELLMAN4_POLICY_VERBOSE");
+    e->bellman4_ragged = env_int("SL_BELLMAN4_RAGGED");
+    e->bellman4_quarter = env_int("SL_BELLMAN4_QUARTER");
+    e->bellman4_split = env_int("SL_BELLMAN4_SPLIT");
+    e->bellman4_round = env_int("SL_BELLMAN4_ROUND");
+    e->bellman4_shared = env_int("SL_BELLMAN4_SHARED");
+    e->probe_blocks_per_cu = env_int("SL_PROBE_BLOCKS_PER_CU");
+    e->succ_cache = env_int("SL_SUCC_CACHE");
+}
+
 extern "C" const char* sl_last_error(const sl_ctx* ctx) {
     return ctx ? ctx->error.c_str() : g_sl_last_error.c_str();
 }
@@ -82,6 +112,10 @@ extern "C" int sl_ctx_create(int device, void* hip_stream, sl_ctx** out) {
     SL_HIP_CHECK(ctx, hipMemset(ctx->d_tri, 0, 2 * sizeof(SlTri)));
     SL_HIP_CHECK(ctx, hipMemset(ctx->d_net, 0, sizeof(SlNet)));
     SL_HIP_CHECK(ctx, hipMemset(ctx->d_gp, 0, sizeof(SlGpDev)));
+    // environment switches are read HERE, once (not per launch)
+    sl_env_read(&ctx->env);
+    ctx->succ.enabled = ctx->env.succ_cache != 0;
+    ctx->succ.max_bytes = -1;                      // default budget: a quarter of the device's memory
     *out = ctx;
     return SL_OK;
 }
@@ -106,6 +140,8 @@ extern "C" int sl_ctx_destroy(sl_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_gp4_seeds) (void)hipFree(ctx->d_gp4_seeds);
     if (ctx->d_policy_cache) (void)hipFree(ctx->d_policy_cache);
+    if (ctx->succ.d) (void)hipFree(ctx->succ.d);
+    if (ctx->succ.d_select) (void)hipFree(ctx->succ.d_select);
     if (ctx->d_records) (void)hipFree(ctx->d_records);
     (void)hipFree(ctx->d_partials);
     (void)hipFree(ctx->d_partial_counts);
@@ -190,6 +226,12 @@ extern "C" int sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model) {
     if (!ctx->model_set || memcmp(&ctx->h_model.m.policy, &M.m.policy, sizeof(M.m.policy)) != 0 ||
         memcmp(&ctx->h_model.m.grid, &M.m.grid, sizeof(M.m.grid)) != 0)
         ++ctx->policy_token;
+    // the successor cache (sl_succ.hip) holds where f(x_i, u_a) lies in the value grid: another
+    // grid, another dynamics description (kind, prior-mean / system matrix, normalisation) voids it
+    if (!ctx->model_set || memcmp(&ctx->h_model.m.dynamics, &M.m.dynamics, sizeof(M.m.dynamics)) != 0 ||
+        memcmp(&ctx->h_model.m.grid, &M.m.grid, sizeof(M.m.grid)) != 0 ||
+        ctx->h_model.m.policy.m != M.m.policy.m)
+        ++ctx->dynamics_token;
     ctx->h_model = M;
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_model, &ctx->h_model, sizeof(SlDevModel),
@@ -240,6 +282,7 @@ extern "C" int sl_tri_set(sl_ctx* ctx, int slot, const sl_grid_desc* h_grid, int
     t.points = ctx->d_tri_points[slot];
     t.table = d_table;
     if (slot == 1) ++ctx->policy_token;
+    if (slot == 0) ++ctx->dynamics_token;          // another value grid / simplices / projection
     sl_tri_finish(t, h_discrete_points);
     SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_tri + slot, &t, sizeof(SlTri), hipMemcpyHostToDevice));
     return SL_OK;
@@ -796,7 +839,7 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
         rc = sl_gp_sweep_launch(ctx, ctx->h_model, lo, hi, d_init_bits, d_values, d_neg_bits,
                                 &blocks, d_dbg, d_points);
         if (rc) return rc;
-    } else if (!d_dbg && !d_points && sl_det_rows_supports(ctx->h_model, lo, hi)) {
+    } else if (!d_dbg && !d_points && ctx->env.det_rows != 0 && sl_det_rows_supports(ctx->h_model, lo, hi)) {
         // linear dynamics / linear policy / quadratic V: 8 cells of a grid row per thread
         rc = sl_det_rows_launch(ctx, lo, hi, d_init_bits, d_values, d_neg_bits, &blocks);
         if (rc) return rc;

@@ -813,6 +813,8 @@ template <int D>
 struct SlTriLoc {
     int64_t row[D + 1];          // row[0] = simplex origin
     double  w[D + 1];            // w[0] = 1 - (w[1] + ... + w[D])
+    int64_t corner;              // vertex index of the rectangle's lower corner and the unit-cell
+    int     simplex;             // simplex: (corner, simplex, w[1..D]) rebuild the rest (sl_tri_reloc)
 };
 
 template <int DT>
@@ -924,6 +926,30 @@ SL_HD void sl_tri_locate_fast(const SlTri& t, const double* x, SlTriLoc<(DT > 0 
     }
     loc.row[0] = v0 * t.ncols;
     loc.w[0] = 1.0 - wsum;
+    loc.corner = corner;
+    loc.simplex = best;
+}
+
+// A located point from what the successor cache keeps of it (sl_succ.hip): the same rows and the
+// same weights, bit for bit, as sl_tri_locate_fast produced - w[0] by the same ordered sum.
+template <int D>
+SL_HD void sl_tri_reloc(const SlTri& t, int64_t corner, int simplex, const double* w, SlTriLoc<D>& loc) {
+    double wsum = 0.0;
+#pragma unroll
+    for (int j = 0; j <= D; ++j) {
+        const int code = t.simplices[simplex][j];
+        int64_t v = corner;
+#pragma unroll
+        for (int k = 0; k < D; ++k) v += ((code >> k) & 1) * t.stride[k];
+        loc.row[j] = v * t.ncols;
+        if (j > 0) {
+            loc.w[j] = w[j - 1];
+            wsum += w[j - 1];
+        }
+    }
+    loc.w[0] = 1.0 - wsum;
+    loc.corner = corner;
+    loc.simplex = simplex;
 }
 
 // the table reads of a located point, apart from their use: kernels issue them early

@@ -26,6 +26,19 @@ import itertools
 
 from . import _hip
 from .configuration import config
+from .unit_cells import UNIT_CELL_SIMPLICES
+
+
+def qhull_unit_cell(unit_maxes):
+    """The unit-cell triangulation as the reference computes it (``functions.py:1019-1023``):
+    ``spatial.Delaunay`` of ``cartesian(*np.diag(unit_maxes))`` (3^d rows with duplicates for
+    d >= 3), as corner codes (bit k = coordinate k at ``unit_maxes[k]``)."""
+    unit_maxes = np.asarray(unit_maxes, dtype=config.np_dtype)
+    d = len(unit_maxes)
+    corners = np.array(list(_cartesian(*np.diag(unit_maxes))), dtype=config.np_dtype)
+    tri = spatial.Delaunay(corners)
+    codes = ((corners > 0).astype(np.int64) << np.arange(d)).sum(axis=1)
+    return codes[tri.simplices].astype(np.int32)
 
 # Upload caches (``_model.ModelBuilder``) are keyed on these process-wide, never reused tokens:
 # ``id()`` values can be recycled by CPython once an object is collected.
@@ -635,11 +648,14 @@ class Triangulation(DeterministicFunction):
         d = disc.ndim
         if d == 1:
             simplices = np.array([[0, 1]], dtype=np.int32)            # functions.py:935-958
+        elif d in UNIT_CELL_SIMPLICES:
+            # the reference asks Qhull (functions.py:1019-1023); which of the valid triangulations
+            # of a box Qhull returns, and in which order, is frozen in unit_cells.py (the answer of
+            # scipy 1.15.3 for every cell size): another SciPy cannot move product and oracle
+            # together (tests/test_host_logic.py compares this table, the fixture and live SciPy)
+            simplices = np.array(UNIT_CELL_SIMPLICES[d], dtype=np.int32)
         else:
-            corners = np.array(list(_cartesian(*np.diag(disc.unit_maxes))), dtype=config.np_dtype)
-            tri = spatial.Delaunay(corners)
-            codes = ((corners > 0).astype(np.int64) << np.arange(d)).sum(axis=1)
-            simplices = codes[tri.simplices].astype(np.int32)
+            simplices = qhull_unit_cell(disc.unit_maxes)               # d > 4: parity unpinned
         self.unit_simplex_codes = simplices
         self.nsimplex_unit = len(simplices)
         self.nsimplex = self.nsimplex_unit * disc.nrectangles

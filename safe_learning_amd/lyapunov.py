@@ -490,8 +490,12 @@ class Lyapunov(object):
         init = self._initial_safe_set
         if init is None:
             version = ('none',)
-        elif _frozen(init) and init is self._init_object:
-            return
+        elif _frozen(init):
+            # read-only: identified by object identity from its FIRST use on - never hashed, no warning
+            if init is self._init_object:
+                return
+            arr = np.asarray(init)
+            version = ('frozen',)
         else:
             arr = np.asarray(init)
             if arr.nbytes > (1 << 24) and not getattr(self, '_warned_large_mask', False):
@@ -530,6 +534,10 @@ class Lyapunov(object):
         later read of ``values`` on ONE rank only is a local read (the lazy gather behind the
         attribute is a collective and must otherwise be reached by every rank)."""
         import copy
+        # c_max / safe_count of the last update_safe_set are the reference's values OF THAT MOMENT
+        # (lyapunov.py:590-595): a deferred no-failure select reads the ordering keys, so it has to
+        # run before they are replaced
+        self._resolve_pending()
         self._upload_model()
         self._values_implicit = self._ctx.values_implicit()
         self._implicit_snapshot = ((copy.deepcopy(self._lyapunov_function), self._implicit_signature())

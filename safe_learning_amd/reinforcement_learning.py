@@ -48,6 +48,23 @@ class PolicyIteration(object):
         self._lo, self._hi = self._bounds[self._rank], self._bounds[self._rank + 1]
         self.last_residual = None
 
+    def successor_cache(self, max_bytes=-1):
+        """Budget of the engine's successor cache (``sl_successor_cache_configure``).
+
+        The next state of (vertex, action) never sees the value table (``:89-104``), so the first
+        ``value_iteration(action_space)`` / ``discrete_policy_optimization`` sweep keeps where
+        every successor lies in the value grid and the following sweeps - max sweeps over the same
+        action set, policy evaluation with a greedy table policy - only gather and combine (bit
+        for bit the tables of the uncached sweeps).  ``-1``: default budget (a quarter of the
+        GPU's memory), ``0``: recompute every sweep, otherwise a byte limit.  New GP data, other
+        dynamics or another action set are noticed by the engine."""
+        self._ctx.successor_cache_configure(max_bytes)
+
+    @property
+    def successor_cache_info(self):
+        """``sl_successor_cache_info``: bytes, validity and hit counters of the cache."""
+        return self._ctx.successor_cache_info()
+
     @property
     def state_space(self):
         """All grid vertices (``reinforcement_learning.py:58-59``)."""

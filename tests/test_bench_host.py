@@ -95,3 +95,29 @@ def test_valu_roof_replaces_the_byte_roof_only_with_a_matching_measurement(tmp_p
     monkeypatch.setattr(pmc_valu, "sources_sha", lambda kernel: "other")
     stale = bench.valu_roof(args, dict(base))
     assert stale["bound"] == "hbm" and "valu_note" in stale
+
+
+def test_bench_refuses_diagnostic_environments():
+    """A development library (SL_LIB_PATH) or the work-skipping switches of a development build
+    (SL_GP4_SKIP, SL_BM_FLAGS, SL_B4P_FLAGS) do not produce benchmark lines: bench.py exits before
+    it touches a GPU.  The shipped library does not read those switches at all - no `getenv` outside
+    the one function that fills the context's switches at sl_ctx_create."""
+    import subprocess
+    for name in bench.REFUSED_ENV:
+        env = dict(os.environ, **{name: "8"})
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        assert res.returncode != 0 and name in res.stderr and "{" not in res.stdout, (name, res.stderr[-300:])
+    # every SL_* variable the sources read is either refused or listed in the line
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "safe_learning_amd", "csrc")
+    calls, names = [], set()
+    for path in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        text = open(path).read()
+        calls += [(os.path.basename(path), m.start()) for m in re.finditer(r"\bgetenv\(", text)]
+        names |= set(re.findall(r'"(SL_[A-Z0-9_]+)"', text))
+    # getenv appears in sl_kernels.hip's env_int (context creation) and in the SL_DIAG-only helper
+    assert sorted({f for f, _ in calls}) == ["sl_common.h", "sl_kernels.hip"], calls
+    known = set(bench.REFUSED_ENV) | set(bench.AB_ENV) | {"SL_PROBE_BLOCKS_PER_CU", "SL_BELLMAN4_POLICY_VERBOSE"}
+    assert names - known == set(), names - known

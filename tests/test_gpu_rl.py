@@ -54,7 +54,8 @@ def test_value_iteration_1d_lqr(sl, golden):
     assert_allclose(fv, orl.future_values(orl.state_space), rtol=1e-12, atol=1e-13)
 
 
-def _rl_pair(sl, case, n_vgrid):
+def _rl_pair(sl, case, n_vgrid, cache=True):
+    """cache=False: every sweep recomputes its successors (the tests of the uncached kernels)."""
     d = case["d"]
     limits = case["limits"]
     qmat = -scipy.linalg.block_diag(np.eye(d), 0.1 * np.eye(1))
@@ -68,6 +69,8 @@ def _rl_pair(sl, case, n_vgrid):
     ovf = oracle.Triangulation(ovgrid, v0, project=True)
     rl = sl.PolicyIteration(policy, dynamics, sl.QuadraticFunction(qmat), vf, gamma=0.95)
     orl = oracle.PolicyIteration(opolicy, odynamics, oracle.QuadraticFunction(qmat), ovf, gamma=0.95)
+    if not cache:
+        rl.successor_cache(0)
     return rl, orl, vf, ovf
 
 
@@ -411,7 +414,7 @@ def test_policy_evaluation_4x4x4_kernel(sl, name, kw, nv, na, style, monkeypatch
     results = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("SL_BELLMAN4_POLICY", flag)
-        rl, orl, vf, ovf = _rl_pair(sl, case, nv)
+        rl, orl, vf, ovf = _rl_pair(sl, case, nv, cache=False)
         grid, ogrid = vf.discretization, ovf.discretization
         n = grid.nindex
         if style == "greedy":
@@ -481,7 +484,7 @@ def test_4x4x4_kernels_on_sub_ranges(sl):
     values of the full-range sweep on its slice, bit for bit."""
     import torch
     case = cases.make_case("pendulum", num_points=[7, 128], n_gp=70)
-    rl, orl, vf, ovf = _rl_pair(sl, case, [7, 128])
+    rl, orl, vf, ovf = _rl_pair(sl, case, [7, 128], cache=False)
     n = vf.discretization.nindex
     actions = np.linspace(-1, 1, 9)[:, None]
     table = actions[np.random.default_rng(3).integers(0, 5, n)]
