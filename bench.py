@@ -276,6 +276,21 @@ def cpu_baseline(kind, case, budget_s=14.0, min_cells=0):
     return out
 
 
+def _cpu_quota():
+    """CPUs' worth of time the cgroup of this process may use per period (None: unlimited)."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def _all_cores_baseline(case, min_cells=0, budget_s=60.0):
     """The batch loop of lyapunov.py:517-529 as C++ / OpenMP over all the cores this process may use
     (oracle/cpu_sweep.cpp; measurement only - the NumPy oracle stays the checker and checks one of
@@ -295,28 +310,44 @@ def _all_cores_baseline(case, min_cells=0, budget_s=60.0):
         starts = rng.integers(0, max(n - batch, 1), count)
         return np.concatenate([np.arange(s, min(s + batch, n)) for s in starts])
 
+    # the cores this process may really use: its affinity mask, cut by the cgroup's CPU quota (a
+    # container with 256 visible CPUs and a quota of 32 runs 128 OpenMP threads at a quarter speed)
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = _cpu_quota()
+    nthreads = max(1, min(allowed, int(quota + 0.999)) if quota else allowed)
     first = batches(1)
-    neg, rec, _, threads = sweep.check(first, records=True)                 # warm-up + the checked batch
+    neg, rec, _, threads = sweep.check(first, threads=nthreads, records=True)   # warm-up + the checked batch
     ref = cases.oracle_cell_records(olyap, first)
     scale = float(np.abs(ref[:, 0]).max())
     diff = float(np.abs(rec[:, 0] - ref[:, 0]).max())
     flips = int(np.count_nonzero(neg != (ref[:, 0] < ref[:, 1])))
-    calib = batches(max(2 * threads * 32 // batch, 8))
-    _, _, sec, _ = sweep.check(calib)
-    rate = len(calib) / sec
+    # the thread count that is fastest HERE (SMT siblings, a CPU quota the cgroup files do not show,
+    # other tenants of the host): calibrated on a small sample
+    calib = batches(max(2 * nthreads * 32 // batch, 8))
+    rate, tried = 0.0, {}
+    for cand in sorted({nthreads, max(1, nthreads // 2), max(1, nthreads // 4)}, reverse=True):
+        _, _, sec, _ = sweep.check(calib, threads=cand)
+        tried[cand] = len(calib) / sec
+        if tried[cand] > rate:
+            rate, best = tried[cand], cand
+    nthreads = best
     want = max(int(min_cells), min(n, 1 << 24))
     cells = int(min(want, max(rate * budget_s, len(calib))))
-    idx = batches(max(cells // batch, 1))
-    _, _, sec, threads = sweep.check(idx)
+    idx = batches(max(-(-cells // batch), 1))
+    cpu0 = time.process_time()
+    _, _, sec, threads = sweep.check(idx, threads=nthreads)
+    busy = (time.process_time() - cpu0) / sec                               # CPUs kept busy on average
     value = len(idx) / sec
     return {"value": value, "threads": threads, "cells": int(len(idx)), "seconds": sec,
+            "cpus_in_affinity_mask": allowed, "cgroup_cpu_quota": quota, "cpus_busy_on_average": busy,
+            "calibration_checks_per_s_by_threads": {str(k): v for k, v in tried.items()},
             "gflops": value * sweep.flops_per_check / 1e9, "kind": "port",
             "checked": {"cells": int(len(first)), "max_abs_decrease_difference": diff, "decrease_scale": scale,
                         "mask_flips": flips, "against": "NumPy oracle (oracle/np_lyapunov.py), same batch"},
             "sample": ("%d cells (%d random 10000-cell batches of the same grid and model) in %.2f s on %d "
-                       "OpenMP threads: oracle/cpu_sweep.cpp, the batch loop of lyapunov.py:517-529 in C++ "
+                       "OpenMP threads (%.1f CPUs busy on average): oracle/cpu_sweep.cpp, the batch loop of lyapunov.py:517-529 in C++ "
                        "(%.0f GFLOP/s of SURVEY 8d's %d flops per check)%s"
-                       % (len(idx), len(idx) // batch, sec, threads, value * sweep.flops_per_check / 1e9,
+                       % (len(idx), len(idx) // batch, sec, threads, busy, value * sweep.flops_per_check / 1e9,
                           sweep.flops_per_check,
                           "" if len(idx) >= want else "; fewer than the %d cells asked for: bounded by %.0f s" % (want, budget_s)))}
 
@@ -465,6 +496,17 @@ def run_rank(args, rank, world, local_rank, backend):
         if grouped:
             dist.all_reduce(cnt)
         extra["negative_cells"] = int(cnt[0])
+        # update_safe_set() returns when its kernels are enqueued; the reference's call also leaves
+        # c_max on the host (lyapunov.py:590-595).  The same loop with c_max READ after every update
+        # (the 64-byte record copy + the host code behind it - and, when nothing failed, the select
+        # passes of the no-failure quirk - inside the clock): two steps, labelled.
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            obj.update_safe_set()
+            obj.c_max
+        barrier()
+        extra["ms_per_step_incl_c_max_read"] = 1e3 * (time.perf_counter() - t1) / 2
         # end to end: one more update including the bool[N] mask on the host (lyapunov.py:598-606)
         barrier()
         t1 = time.perf_counter()

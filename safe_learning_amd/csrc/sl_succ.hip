@@ -128,11 +128,13 @@ void sl_succ_commit(sl_ctx* ctx) {
 template <int D>
 __device__ __forceinline__ double succ_value(const SlSuccDev& sc, const int64_t* voff, int ncols,
                                              const double* __restrict__ table, int slot, int64_t cell) {
-    const int64_t corner = sc.corner[(int64_t)slot * sc.n + cell];
-    const int s = sc.simplex[(int64_t)slot * sc.n + cell];
+    // (read once per sweep: non-temporal, so that the cache lines of the value table - gathered
+    // below, 134 MB at 64^4 - are the ones L2 and the Infinity Cache keep)
+    const int64_t corner = __builtin_nontemporal_load(&sc.corner[(int64_t)slot * sc.n + cell]);
+    const int s = __builtin_nontemporal_load(&sc.simplex[(int64_t)slot * sc.n + cell]);
     double w[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) w[j] = sc.w[((int64_t)slot * D + j) * sc.n + cell];
+    for (int j = 0; j < D; ++j) w[j] = __builtin_nontemporal_load(&sc.w[((int64_t)slot * D + j) * sc.n + cell]);
     // sl_tri_reloc with the vertex offsets of the simplex from LDS: same rows, same weights
     SlTriLoc<D> loc;
     double vals[D + 1];
@@ -268,48 +270,85 @@ __global__ __launch_bounds__(256) void k_succ_select(const SlDevModel M, SlAux a
 }
 
 // Policy evaluation at the vertices of the miss list: the successor of (x_i, u_i) computed directly
-// (posterior mean one training point at a time / deterministic dynamics, like k_bellman), located
-// and interpolated as usual; the vertex's own value from slot A of the cache.
+// and located / interpolated as usual.  A WAVEFRONT per vertex: its lanes share the training points
+// of the posterior mean (reinforcement_learning.py:98-99; any kernel family), partial sums folded
+// across the lanes - 825 such vertices at 64^4 x 9 actions, one thread each walking 1024 points was
+// 0.7 ms of a 1.3 ms sweep.
 template <int DT>
 __global__ __launch_bounds__(256) void k_succ_policy_miss(
     const SlDevModel M, const SlGpDev gp, SlAux aux, const SlSuccDev sc, int64_t lo, int64_t nmiss,
     const int32_t* __restrict__ miss_list, const double* __restrict__ usel,
     double* __restrict__ v_new, double* __restrict__ stats) {
     __shared__ SlTri vt_lds;
-    __shared__ double red_max[4], red_sum[4];
     sl_stage_tri(&vt_lds, &aux.tri[0]);
     const SlTri& vt = vt_lds;
     const SlDims nd = sl_dims<DT, 1>(M);
+    const int d = nd.d, p = nd.p, lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     double lmax = 0.0, lsum = 0.0;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nmiss;
-         t += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t t = wave; t < nmiss; t += nwaves) {
         const int64_t cell = miss_list[t], idx = lo + cell;
         double x[SL_P], u[SL_M], nxt[SL_D];
-        sl_index_to_state(M.m.grid, M.gf, nd.d, idx, x);
+        sl_index_to_state(M.m.grid, M.gf, d, idx, x);
         u[0] = usel[cell];
         sl_append_action(nd, u, x);
-        sl_next_state_mean(M, gp, nd, x, nxt);
-        const double r = sl_quadratic(M.m.reward, nd.p, x);
+        if (M.m.dynamics.kind == SL_DYN_GP) {
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) nxt[k] = 0.0;
+            for (int h = 0; h < gp.nheads; ++h) {
+                const SlGpHeadDev& hd = gp.head[h];
+                double xg[SL_P];
+#pragma unroll
+                for (int qd = 0; qd < SL_P; ++qd) xg[qd] = (qd < p) ? x[qd] * hd.inv_ls[qd] : 0.0;
+                for (int j = lane; j < hd.n; j += 64) {
+                    double z = 0.0, xa[SL_P];
+#pragma unroll
+                    for (int qd = 0; qd < SL_P; ++qd) {
+                        xa[qd] = 0.0;
+                        if (qd < p) {
+                            xa[qd] = hd.xs[qd * hd.n_pad + j];
+                            const double dlt = xa[qd] - xg[qd];
+                            z = fma(dlt, dlt, z);
+                        }
+                    }
+                    const double kx = hd.kernel ? sl_kernel_eval(*hd.kernel, p, xa, xg)
+                                                : hd.variance * sl_exp_nonpos(-0.5 * z);
+#pragma unroll
+                    for (int k = 0; k < SL_D; ++k) {
+                        const int dd = k - hd.col0;
+                        if (k < d && dd >= 0 && dd < hd.dout) nxt[k] = fma(kx, hd.alpha[j * hd.dout + dd], nxt[k]);
+                    }
+                }
+            }
+            double prior[SL_D];
+            sl_rows_dot<SL_D, SL_P>(M.m.dynamics.matrix, d, p, x, prior);
+#pragma unroll
+            for (int k = 0; k < SL_D; ++k) {
+                if (k < d) {
+                    for (int o = 32; o >= 1; o >>= 1) nxt[k] += __shfl_xor(nxt[k], o, 64);
+                    nxt[k] = nxt[k] + prior[k];
+                }
+            }
+        } else {
+            sl_dynamics_det<0>(M, nd, x, nxt);
+        }
+        const double r = sl_quadratic(M.m.reward, p, x);
         double v = sl_tri_value_fast<DT>(vt, nxt);
         if (M.m.value.negate) v = v * -1.0;
         const double tq = M.m.gamma * v;
         const double q = r + tq;
-        v_new[cell] = q;
         double v_old = vt.table[idx * vt.ncols];
         double v_int = sl_tri_value_fast<DT>(vt, x);
         if (M.m.value.negate) { v_old = v_old * -1.0; v_int = v_int * -1.0; }
-        lmax = fmax(lmax, fabs(q - v_old));
-        const double diff = q - v_int;
-        lsum = fma(diff, diff, lsum);
+        if (lane == 0) {
+            v_new[cell] = q;
+            lmax = fmax(lmax, fabs(q - v_old));
+            const double diff = q - v_int;
+            lsum = fma(diff, diff, lsum);
+        }
     }
-    for (int o = 32; o >= 1; o >>= 1) {
-        lmax = fmax(lmax, __shfl_xor(lmax, o, 64));
-        lsum += __shfl_xor(lsum, o, 64);
-    }
-    if ((threadIdx.x & 63) == 0) { red_max[threadIdx.x >> 6] = lmax; red_sum[threadIdx.x >> 6] = lsum; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) { lmax = fmax(lmax, red_max[w]); lsum += red_sum[w]; }
+    if (lane == 0 && (lmax > 0.0 || lsum > 0.0)) {
         atomicMax(reinterpret_cast<unsigned long long*>(&stats[0]),
                   (unsigned long long)__double_as_longlong(lmax));
         atomicAdd(&stats[1], lsum);
@@ -407,7 +446,7 @@ int sl_succ_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const doub
 #undef SL_CACHED
     SL_HIP_CHECK(ctx, hipGetLastError());
     if (policy && nmiss > 0) {
-        const int64_t mblk = (nmiss + 255) / 256;
+        const int64_t mblk = (nmiss + 3) / 4;                  // a wavefront per vertex
         const int mblocks = (int)(mblk < 8 * (int64_t)ctx->num_cu ? mblk : 8 * (int64_t)ctx->num_cu);
 #define SL_MISS(D_)                                                                                \
     hipLaunchKernelGGL(k_succ_policy_miss<D_>, dim3(mblocks), dim3(256), 0, ctx->stream,           \

@@ -486,7 +486,9 @@ class Lyapunov(object):
         identified by a digest of its content, computed on every call (xxh3: 0.15 ms per MB); an
         array that nobody can write to (``mask.flags.writeable = False``, no writable base) by
         object identity - the way to keep a 268 MB mask at 128^4 from being hashed by every
-        update."""
+        update.  Caveat of the identity rule: NumPy lets the owner flip ``flags.writeable`` back on,
+        and a writable VIEW taken before the freeze stays writable - edits made that way after the
+        first use go unnoticed (assign a new array, or keep the mask writable, if it must change)."""
         init = self._initial_safe_set
         if init is None:
             version = ('none',)
@@ -1113,7 +1115,8 @@ def get_safe_sample(lyapunov, perturbations=None, limits=None, positive=False,
         # lyapunov.py:737-741: every safe state with every row of ``actions`` (a meshgrid of the two
         # RAVELLED arrays, i.e. one state and one action dimension - the 1-D examples)
         grid_actions = np.asarray(actions, dtype=np.float64)
-        if d == 1 and grid_actions.size == grid_actions.reshape(-1, 1).shape[0]:
+        if d == 1:
+            # (the reference ravels `actions` whatever its shape, so every element is one action)
             # state-major pairs on the device: the pairs of perturb_actions around a zero baseline
             # (0 + a = a exactly), without limits - no clipping, no duplicate removal
             zero = torch.zeros((len(safe_states), 1), dtype=torch.float64, device=safe_states.device)

@@ -252,7 +252,14 @@ class PolicyIteration(object):
             # (both contexts enqueue on torch's current stream: the masks are complete when read)
             self._ctx.argmax_rows_masked(count, n_act, q, allowed, allowed.shape[1], argmax)
             self._adopt_greedy_policy(action_space, argmax)
-            return self._gather(q, n_act).reshape(-1, n_act) if return_values else None
+            if not return_values:
+                return None
+            # `values` of the reference carries -inf at the vetoed entries (:272-275), like the
+            # callback path below: unpack this rank's mask words and mask the table before the gather
+            shifts = torch.arange(64, dtype=torch.int64, device=q.device)
+            bits = ((allowed[:, :, None] >> shifts) & 1).reshape(n_act, -1)[:, :count].t().bool()
+            q[:count] = torch.where(bits, q[:count], torch.full_like(q[:count], -float('inf')))
+            return self._gather(q, n_act).reshape(-1, n_act)
         q_all = None
         if want_q:
             q_all = self._gather(q, n_act).reshape(-1, n_act)

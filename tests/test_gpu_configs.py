@@ -52,10 +52,15 @@ def test_c2_pendulum_256_every_cell():
     lyap.update_safe_set(); olyap.update_safe_set()
     init = np.count_nonzero(cases.initial_safe_mask(case))
     assert olyap.safe_set.sum() >= init + 1000
-    if flips == 0:
-        assert_array_equal(lyap.safe_set, olyap.safe_set)
-        assert lyap.c_max == olyap.c_max
-        assert lyap.safe_count == int(olyap.safe_set.sum())
+    if flips:
+        # cells within rounding of the threshold decided differently: the oracle's sequential rule
+        # on the ENGINE's decrease mask - compared modulo the flipped cells, never skipped
+        grid = olyap.discretization
+        olyap.negative = lambda states: neg[grid.state_to_index(states)]
+        olyap.update_safe_set()
+    assert_array_equal(lyap.safe_set, olyap.safe_set)
+    assert lyap.c_max == olyap.c_max
+    assert lyap.safe_count == int(olyap.safe_set.sum())
 
 
 def _sampled_checks(lyap, olyap, n, neg, rtol, nsample, seed, starts=()):

@@ -7,6 +7,7 @@ import pytest
 from numpy.testing import assert_allclose, assert_array_equal
 
 import cases
+from test_gpu_lyapunov import log_mask_flips
 
 pytestmark = pytest.mark.gpu
 
@@ -151,6 +152,7 @@ def _gp_full_size_checks(case, nsample, seed):
         margin = np.abs(ref[:, 0] - ref[:, 1]) / np.maximum(np.abs(ref[:, 0]), 1e-300)
         differs = bits != ref_neg
         assert not np.any(differs & (margin > 1e-9)), "mask differs away from the threshold"
+        log_mask_flips(int(differs.sum()), len(differs), float(margin.min()))
         assert_array_equal(bits, neg[lo:hi])          # sub-range sweep == whole-grid sweep
         both += int(ref_neg.any() and (~ref_neg).any())
     assert both >= 2, "the compared sub-ranges must contain passing and failing cells"
@@ -167,6 +169,7 @@ def _gp_full_size_checks(case, nsample, seed):
     differs = neg[idx] != ref_neg
     assert not np.any(differs & (margin > 1e-9))
     assert differs.sum() <= 2
+    log_mask_flips(int(differs.sum()), len(differs), float(margin.min()))
     assert ref_neg.any() and (~ref_neg).any()
     assert not ref_neg[np.searchsorted(idx, i_star)] and not init[i_star]   # key* really fails
     return lyap, grown

@@ -686,9 +686,12 @@ def test_discrete_policy_optimization_with_a_lyapunov_constraint(sl, name, kw, n
         nxt = orl.dynamics(x, np.broadcast_to(action, (len(x), 1)))
         nxt = nxt[0] if isinstance(nxt, tuple) else nxt
         ok_q[:, a] = ~ambiguous_points(ovf, nxt)
-    got_q = q.cpu().numpy()                           # (unconstrained action values, as in the oracle's table where finite)
+    got_q = q.cpu().numpy()
     finite = np.isfinite(oq)
     assert_allclose(got_q[ok_q & finite], oq[ok_q & finite], rtol=1e-9, atol=1e-12)
+    # the vetoed entries carry -inf like the reference's `values` (:272-275) - away from the cells
+    # whose decrease sits on the threshold, where engine and oracle may decide differently
+    assert_array_equal(np.isfinite(got_q)[~near], finite[~near])
     best = rl.policy._host_parameters()[:, 0]
     obest_val = orl.policy.parameters[:, 0]
     masked = np.where(finite, oq, -np.inf)
