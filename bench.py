@@ -326,7 +326,11 @@ def _all_cores_baseline(case, min_cells=0, budget_s=60.0):
     calib = batches(max(2 * nthreads * 32 // batch, 8))
     rate, tried = 0.0, {}
     for cand in sorted({nthreads, max(1, nthreads // 2), max(1, nthreads // 4)}, reverse=True):
-        _, _, sec, _ = sweep.check(calib, threads=cand)
+        while True:                                   # at least 0.3 s per candidate
+            _, _, sec, _ = sweep.check(calib, threads=cand)
+            if sec >= 0.3 or len(calib) >= min(n, 1 << 22):
+                break
+            calib = batches(4 * len(calib) // batch)
         tried[cand] = len(calib) / sec
         if tried[cand] > rate:
             rate, best = tried[cand], cand

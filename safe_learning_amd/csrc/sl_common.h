@@ -66,7 +66,6 @@ struct sl_ctx {
     bool model_set = false;
 
     SlDevModel h_model;            // host copy
-    SlDevModel* d_model = nullptr; // device copy read by the kernels
     SlGpDev h_gp;
     SlGpDev* d_gp = nullptr;
     SlGpHeadHost gp_heads[SL_MAX_GP_HEADS];

@@ -101,7 +101,6 @@ extern "C" int sl_ctx_create(int device, void* hip_stream, sl_ctx** out) {
     SL_HIP_CHECK(ctx, hipSetDevice(device));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
-    SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_model, sizeof(SlDevModel)));
     SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_gp, sizeof(SlGpDev)));
     SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_tri, 2 * sizeof(SlTri)));
     SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_net, sizeof(SlNet)));
@@ -133,7 +132,6 @@ extern "C" int sl_ctx_destroy(sl_ctx* ctx) {
     }
     for (int s = 0; s < 2; ++s) if (ctx->d_tri_points[s]) (void)hipFree(ctx->d_tri_points[s]);
     if (ctx->d_net_kernels) (void)hipFree(ctx->d_net_kernels);
-    (void)hipFree(ctx->d_model);
     (void)hipFree(ctx->d_gp);
     (void)hipFree(ctx->d_tri);
     (void)hipFree(ctx->d_net);
@@ -232,11 +230,10 @@ extern "C" int sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model) {
         memcmp(&ctx->h_model.m.grid, &M.m.grid, sizeof(M.m.grid)) != 0 ||
         ctx->h_model.m.policy.m != M.m.policy.m)
         ++ctx->dynamics_token;
+    // The model travels BY VALUE in every kernel's argument segment (sl_common.h): setting it is a
+    // host-side copy - no device traffic, no synchronisation (a loop that uploads the same
+    // description before every sweep, as the Python layer does, costs nothing here).
     ctx->h_model = M;
-    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    SL_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_model, &ctx->h_model, sizeof(SlDevModel),
-                                     hipMemcpyHostToDevice, ctx->stream));
-    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // h_model may change right after
     ctx->model_set = true;
     return SL_OK;
 }
@@ -288,15 +285,19 @@ extern "C" int sl_tri_set(sl_ctx* ctx, int slot, const sl_grid_desc* h_grid, int
     return SL_OK;
 }
 
+__global__ void k_set_table_pointer(SlTri* tri, const double* table) { tri->table = table; }
+
 extern "C" int sl_tri_set_table(sl_ctx* ctx, int slot, const double* d_table) {
     if (!ctx || slot < 0 || slot > 1 || !ctx->h_tri[slot].set)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_tri_set_table: slot not set");
     ctx->h_tri[slot].table = d_table;
     if (slot == 1) ++ctx->policy_token;            // new vertex values of the policy
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    SL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    SL_HIP_CHECK(ctx, hipMemcpy(ctx->d_tri + slot, &ctx->h_tri[slot], sizeof(SlTri),
-                                hipMemcpyHostToDevice));
+    // only the table pointer of the device descriptor changes: written by a one-thread kernel ON THE
+    // STREAM, behind the sweeps that still read the old table and in front of those that follow -
+    // no host synchronisation in a value-iteration loop that hands in a new table every sweep
+    hipLaunchKernelGGL(k_set_table_pointer, dim3(1), dim3(1), 0, ctx->stream, ctx->d_tri + slot, d_table);
+    SL_HIP_CHECK(ctx, hipGetLastError());
     return SL_OK;
 }
 

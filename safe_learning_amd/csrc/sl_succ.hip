@@ -125,33 +125,48 @@ void sl_succ_commit(sl_ctx* ctx) {
 // ---------------------------------------------------------------------------------------------
 // the sweeps from the cache
 // ---------------------------------------------------------------------------------------------
+// One cache entry: what the interpolation of a located point needs (sl_tri_reloc's rule with the
+// vertex offsets of the simplex from LDS: the same rows, the same weights, bit for bit).  The two
+// halves are separate so that a kernel can issue the loads of several entries, then their
+// gathers, before it combines the first (memory-level parallelism: the sweep is bound by the
+// latency of these two dependent round trips unless several are in flight).
 template <int D>
-__device__ __forceinline__ double succ_value(const SlSuccDev& sc, const int64_t* voff, int ncols,
-                                             const double* __restrict__ table, int slot, int64_t cell) {
+struct SuccEntry {
+    int64_t corner;
+    int simplex;
+    double w[D];
+};
+template <int D>
+__device__ __forceinline__ void succ_load(const SlSuccDev& sc, int slot, int64_t cell, SuccEntry<D>& e) {
     // (read once per sweep: non-temporal, so that the cache lines of the value table - gathered
     // below, 134 MB at 64^4 - are the ones L2 and the Infinity Cache keep)
-    const int64_t corner = __builtin_nontemporal_load(&sc.corner[(int64_t)slot * sc.n + cell]);
-    const int s = __builtin_nontemporal_load(&sc.simplex[(int64_t)slot * sc.n + cell]);
-    double w[D];
+    e.corner = __builtin_nontemporal_load(&sc.corner[(int64_t)slot * sc.n + cell]);
+    e.simplex = __builtin_nontemporal_load(&sc.simplex[(int64_t)slot * sc.n + cell]);
 #pragma unroll
-    for (int j = 0; j < D; ++j) w[j] = __builtin_nontemporal_load(&sc.w[((int64_t)slot * D + j) * sc.n + cell]);
-    // sl_tri_reloc with the vertex offsets of the simplex from LDS: same rows, same weights
+    for (int j = 0; j < D; ++j) e.w[j] = __builtin_nontemporal_load(&sc.w[((int64_t)slot * D + j) * sc.n + cell]);
+}
+template <int D>
+__device__ __forceinline__ void succ_gather(const SuccEntry<D>& e, const int64_t* voff, int ncols,
+                                            const double* __restrict__ table, double* vals) {
+#pragma unroll
+    for (int j = 0; j <= D; ++j) vals[j] = table[(e.corner + voff[e.simplex * (D + 1) + j]) * ncols];
+}
+template <int D>
+__device__ __forceinline__ double succ_combine(const SuccEntry<D>& e, const double* vals) {
     SlTriLoc<D> loc;
-    double vals[D + 1];
     double wsum = 0.0;
 #pragma unroll
-    for (int j = 0; j <= D; ++j) {
-        loc.row[j] = (corner + voff[s * (D + 1) + j]) * ncols;
-        vals[j] = table[loc.row[j]];
-        if (j > 0) {
-            loc.w[j] = w[j - 1];
-            wsum += w[j - 1];
-        }
+    for (int j = 1; j <= D; ++j) {
+        loc.w[j] = e.w[j - 1];
+        wsum += e.w[j - 1];
     }
     loc.w[0] = 1.0 - wsum;
     return sl_tri_combine<D>(loc, vals);
 }
-
+// (Measured and dropped, round 6, 64^4 x 9: one entry at a time 1.35 - 1.42 ms; three entries in
+// flight - shipped - 1.40 ms; two cells per thread with 16-byte loads 1.40 ms: the kernel moves its
+// 6.3 GB - rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, profiles/r06_C5_cached_traffic.txt, against 5.9 GB
+// of entries + 0.2 GB of outputs - at 4.5 TB/s next to the gathers, whatever its instruction mix.)
 // POLICY = false: max over the cached actions (value_iteration(action_space),
 //                 discrete_policy_optimization; reinforcement_learning.py:266-279)
 // POLICY = true:  the cached action the policy takes at the vertex (value_iteration(), :135-140;
@@ -184,28 +199,51 @@ __global__ __launch_bounds__(256) void k_bellman_cached(
         const int64_t cell = idx - lo;
         double x[SL_P], u[SL_M];
         sl_index_to_state(M.m.grid, M.gf, D, idx, x);
-        double best_q = 0.0;
+        double best_q = 0.0, v_self = 0.0;
         int best_a = -1;
         if (POLICY) {
             if (asel[cell] < 0) continue;                      // k_succ_policy_miss computes it
             u[0] = usel[cell];
             sl_append_action(nd, u, x);
             const double r = sl_quadratic(M.m.reward, p, x);
-            double v = succ_value<D>(sc, voff, ncols, table, asel[cell], cell);
+            // the vertex's action and the vertex itself (slot A): both entries in flight together
+            SuccEntry<D> ea, es;
+            double va[D + 1], vs[D + 1];
+            succ_load<D>(sc, asel[cell], cell, ea);
+            succ_load<D>(sc, A, cell, es);
+            succ_gather<D>(ea, voff, ncols, table, va);
+            succ_gather<D>(es, voff, ncols, table, vs);
+            double v = succ_combine<D>(ea, va);
+            v_self = succ_combine<D>(es, vs);
             if (M.m.value.negate) v = v * -1.0;
             const double tq = M.m.gamma * v;
             best_q = r + tq;
         } else {
-            for (int a = 0; a < A; ++a) {
-                u[0] = act_l[a];
-                sl_append_action(nd, u, x);
-                const double r = sl_quadratic(M.m.reward, p, x);
-                double v = succ_value<D>(sc, voff, ncols, table, a, cell);
-                if (M.m.value.negate) v = v * -1.0;
-                const double tq = M.m.gamma * v;
-                const double q = r + tq;                       // reinforcement_learning.py:104
-                if (q_out) q_out[cell * A + a] = q;
-                if (best_a < 0 || q > best_q) { best_q = q; best_a = a; }
+            // three actions at a time: their entries, then their 3 (D + 1) gathers, are in flight
+            // together; the maximum is still taken in ascending action order (first maximiser wins)
+            constexpr int G = 3;
+            for (int a0 = 0; a0 < A; a0 += G) {
+                SuccEntry<D> e[G];
+                double vals[G][D + 1];
+#pragma unroll
+                for (int g = 0; g < G; ++g) succ_load<D>(sc, a0 + g < A ? a0 + g : A - 1, cell, e[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) succ_gather<D>(e[g], voff, ncols, table, vals[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int a = a0 + g;
+                    if (a < A) {
+                        u[0] = act_l[a];
+                        sl_append_action(nd, u, x);
+                        const double r = sl_quadratic(M.m.reward, p, x);
+                        double v = succ_combine<D>(e[g], vals[g]);
+                        if (M.m.value.negate) v = v * -1.0;
+                        const double tq = M.m.gamma * v;
+                        const double q = r + tq;               // reinforcement_learning.py:104
+                        if (q_out) q_out[cell * A + a] = q;
+                        if (best_a < 0 || q > best_q) { best_q = q; best_a = a; }
+                    }
+                }
             }
             if (argmax) argmax[cell] = best_a;
         }
@@ -214,7 +252,7 @@ __global__ __launch_bounds__(256) void k_bellman_cached(
         if (M.m.value.negate) v_old = v_old * -1.0;
         lmax = fmax(lmax, fabs(best_q - v_old));
         if (POLICY) {
-            double v_int = succ_value<D>(sc, voff, ncols, table, A, cell);
+            double v_int = v_self;
             if (M.m.value.negate) v_int = v_int * -1.0;
             const double diff = best_q - v_int;
             lsum = fma(diff, diff, lsum);

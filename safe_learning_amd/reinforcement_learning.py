@@ -199,8 +199,13 @@ class PolicyIteration(object):
         ranks (4 bytes per vertex), never the ``[N, A]`` table of action values."""
         import torch
         if best is None:
-            best = self._gather(argmax).to(torch.int64)
-        table = torch.from_numpy(action_space).to(best.device)[best]
+            best = self._gather(argmax)                  # int32 indices index as they are
+        # the action table stays on the device across the sweeps of a loop (no upload per sweep)
+        key = (action_space.shape, action_space.tobytes(), str(best.device))
+        if getattr(self, '_actions_dev_key', None) != key:
+            self._actions_dev = torch.from_numpy(np.ascontiguousarray(action_space)).to(best.device)
+            self._actions_dev_key = key
+        table = self._actions_dev[best]
         if not isinstance(self.policy, Triangulation):
             self.policy = Triangulation(self.discretization)
         self.policy._adopt_device_table(table.contiguous())
