@@ -709,10 +709,10 @@ def roofline(args, kind, case, dyn, d, cells_per_launch, avg_ms, world):
                 if pmc.get("source_sha256") == pmc_traffic.kernel_source_sha():
                     traffic, source = pmc["bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 " \
                         "FETCH_SIZE x2 + WRITE_SIZE of this command on this version of sl_gp4.hip, " \
-                        "separate passes, tools/profile_r05.sh; not this run)"
+                        "separate passes, tools/profile_r06.sh; not this run)"
                 else:
                     source = "profiles/pmc_traffic.json was measured on another version of sl_gp4.hip: " \
-                        "re-run tools/profile_r05.sh"
+                        "re-run tools/profile_r06.sh"
         except (OSError, ValueError, KeyError):
             pass
         return {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
@@ -751,7 +751,7 @@ def valu_roof(args, out):
     import pmc_valu
     if entry.get("source_sha256") != pmc_valu.sources_sha(entry["kernel"]):
         out["valu_note"] = "profiles/pmc_valu.json[%s] was measured on other kernel sources: re-run " \
-                           "tools/profile_r05.sh" % args.config
+                           "tools/profile_r06.sh" % args.config
         return out
     old_bound = out["bound"]
     out[old_bound + "_achieved"], out[old_bound + "_frac"] = out["achieved"], out["frac"]
@@ -761,7 +761,7 @@ def valu_roof(args, out):
                     "(SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024))",
                valu_kernel=entry["kernel"],
                valu_source="profiles/pmc_valu.json (rocprofv3 counter passes of this command on these kernel "
-                           "sources, tools/profile_r05.sh; not this run)")
+                           "sources, tools/profile_r06.sh; not this run)")
     for key in ("fp64_share_of_valu_instructions", "mfma_busy", "waves_waiting"):
         if key in entry:
             out[key] = entry[key]

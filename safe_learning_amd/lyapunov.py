@@ -175,17 +175,21 @@ class Lyapunov(object):
                                                 device=self._ctx.torch_device)
             self._values_stale = True
         if self._values_stale:
-            # implicit values are those of the function as it was at update_values() (a copy of
-            # its d x d matrix): the reference's array does not follow later edits of the function
-            snapshot = getattr(self, '_implicit_snapshot', None)
-            fun = snapshot[0] if (self._values_implicit and snapshot is not None) else self.lyapunov_function
-            self._builder.upload(self.policy, self.dynamics, fun, self._lipschitz_lyapunov,
-                                 self._lipschitz_dynamics, self.tau)
-            self._ctx.values(self._lo, self._hi, self._d_values_buffer)
+            self._values_into(self._lo, self._hi, self._d_values_buffer)
             self._values_stale = False
-            if fun is not self.lyapunov_function:
-                self._upload_model()
         return self._d_values_buffer
+
+    def _values_into(self, lo, hi, buffer):
+        """V of the cells ``[lo, hi)`` (``sl_values``) into a device buffer."""
+        # implicit values are those of the function as it was at update_values() (a copy of
+        # its d x d matrix): the reference's array does not follow later edits of the function
+        snapshot = getattr(self, '_implicit_snapshot', None)
+        fun = snapshot[0] if (self._values_implicit and snapshot is not None) else self.lyapunov_function
+        self._builder.upload(self.policy, self.dynamics, fun, self._lipschitz_lyapunov,
+                             self._lipschitz_dynamics, self.tau)
+        self._ctx.values(lo, hi, buffer)
+        if fun is not self.lyapunov_function:
+            self._upload_model()
 
     def _implicit_signature(self):
         """What the kernels' recomputed keys depend on (closed-form V: its matrix and sign)."""
@@ -331,22 +335,27 @@ class Lyapunov(object):
         """V at every grid point, ``float64[nindex]`` (``lyapunov.py:305-322``).
 
         With more than one rank every rank keeps only its shard of V on the device (the sweep
-        needs nothing else); the first read after ``update_values`` gathers the shards and is
-        therefore COLLECTIVE: read it on every rank (or call :meth:`gather_values` on every
-        rank first), never on one rank only."""
+        needs nothing else).  Reading the attribute is a LOCAL operation on every rank: each rank
+        holds the whole model, so the first read after ``update_values`` computes V of the whole
+        grid on this rank's GPU (``sl_values``, 0.75 ms at 128^4) - no collective hides behind the
+        attribute, a rank-guarded read cannot deadlock (round 5 gathered the shards here)."""
         if self._values_host is None:
             self._values_host = self.gather_values().cpu().numpy()
         return self._values_host
 
     def gather_values(self):
-        """All shards of V as one device tensor ``float64[nindex]`` (collective when the grid is
-        sharded; cached until the next ``update_values``).  One ``all_gather_into_tensor`` into a
-        pre-sized buffer - 2.1 GB per GPU at 128^4, which is why it is not done eagerly."""
+        """V of the whole grid as one device tensor ``float64[nindex]`` (cached until the next
+        ``update_values``).  On a sharded grid the other ranks' cells are COMPUTED here (every
+        rank has the model; 2.1 GB per GPU at 128^4, which is why it is not done eagerly) - a
+        local operation, not a collective."""
         if not self._collective:
             return self._d_values[:self._hi - self._lo]
         if self._d_values_full is None:
-            self._d_values_full = dist_utils.allgather_equal(self._d_values,
-                                                             self.discretization.nindex)
+            import torch
+            n = self.discretization.nindex
+            full = torch.empty(n, dtype=torch.float64, device=self._ctx.torch_device)
+            self._values_into(0, n, full)
+            self._d_values_full = full
         return self._d_values_full
 
     def _safe_full_buffer(self):
@@ -410,12 +419,10 @@ class Lyapunov(object):
     def _refinement(self):
         """Refinement N(x) per cell (``lyapunov.py:220-225``): the array kept by the adaptive
         branch, otherwise 1 on safe cells and 0 elsewhere (``:531, 586, 601-606``)."""
-        if self._refinement_host is None and getattr(self, '_refinement_dev', None) is not None:
-            # every rank keeps the refinement of its own cells; reading the attribute gathers the
-            # shards (collective with more than one rank, like ``values``)
-            sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
-            full = dist_utils.allgather_concat(self._refinement_dev, sizes)
-            self._refinement_host = full.cpu().numpy().astype(int)
+        if self._refinement_host is None and getattr(self, '_refinement_full', None) is not None:
+            # (the shards were gathered INSIDE update_safe_set, which every rank calls: reading the
+            # attribute is local - no collective behind a property)
+            self._refinement_host = self._refinement_full.cpu().numpy().astype(int)
         if self._refinement_host is not None:
             return self._refinement_host
         return self.safe_set.astype(int)
@@ -566,6 +573,7 @@ class Lyapunov(object):
             carry = carry.clone()
         self._refinement_host = None
         self._refinement_dev = None
+        self._refinement_full = None
         self._upload_model()
         self._refresh_init_bits()
         if not can_shrink:                                       # lyapunov.py:507-510
@@ -585,7 +593,7 @@ class Lyapunov(object):
             self._ctx.refinement_carry(self._lo, self._hi, self._values_arg(), self._d_init, self._d_neg,
                                        stats['folded'],
                                        None if keep is None else keep[_hip.S_KEY_V:_hip.S_KEY_V + 2], carry)
-            self._refinement_dev = carry
+            self._publish_refinement(carry)
         self._safe_host_valid = False
         self._safe_dev_valid = True
         self._safe_host_digest = None
@@ -617,14 +625,23 @@ class Lyapunov(object):
         self.c_max = adaptive_rule(engine, self.discretization.nindex, int(config.gp_batch_size),
                                    max_refinement, max(float(safety_factor), 1.), stats)
         self.safe_count = stats['safe']
-        self._refinement_dev = engine.refinement        # this rank's shard, int64
-        self._refinement_host = None
+        self._publish_refinement(engine.refinement)     # this rank's shard, int64
         self._safe_host_valid = False
         self._safe_dev_valid = True
         self._safe_host_digest = None
         if self._collective:
             self._d_safe_full = dist_utils.allgather_equal(
                 self._d_safe, -(-self.discretization.nindex // 64), out=self._safe_full_buffer())
+
+    def _publish_refinement(self, shard):
+        """This rank's refinement shard (device, or None) becomes the object's; with more than one
+        rank the shards are all-gathered HERE, inside the update every rank takes part in."""
+        self._refinement_dev = shard
+        self._refinement_host = None
+        self._refinement_full = None
+        if shard is not None:
+            sizes = [self._bounds[r + 1] - self._bounds[r] for r in range(self._world)]
+            self._refinement_full = dist_utils.allgather_concat(shard, sizes)
 
     def _refinement_shard(self):
         """Refinement N(x) of this rank's cells as a device tensor (int64), or None when it is

@@ -98,7 +98,7 @@ def test_adaptive_kernels_on_synthetic_cells(n, batch, max_ref, hard, seed, monk
         engine = Synthetic(lyap, shrink)
         stats = {}
         c_max = adaptive_rule(engine, n, batch, max_ref, 1.1, stats)
-        lyap._refinement_dev, lyap._refinement_host = engine.refinement, None
+        lyap._publish_refinement(engine.refinement)
         lyap._safe_host_valid, lyap._safe_dev_valid = False, True
         assert np.array_equal(lyap.safe_set, want[0])
         assert np.array_equal(np.asarray(lyap._refinement), want[1])

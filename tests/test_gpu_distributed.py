@@ -52,9 +52,14 @@ def _worker(rank, world, port, results, backend="gloo", device_per_rank=False):
         lyap, olyap = build_lyapunov(case), cases.oracle_lyapunov(case)
         assert lyap._world == world
         assert world == 1 or name == "tiny" or lyap._hi - lyap._lo < lyap.discretization.nindex
-        # the constructor keeps only the shard of V; the first read of `values` gathers (collective)
+        # the constructor keeps only the shard of V; reading `values` is a LOCAL operation (the other
+        # ranks' cells are computed here, no collective behind the attribute): rank 0 alone reads
+        # it first - with a gather behind the property this line would wait for rank 1 forever
         if lyap._d_values_full is not None:
-            failures.append((name, "V gathered eagerly"))
+            failures.append((name, "V computed eagerly"))
+        if rank == 0 and not np.array_equal(lyap.values, olyap.values):
+            failures.append((name, "values, read on rank 0 only"))
+        dist.barrier()
         if not np.array_equal(lyap.values, olyap.values):
             failures.append((name, "values"))
         if lyap._d_values_full is None or lyap._d_values_full.numel() != lyap.discretization.nindex:
@@ -89,9 +94,14 @@ def _worker(rank, world, port, results, backend="gloo", device_per_rank=False):
         if (not np.array_equal(lyap.safe_set, olyap.safe_set) or lyap.c_max != olyap.c_max
                 or not np.array_equal(lyap._refinement, olyap._refinement)):
             failures.append(("adaptive", shrink))
-    # the refinement array is sharded like V: every rank keeps its cells, the attribute gathers
+    # the refinement array is sharded like V: every rank keeps its cells; the shards were gathered
+    # inside update_safe_set (which every rank calls), so a read on ONE rank is local too
     if lyap._refinement_dev is None or lyap._refinement_dev.numel() != lyap._hi - lyap._lo:
         failures.append(("adaptive", "refinement not sharded"))
+    lyap._refinement_host = None
+    if rank == world - 1 and not np.array_equal(lyap._refinement, olyap._refinement):
+        failures.append(("adaptive", "refinement, read on the last rank only"))
+    dist.barrier()
     # get_safe_sample on every rank (the mask words of the whole grid are on every rank): the same
     # pair and bound as the oracle's
     case = cases.make_case("pendulum", num_points=33, n_gp=40, tau_scale=0.01, signal_std=0.001,
