@@ -21,6 +21,11 @@ What it restates (reference file:line, relative to the upstream checkout):
 * ``oracle.np_rl`` - ``safe_learning/reinforcement_learning.py:26-140,
   213-279``.
 
+* ``oracle/cpu_sweep.cpp`` + ``oracle.cpu_sweep`` (round 6) - the batch loop of
+  ``safe_learning/lyapunov.py:517-529`` for the shared-kernel RBF configurations in C++ / OpenMP: the
+  CPU BASELINE of ``bench.py`` at host strength.  Measurement only: it checks nothing,
+  the NumPy code below checks it (``tests/test_cpu_sweep.py``).
+
 Third-party arithmetic that is not in the upstream checkout: the RBF kernel and
 ``GPR.build_predict`` of gpflow==0.4.0 (pinned in the reference's
 ``requirements.txt:3``).  The published algorithm is restated in
