@@ -52,7 +52,8 @@ enum sl_policy_kind {
     SL_POLICY_LINEAR = 1,   /* u = x K^T            (LinearSystem, functions.py:1567-1583)  */
     SL_POLICY_CONST  = 2,   /* u = constant row     (reinforcement_learning.py:233-235,268) */
     SL_POLICY_TABLE  = 3,   /* u = table[i]         (per-vertex policy on the same grid)    */
-    SL_POLICY_TRI    = 4    /* u = Triangulation(x) on the auxiliary grid #1                */
+    SL_POLICY_TRI    = 4,   /* u = Triangulation(x) on the auxiliary grid #1                */
+    SL_POLICY_NETWORK = 5   /* u = NeuralNetwork(x)  (functions.py:1663-1729), sl_policy_network_set */
 };
 enum sl_dynamics_kind {
     SL_DYN_LINEAR   = 1,    /* [x,u] M^T            (functions.py:1567-1583)                */
@@ -218,6 +219,21 @@ SL_API int  sl_tri_set_table(sl_ctx* ctx, int slot, const double* d_table);
  * [out_i][in_i] concatenated; activation codes 0 = linear, 1 = tanh, 2 = relu. */
 SL_API int  sl_network_set(sl_ctx* ctx, int nlayers, const int32_t* h_dims /* nlayers+1 */,
                     const int32_t* h_activations, const double* h_kernels);
+
+/* NeuralNetwork as the policy (functions.py:1663-1729; the policies of examples/inverted_pendulum.ipynb
+ * :215 and of the reinforcement-learning notebooks): a chain of dense layers
+ *   net <- act_l(net W_l + b_l),  u = output_scale * net
+ * h_dims [nlayers + 1] = input width (the state dimension) followed by the units of every layer (the
+ * reference's `layers`), widths <= 64, the last <= SL_MAX_ACTION_DIM; h_activations [nlayers]: 0 none,
+ * 1 tanh, 2 relu, 3 sigmoid; h_kernels = the W_l ([in][out] row-major, tf.layers.dense's kernel)
+ * concatenated; h_has_bias [nlayers] (may be NULL: none) and h_biases = the b_l of the layers that
+ * have one, concatenated (the reference's output layer never has).  With policy.kind =
+ * SL_POLICY_NETWORK the entry points that evaluate the policy (sl_lyap_sweep, sl_bellman_sweep with
+ * n_actions == 0, sl_eval_points) evaluate the network once per cell / vertex / point into an
+ * action table of their own and run the kernels on that table (policy.saturate applies as usual). */
+SL_API int  sl_policy_network_set(sl_ctx* ctx, int nlayers, const int32_t* h_dims,
+                           const int32_t* h_activations, const double* h_kernels,
+                           const double* h_biases, const int32_t* h_has_bias, double output_scale);
 
 /* ---- Lyapunov passes ------------------------------------------------------------------- */
 /* values[i-lo] = V(all_points[i]), i in [lo,hi): the points of functions.py:622-638 (np.linspace:

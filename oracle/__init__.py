@@ -80,7 +80,7 @@ from .np_utilities import batchify, dlqr
 from .np_grid import GridWorld, DimensionError
 from .np_functions import (ordered_matmul, QuadraticFunction, LinearSystem, Saturation,
                         RBF, GPRCached, GaussianProcess, FunctionStack, Triangulation,
-                        InvertedPendulum, CartPole, LyapunovNetwork, AbsFunction,
+                        InvertedPendulum, CartPole, LyapunovNetwork, NeuralNetwork, AbsFunction,
                         Norm1Function, NegatedFunction, ConstantPolicy,
                         TriangulationGradient)
 from .np_lyapunov import (Lyapunov, smallest_boundary_value, config, get_safe_sample,

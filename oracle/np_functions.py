@@ -646,6 +646,39 @@ class CartPole(object):
 # Positive-definite network of lyapunov_function_learning.ipynb
 # --------------------------------------------------------------------------------------
 
+class NeuralNetwork(object):
+    """Chain of dense layers, ``net <- act_l(net W_l + b_l)``, output times ``output_scale``.
+
+    Reference: ``functions.py:1663-1729`` (``build_evaluation``: one ``tf.layers.dense`` per entry of
+    ``layers``, bias on every layer but the last when ``use_bias``, ``tf.multiply(net,
+    output_scale)``).  The reference's parameters are TensorFlow variables; here they are given in its
+    variable order ``[W_0, b_0, ..., W_out]`` (``_parameter_iter``, ``:1731-1740``).  No test of the
+    reference holds a number for this class (``tests/test_functions.py:764-777`` checks that the
+    Lipschitz constant is positive): the dense-layer arithmetic is restated, **parity unpinned**."""
+
+    _ACT = {None: lambda x: x, 'linear': lambda x: x, 'tanh': np.tanh,
+            'relu': lambda x: np.maximum(x, 0.0), 'sigmoid': lambda x: 1.0 / (1.0 + np.exp(-x))}
+
+    def __init__(self, layers, nonlinearities, output_scale=1., use_bias=True, parameters=None):
+        self.layers = list(layers)
+        self.nonlinearities = list(nonlinearities)
+        self.output_scale = output_scale
+        self.use_bias = use_bias
+        self.parameters = [np.asarray(p, dtype=np.float64) for p in parameters]
+        self.input_dim = self.parameters[0].shape[0]
+        self.output_dim = self.layers[-1]
+
+    def __call__(self, points):
+        net = np.atleast_2d(np.asarray(points, dtype=np.float64))
+        it = iter(self.parameters)
+        for l, activation in enumerate(self.nonlinearities):
+            net = net.dot(next(it))                                         # :1708-1713 / :1717-1722
+            if self.use_bias and l < len(self.layers) - 1:
+                net = net + next(it)
+            net = self._ACT[activation](net)
+        return net * self.output_scale                                      # :1727
+
+
 class LyapunovNetwork(object):
     """``sum(phi(x)^2)`` with layer kernels ``[W^T W + eps I ; W']``.
 

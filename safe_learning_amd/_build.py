@@ -26,7 +26,7 @@ UNITS = [("sl_kernels", "sl_kernels.hip", []), ("sl_gp", "sl_gp.hip", []),
          ("sl_gp_small", "sl_gp_small.hip", []), ("sl_det_rows", "sl_det_rows.hip", []),
          ("sl_level", "sl_level.hip", []), ("sl_adaptive", "sl_adaptive.hip", []),
          ("sl_sample", "sl_sample.hip", []), ("sl_region", "sl_region.hip", []),
-         ("sl_succ", "sl_succ.hip", [])]
+         ("sl_succ", "sl_succ.hip", []), ("sl_policy_net", "sl_policy_net.hip", [])]
 UNITS += [("sl_gp4_d%d" % dim, "sl_gp4.hip", GP4_FLAGS + ["-DSL_GP4_DIM=%d" % dim]) for dim in (1, 2, 3, 4)]
 LIB = os.path.join(HERE, "libslhip.so")
 

@@ -22,7 +22,7 @@ MAX_NN_LAYERS = 4
 MAX_SIMPLICES = 32
 
 # enum values of include/sl_hip.h
-POLICY_LINEAR, POLICY_CONST, POLICY_TABLE, POLICY_TRI = 1, 2, 3, 4
+POLICY_LINEAR, POLICY_CONST, POLICY_TABLE, POLICY_TRI, POLICY_NETWORK = 1, 2, 3, 4, 5
 DYN_LINEAR, DYN_PENDULUM, DYN_CARTPOLE, DYN_GP = 1, 2, 3, 4
 V_QUADRATIC, V_TRI, V_NETWORK = 1, 2, 3
 LIP_CONST, LIP_ABS_LINEAR, LIP_NORM_LINEAR, LIP_ABS_GRAD, LIP_NORM_GRAD = 0, 1, 2, 3, 4
@@ -116,7 +116,7 @@ EXPORTS = [
     "sl_version", "sl_ctx_create", "sl_ctx_destroy", "sl_last_error", "sl_ctx_synchronize",
     "sl_last_kernel",
     "sl_model_set", "sl_gp_set_head", "sl_gp_set_head_kernel", "sl_gp_append_point", "sl_gp_configure", "sl_tri_set", "sl_tri_set_table",
-    "sl_network_set", "sl_values", "sl_lyap_sweep", "sl_lyap_finalize", "sl_select_pass",
+    "sl_network_set", "sl_policy_network_set", "sl_values", "sl_lyap_sweep", "sl_lyap_finalize", "sl_select_pass",
     "sl_values_implicit", "sl_fold_results", "sl_lyap_finalize_dev", "sl_refinement_carry", "sl_select_begin",
     "sl_select_hist", "sl_select_digit",
     "sl_sort_pairs", "sl_partition_by_digit", "sl_gather_rows", "sl_adaptive_pack", "sl_adaptive_dest",
@@ -153,6 +153,7 @@ def load_library():
     lib.sl_version.restype = C.c_int
     lib.sl_last_error.restype = C.c_char_p
     lib.sl_last_error.argtypes = [C.c_void_p]
+    dev_early = bool(os.environ.get("SL_LIB_PATH"))
     lib.sl_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.sl_ctx_destroy.argtypes = [C.c_void_p]
     lib.sl_ctx_synchronize.argtypes = [C.c_void_p]
@@ -169,6 +170,9 @@ def load_library():
     lib.sl_tri_set_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.sl_network_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32),
                                    C.POINTER(C.c_int32), c_double_p]
+    if not dev_early or hasattr(lib, "sl_policy_network_set"):
+        lib.sl_policy_network_set.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                              c_double_p, c_double_p, C.POINTER(C.c_int32), C.c_double]
     lib.sl_values.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.sl_lyap_sweep.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]
@@ -362,6 +366,20 @@ class Context(object):
                                            dims.ctypes.data_as(C.POINTER(C.c_int32)),
                                            acts.ctypes.data_as(C.POINTER(C.c_int32)), pk),
                    "sl_network_set")
+
+    def policy_network_set(self, dims, activations, kernels, biases, output_scale):
+        """``sl_policy_network_set``: ``kernels[l]`` is ``[in, out]``, ``biases[l]`` an ``[out]`` array or None."""
+        dims = np.ascontiguousarray(dims, dtype=np.int32)
+        acts = np.ascontiguousarray(activations, dtype=np.int32)
+        flat, pk = _as_c(np.concatenate([np.asarray(k, dtype=np.float64).ravel() for k in kernels]))
+        has = np.ascontiguousarray([0 if b is None else 1 for b in biases], dtype=np.int32)
+        present = [np.asarray(b, dtype=np.float64).ravel() for b in biases if b is not None]
+        bflat, pb = _as_c(np.concatenate(present) if present else np.zeros(1))
+        self.check(self.lib.sl_policy_network_set(self.handle, len(acts),
+                                                  dims.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                  acts.ctypes.data_as(C.POINTER(C.c_int32)), pk, pb,
+                                                  has.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                  float(output_scale)), "sl_policy_network_set")
 
     # ---- passes --------------------------------------------------------------------------
     def values(self, lo, hi, d_values):

@@ -11,6 +11,7 @@ import numpy as np
 from . import _hip
 from .functions import (AbsFunction, CartPole, ConstantFunction, FunctionStack,
                         GaussianProcess, Gradient, InvertedPendulum, LinearSystem, LyapunovNetwork,
+                        NeuralNetwork,
                         Norm1Function, QuadraticFunction, Saturation, Triangulation, _gp_heads,
                         _is_plain_rbf)
 
@@ -27,6 +28,7 @@ class ModelBuilder(object):
         self._tri_structure = [None, None]
         self._net_signature = None
         self._policy_table = None
+        self._policy_net_signature = None
 
     # ---- pieces --------------------------------------------------------------------------
     def _write_policy(self, desc, policy):
@@ -57,6 +59,15 @@ class ModelBuilder(object):
             # (policy(states) in reinforcement_learning.py:92 / lyapunov.py:436)
             pd.kind = _hip.POLICY_TRI
             self._upload_tri(1, inner)
+        elif isinstance(inner, NeuralNetwork):
+            # evaluated once per cell of a call into an action table (sl_policy_net.hip)
+            dims, acts, kernels, biases = inner._layers_for_upload(d)
+            m = inner.output_dim
+            pd.kind = _hip.POLICY_NETWORK
+            signature = (id(inner), inner._version, inner.output_scale)
+            if signature != self._policy_net_signature:
+                self.ctx.policy_network_set(dims, acts, kernels, biases, inner.output_scale)
+                self._policy_net_signature = signature
         elif isinstance(inner, (np.ndarray, torch.Tensor)):
             # one action row per vertex / point; a device tensor is used in place
             if isinstance(inner, torch.Tensor):
@@ -71,7 +82,7 @@ class ModelBuilder(object):
             pd.d_table = self._policy_table.data_ptr()
         else:
             raise TypeError('unsupported policy spec %r: use LinearSystem, Saturation(LinearSystem), '
-                            'Triangulation, ConstantFunction or a per-vertex ndarray' % (policy,))
+                            'Triangulation, NeuralNetwork, ConstantFunction or a per-vertex ndarray' % (policy,))
         if m > _hip.MAX_ACTION_DIM:
             raise ValueError('at most %d action dimensions are supported' % _hip.MAX_ACTION_DIM)
         pd.m = m

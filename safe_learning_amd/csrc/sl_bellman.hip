@@ -883,6 +883,9 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
     SL_HIP_CHECK(ctx, hipMemsetAsync(d_stats, 0, 2 * sizeof(double), ctx->stream));
     ctx->last_kernel[0] = 0;
     if (hi == lo) return SL_OK;
+    // policy evaluation with a network policy: one action per vertex first (a max sweep ignores the policy)
+    SlPolicyTableScope network_policy(ctx, n_actions == 0 ? lo : 0, n_actions == 0 ? hi : 0, nullptr);
+    if (network_policy.rc) return network_policy.rc;
     // The successors of (vertex, action) do not depend on the value table
     // (reinforcement_learning.py:89-104): a sweep over a range / action set / dynamics that an
     // earlier max sweep located is served from the successor cache (sl_succ.hip); otherwise a max
@@ -1002,6 +1005,17 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
                  const double* d_values, uint64_t* d_neg_bits, sl_sweep_result* d_result,
                  double* d_dbg, const double* d_points);
 
+// rows 0 .. n-1 of a per-point action table through the policy's saturation
+__global__ __launch_bounds__(SL_BLOCK) void k_policy_rows(const SlDevModel M, int64_t n, double* __restrict__ out) {
+    const SlDims nd = sl_dims<0, 0>(M);
+    for (int64_t i = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * SL_BLOCK) {
+        double x[SL_P] = {}, u[SL_M];
+        sl_policy_any<false>(M, nd, nullptr, i, x, u);
+#pragma unroll
+        for (int a = 0; a < SL_M; ++a) if (a < nd.m) out[i * nd.m + a] = u[a];
+    }
+}
+
 extern "C" int sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_points,
                               double* d_out) {
     if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_eval_points: NULL context");
@@ -1009,7 +1023,19 @@ extern "C" int sl_eval_points(sl_ctx* ctx, int what, int64_t n, const double* d_
     if (n < 0 || !d_points || !d_out) return sl_fail(ctx, SL_ERR_INVALID, "sl_eval_points: bad argument");
     if (n == 0) return SL_OK;
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    // a network policy: one action per point first (V and L_v do not evaluate the policy)
+    const bool needs_policy = what == SL_EVAL_POLICY || what == SL_EVAL_DYNAMICS || what == SL_EVAL_DECREASE;
+    SlPolicyTableScope network_policy(ctx, 0, needs_policy ? n : 0, d_points);
+    if (network_policy.rc) return network_policy.rc;
     const SlDevModel& M = ctx->h_model;
+    if (what == SL_EVAL_POLICY && network_policy.swapped) {
+        // the action table IS the answer (saturated like every policy, functions.py:349-354)
+        int64_t b = (n + SL_BLOCK - 1) / SL_BLOCK;
+        if (b > SL_MAX_GRID) b = SL_MAX_GRID;
+        hipLaunchKernelGGL(k_policy_rows, dim3((unsigned)b), dim3(SL_BLOCK), 0, ctx->stream, ctx->h_model, n, d_out);
+        SL_HIP_CHECK(ctx, hipGetLastError());
+        return SL_OK;
+    }
     if (what == SL_EVAL_VALUE || what == SL_EVAL_POLICY || what == SL_EVAL_LV) {
         if (what == SL_EVAL_POLICY && M.m.policy.kind == SL_POLICY_TABLE)
             return sl_fail(ctx, SL_ERR_UNSUPPORTED, "a per-vertex policy table cannot be evaluated "

@@ -58,9 +58,24 @@ static inline constexpr int sl_diag_flags(const char*) { return 0; }
 #endif
 void sl_env_read(SlEnv* env);
 
+// A NeuralNetwork policy (sl_policy_net.hip): per layer the dense kernel [in][out] and an optional
+// bias at params + koff / boff (boff < 0: none), activation codes 0 linear, 1 tanh, 2 relu, 3 sigmoid.
+struct SlPolicyNet {
+    int32_t nlayers, set;
+    int32_t dims[SL_MAX_NN_LAYERS + 1];
+    int32_t act[SL_MAX_NN_LAYERS];
+    int32_t koff[SL_MAX_NN_LAYERS], boff[SL_MAX_NN_LAYERS];
+    double scale;
+    const double* params;
+};
+
 struct sl_ctx {
     int device = 0;
     SlEnv env;
+    SlPolicyNet pnet = {};
+    double* d_pnet_params = nullptr;
+    void* d_policy_actions = nullptr;      // per-cell action table of a network policy (one call's cells)
+    size_t policy_actions_bytes = 0;
     hipStream_t stream = nullptr;
     std::string error;
     bool model_set = false;
@@ -152,6 +167,20 @@ void sl_succ_commit(sl_ctx* ctx);
 // *done = 1 when the sweep was served from the cache
 int sl_succ_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const double* h_actions,
                   double* d_v_new, int32_t* d_argmax, double* d_q, double* d_stats, int* done);
+
+// Brackets an entry point that evaluates the policy: a network policy (SL_POLICY_NETWORK) is
+// evaluated once per cell of [lo, hi) (or per explicit point) into an action table and the model
+// the kernels see carries SL_POLICY_TABLE on it until the scope ends.  rc != SL_OK: give up.
+struct SlPolicyTableScope {
+    sl_ctx* ctx;
+    bool swapped;
+    int rc;
+    sl_policy_desc saved;
+    SlPolicyTableScope(sl_ctx* ctx, int64_t lo, int64_t hi, const double* d_points);
+    ~SlPolicyTableScope();
+    SlPolicyTableScope(const SlPolicyTableScope&) = delete;
+    SlPolicyTableScope& operator=(const SlPolicyTableScope&) = delete;
+};
 
 extern thread_local std::string g_sl_last_error;
 

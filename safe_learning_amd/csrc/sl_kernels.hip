@@ -138,6 +138,8 @@ extern "C" int sl_ctx_destroy(sl_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_gp4_seeds) (void)hipFree(ctx->d_gp4_seeds);
     if (ctx->d_policy_cache) (void)hipFree(ctx->d_policy_cache);
+    if (ctx->d_pnet_params) (void)hipFree(ctx->d_pnet_params);
+    if (ctx->d_policy_actions) (void)hipFree(ctx->d_policy_actions);
     if (ctx->succ.d) (void)hipFree(ctx->succ.d);
     if (ctx->succ.d_select) (void)hipFree(ctx->succ.d_select);
     if (ctx->d_records) (void)hipFree(ctx->d_records);
@@ -191,7 +193,7 @@ extern "C" int sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model) {
     if (p.m < 1 || p.m > SL_MAX_ACTION_DIM)
         return sl_fail(ctx, SL_ERR_INVALID, "action dimension %d outside [1,%d]", p.m,
                        SL_MAX_ACTION_DIM);
-    if (p.kind < SL_POLICY_LINEAR || p.kind > SL_POLICY_TRI)
+    if (p.kind < SL_POLICY_LINEAR || p.kind > SL_POLICY_NETWORK)
         return sl_fail(ctx, SL_ERR_INVALID, "unknown policy kind %d", p.kind);
     if (p.kind == SL_POLICY_TABLE && !p.d_table)
         return sl_fail(ctx, SL_ERR_INVALID, "table policy without a table");
@@ -761,6 +763,8 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
     // with explicit points a TABLE policy is indexed by the point number (one action per point)
     if (!d_neg_bits || !d_result) return sl_fail(ctx, SL_ERR_INVALID, "sl_lyap_sweep: NULL output");
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SlPolicyTableScope network_policy(ctx, lo, hi, d_points);   // (a network policy becomes a per-cell table)
+    if (network_policy.rc) return network_policy.rc;
     int blocks = 1;
     ctx->last_kernel[0] = 0;
     if (hi == lo) {

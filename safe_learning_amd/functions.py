@@ -47,7 +47,8 @@ _TOKENS = itertools.count(1)
 __all__ = ['GridWorld', 'DimensionError', 'DeterministicFunction', 'UncertainFunction',
            'QuadraticFunction', 'LinearSystem', 'Saturation', 'AbsFunction', 'Norm1Function',
            'AbsGradient', 'Gradient', 'ConstantFunction', 'RBF', 'Matern32', 'Linear', 'GPRCached', 'GaussianProcess',
-           'FunctionStack', 'Triangulation', 'InvertedPendulum', 'CartPole', 'LyapunovNetwork']
+           'FunctionStack', 'Triangulation', 'InvertedPendulum', 'CartPole', 'LyapunovNetwork',
+           'NeuralNetwork']
 
 
 class DimensionError(Exception):
@@ -831,6 +832,102 @@ def _write_norm(desc, normalization, inv_norm, d):
 # ----------------------------------------------------------------------------------------------
 
 _ACTIVATIONS = {None: 0, 'linear': 0, 'tanh': 1, 'relu': 2}
+
+
+class NeuralNetwork(DeterministicFunction):
+    """A chain of dense layers as a POLICY (``functions.py:1663-1729``; the policy of
+    ``examples/inverted_pendulum.ipynb:215`` and of the reinforcement-learning notebooks).
+
+    ``layers`` are the units of every dense layer (``build_evaluation``, ``:1702-1725``: one
+    ``tf.layers.dense`` per entry, the input width is the data's), ``nonlinearities`` one entry per
+    layer - ``'relu'``, ``'tanh'``, ``'sigmoid'`` or ``None`` (the reference passes TensorFlow
+    callables; the names of the ones it uses are accepted here) -, ``output_scale`` multiplies the
+    output (``:1727-1728``); with ``use_bias`` every layer but the last has a bias (``:1712, 1722``).
+
+    The reference's parameters are TensorFlow variables (Xavier initialisation, trained by SGD -
+    outside this package's scope): here they are given, ``parameters = [W_0, b_0, W_1, b_1, ...,
+    W_out]`` in the reference's variable order (``_parameter_iter``, ``:1731-1740``; ``W_l`` is
+    ``[in, units]``; without biases just the ``W_l``), or drawn Xavier-uniform from ``seed`` once
+    ``input_dim`` is known.  Assigning ``parameters`` again (or calling :meth:`touch` after editing the
+    arrays in place) makes the engine upload them again."""
+
+    _role = 'policy'
+    _ACTIVATIONS = {None: 0, 'linear': 0, 'tanh': 1, 'relu': 2, 'sigmoid': 3}
+
+    def __init__(self, layers, nonlinearities, output_scale=1., use_bias=True, name='neural_network',
+                 input_dim=None, parameters=None, seed=0):
+        self.layers = [int(v) for v in layers]
+        self.nonlinearities = [getattr(a, '__name__', a) for a in nonlinearities]
+        if len(self.nonlinearities) != len(self.layers):
+            raise ValueError('one nonlinearity (or None) per layer')
+        for a in self.nonlinearities:
+            if a not in self._ACTIVATIONS:
+                raise TypeError('nonlinearity %r: the engine has relu, tanh, sigmoid and None' % (a,))
+        self.output_scale = float(output_scale)
+        self.use_bias = bool(use_bias)
+        self.name = name
+        self.output_dim = self.layers[-1]
+        self.input_dim = None if input_dim is None else int(input_dim)
+        self._parameters = None
+        self._version = next(_TOKENS)
+        self._seed = seed
+        if parameters is not None:
+            self.parameters = parameters
+        elif input_dim is not None:
+            self._initialise()
+
+    def _shapes(self):
+        widths = [self.input_dim] + self.layers
+        shapes = []
+        for l in range(len(self.layers)):
+            shapes.append((widths[l], widths[l + 1]))
+            if self.use_bias and l < len(self.layers) - 1:
+                shapes.append((widths[l + 1],))
+        return shapes
+
+    def _initialise(self):
+        rng = np.random.default_rng(self._seed)
+        params = []
+        for shape in self._shapes():
+            if len(shape) == 2:                       # tf.contrib.layers.xavier_initializer (uniform)
+                params.append(rng.uniform(-1, 1, shape) * np.sqrt(6. / (shape[0] + shape[1])))
+            else:
+                params.append(np.zeros(shape))        # tf.layers.dense: zero bias
+        self.parameters = params
+
+    @property
+    def parameters(self):
+        return self._parameters
+
+    @parameters.setter
+    def parameters(self, values):
+        values = [np.asarray(v, dtype=config.np_dtype) for v in values]
+        if self.input_dim is None:
+            self.input_dim = int(values[0].shape[0])
+        if [v.shape for v in values] != self._shapes():
+            raise ValueError('parameters must have shapes %s' % (self._shapes(),))
+        self._parameters = values
+        self._version = next(_TOKENS)
+
+    def touch(self):
+        """Say that the parameter arrays were edited in place."""
+        self._version = next(_TOKENS)
+
+    def _layers_for_upload(self, d):
+        """``(dims, activation codes, kernels, biases)`` of the chain for a d-dimensional state."""
+        if self.input_dim is None:
+            self.input_dim = int(d)
+            self._initialise()
+        if self.input_dim != d:
+            raise ValueError('the network expects %d inputs, the grid has %d dimensions'
+                             % (self.input_dim, d))
+        it = iter(self._parameters)
+        kernels, biases = [], []
+        for l in range(len(self.layers)):
+            kernels.append(next(it))
+            biases.append(next(it) if (self.use_bias and l < len(self.layers) - 1) else None)
+        return ([self.input_dim] + self.layers, [self._ACTIVATIONS[a] for a in self.nonlinearities],
+                kernels, biases)
 
 
 class LyapunovNetwork(DeterministicFunction):
