@@ -413,14 +413,14 @@ def run_rank(args, rank, world, local_rank, backend):
             obj.successor_cache(0)
             obj.value_iteration(actions)
             barrier()
-            obj.sweep_events = []
+            obj._ctx.timing_configure(8)
             t0 = time.perf_counter()
             for _ in range(3):
                 obj.value_iteration(actions)
             barrier()
             un_ms = 1e3 * (time.perf_counter() - t0) / 3
-            un_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in obj.sweep_events]))
-            obj.sweep_events = None
+            un_kernel_ms = float(np.mean(obj._ctx.timing_collect(obj._ctx.TIMING_BELLMAN)))
+            obj._ctx.timing_configure(0)
             extra["uncached_sweep"] = {"ms_per_sweep": un_ms, "kernel_ms": un_kernel_ms,
                                        "kernel": obj._ctx.last_kernel()}
             obj.successor_cache(-1)
@@ -436,8 +436,9 @@ def run_rank(args, rank, world, local_rank, backend):
     for _ in range(args.warmup):
         step()
     barrier()
-    obj.sweep_events = []                         # HIP events around the dominant kernel
-    obj.finalize_events = []                      # ... and around the streaming pass (k_finalize_dev)
+    # HIP events around the dominant kernel and around the streaming pass (k_finalize_dev), recorded
+    # by the library on the stream it launches on (sl_timing_configure: events made here, not per step)
+    obj._ctx.timing_configure(4 * args.steps + 16)
     dist_utils.start_timing()                     # device events around every collective
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -446,10 +447,9 @@ def run_rank(args, rank, world, local_rank, backend):
     barrier()
     elapsed = time.perf_counter() - t0
     collective_ms = dist_utils.stop_timing() / max(args.steps, 1)
-    kernel_ms = [a.elapsed_time(b) for a, b in obj.sweep_events]
-    finalize_ms = [a.elapsed_time(b) for a, b in (getattr(obj, "finalize_events", None) or [])]
-    obj.sweep_events = None
-    obj.finalize_events = None
+    kernel_ms = obj._ctx.timing_collect(obj._ctx.TIMING_LYAP_SWEEP if kind == "lyapunov" else obj._ctx.TIMING_BELLMAN)
+    finalize_ms = obj._ctx.timing_collect(obj._ctx.TIMING_FINALIZE)
+    obj._ctx.timing_configure(0)
     avg_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     per_rank = [elapsed, avg_ms, collective_ms, 1e3 * own_elapsed / max(args.steps, 1)]
     if grouped:

@@ -150,6 +150,15 @@ SL_API int  sl_ctx_synchronize(sl_ctx* ctx);
  * "k_gp_sweep<...> + k_nn_check_mfma<...>" for a two-pass sweep; "" before the first sweep.  The
  * string lives in the context and is overwritten by the next sweep. */
 SL_API const char* sl_last_kernel(const sl_ctx* ctx);
+/* Kernel durations for benchmarks.  With slots > 0 every sl_lyap_sweep (channel 0),
+ * sl_lyap_finalize_dev (channel 1) and sl_bellman_sweep (channel 2) brackets its launches with a pair
+ * of HIP events on the context's stream, up to `slots` calls per channel (later calls are not
+ * recorded); the events are created here, not per call.  slots = 0 switches it off and frees them.
+ * sl_timing_collect waits for the recorded calls of one channel, writes their durations in
+ * milliseconds to h_ms (at most `capacity`), the number written to *count, and empties the channel.
+ * (The reference has no counterpart: its timings are the notebooks' wall clocks.) */
+SL_API int  sl_timing_configure(sl_ctx* ctx, int slots);
+SL_API int  sl_timing_collect(sl_ctx* ctx, int channel, double* h_ms, int capacity, int* count);
 
 /* ---- model upload (copies; replaces the TF graph build of lyapunov.py:431-443) --------- */
 SL_API int  sl_model_set(sl_ctx* ctx, const sl_model_desc* h_model);

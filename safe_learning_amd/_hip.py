@@ -124,7 +124,7 @@ EXPORTS = [
     "sl_index_to_state", "sl_perturb_pairs", "sl_rows_sort_key", "sl_rows_duplicate_flags",
     "sl_sample_bounds", "sl_state_membership", "sl_argmax_masked", "sl_argmax_rows_masked", "sl_lyapunov_region",
     "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_successor_cache_configure",
-    "sl_successor_cache_info", "sl_eval_points",
+    "sl_successor_cache_info", "sl_eval_points", "sl_timing_configure", "sl_timing_collect",
     "sl_comm_unique_id", "sl_comm_init", "sl_comm_destroy", "sl_allreduce_result", "sl_allgather",
     "sl_allreduce_sum_u64", "sl_allreduce_max_f64",
     "sl_debug_mfma", "sl_debug_mfma4", "sl_debug_fp64_rate", "sl_debug_gp_inputs",
@@ -220,6 +220,9 @@ def load_library():
         lib.sl_successor_cache_configure.argtypes = [C.c_void_p, C.c_int64]
         lib.sl_successor_cache_info.argtypes = [C.c_void_p, C.POINTER(SuccessorCacheStats)]
     lib.sl_eval_points.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+    if not dev or hasattr(lib, "sl_timing_configure"):
+        lib.sl_timing_configure.argtypes = [C.c_void_p, C.c_int]
+        lib.sl_timing_collect.argtypes = [C.c_void_p, C.c_int, c_double_p, C.c_int, C.POINTER(C.c_int)]
     lib.sl_comm_unique_id.argtypes = [C.c_char_p]
     lib.sl_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
     lib.sl_comm_destroy.argtypes = [C.c_void_p]
@@ -565,6 +568,25 @@ class Context(object):
 
     def synchronize(self):
         self.check(self.lib.sl_ctx_synchronize(self.handle), "sl_ctx_synchronize")
+
+    TIMING_LYAP_SWEEP, TIMING_FINALIZE, TIMING_BELLMAN = 0, 1, 2
+
+    def timing_configure(self, slots):
+        """``sl_timing_configure``: the library records HIP events around up to ``slots`` calls of
+        each of its sweep entry points (0: off)."""
+        self.check(self.lib.sl_timing_configure(self.handle, int(slots)), "sl_timing_configure")
+        self._timing_slots = int(slots)
+
+    def timing_collect(self, channel):
+        """Durations (ms) of the calls recorded on ``channel`` since the last collect."""
+        slots = getattr(self, "_timing_slots", 0)
+        if not slots:
+            return []
+        out = (C.c_double * slots)()
+        count = C.c_int(0)
+        self.check(self.lib.sl_timing_collect(self.handle, int(channel), out, slots, C.byref(count)),
+                   "sl_timing_collect")
+        return [float(out[i]) for i in range(count.value)]
 
     def last_kernel(self):
         """Name of the kernel(s) the last sweep of this context launched (``sl_last_kernel``)."""

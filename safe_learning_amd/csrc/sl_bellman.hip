@@ -849,6 +849,7 @@ extern "C" int sl_bellman_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actio
                                 const double* h_actions, double* d_v_new, int32_t* d_argmax,
                                 double* d_q, double* d_stats) {
     if (!ctx) return sl_fail(nullptr, SL_ERR_INVALID, "sl_bellman_sweep: NULL context");
+    SlTimed timed(ctx, 2);
     if (!ctx->model_set) return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: call sl_model_set first");
     if (!ctx->h_tri[0].set)
         return sl_fail(ctx, SL_ERR_INVALID, "sl_bellman_sweep: value table (sl_tri_set slot 0) not set");

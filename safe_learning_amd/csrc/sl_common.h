@@ -12,6 +12,7 @@
 #include "sl_model.h"
 
 #define SL_BLOCK 256
+#define SL_TIMING_CHANNELS 3
 #define SL_MAX_ACTIONS 16                 // actions of a Bellman max sweep (sl_bellman_sweep)
 #define SL_MAX_GRID 2048
 
@@ -108,6 +109,13 @@ struct sl_ctx {
     void* d_comm_records = nullptr;    // [world] gathered sl_sweep_result records
     int comm_rank = 0, comm_world = 1;
     char last_kernel[160] = "";        // dominant kernel(s) of the last sweep call (sl_last_kernel)
+    // sl_timing_configure: pairs of HIP events around the launches of an entry point, on the stream
+    // they go to (channel 0: sl_lyap_sweep, 1: sl_lyap_finalize_dev, 2: sl_bellman_sweep)
+    struct Timing {
+        int slots = 0;
+        int used[SL_TIMING_CHANNELS] = {0, 0, 0};
+        hipEvent_t* events[SL_TIMING_CHANNELS] = {nullptr, nullptr, nullptr};   // [2 * slots] each
+    } timing;
     // k_bellman4_policy: what is derived from the policy alone (its action at every cell, the
     // distinct values, the tile order) is kept between sweeps as long as the policy is the same
     void* d_policy_cache = nullptr;
@@ -167,6 +175,23 @@ void sl_succ_commit(sl_ctx* ctx);
 // *done = 1 when the sweep was served from the cache
 int sl_succ_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, int n_actions, const double* h_actions,
                   double* d_v_new, int32_t* d_argmax, double* d_q, double* d_stats, int* done);
+
+// Brackets an entry point's launches with a pair of events when sl_timing_configure asked for it
+// (bench.py's kernel durations: recorded by the library on its own stream, no host objects per call)
+struct SlTimed {
+    sl_ctx* ctx;
+    int channel, slot;
+    SlTimed(sl_ctx* c, int ch) : ctx(c), channel(ch), slot(-1) {
+        if (!c || c->timing.slots <= c->timing.used[ch]) return;
+        slot = c->timing.used[ch];
+        (void)hipEventRecord(c->timing.events[ch][2 * slot], c->stream);
+    }
+    ~SlTimed() {
+        if (slot < 0) return;
+        (void)hipEventRecord(ctx->timing.events[channel][2 * slot + 1], ctx->stream);
+        ctx->timing.used[channel] = slot + 1;
+    }
+};
 
 // Brackets an entry point that evaluates the policy: a network policy (SL_POLICY_NETWORK) is
 // evaluated once per cell of [lo, hi) (or per explicit point) into an action table and the model

@@ -143,11 +143,54 @@ extern "C" int sl_ctx_destroy(sl_ctx* ctx) {
     if (ctx->succ.d) (void)hipFree(ctx->succ.d);
     if (ctx->succ.d_select) (void)hipFree(ctx->succ.d_select);
     if (ctx->d_records) (void)hipFree(ctx->d_records);
+    (void)sl_timing_configure(ctx, 0);
     (void)hipFree(ctx->d_partials);
     (void)hipFree(ctx->d_partial_counts);
     (void)hipFree(ctx->d_ticket);
     (void)hipFree(ctx->d_actions);
     delete ctx;
+    return SL_OK;
+}
+
+// ---- kernel timing for benchmarks ---------------------------------------------------------------
+extern "C" int sl_timing_configure(sl_ctx* ctx, int slots) {
+    if (!ctx || slots < 0) return sl_fail(ctx, SL_ERR_INVALID, "sl_timing_configure: bad argument");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    for (int ch = 0; ch < SL_TIMING_CHANNELS; ++ch) {
+        if (ctx->timing.events[ch]) {
+            for (int e = 0; e < 2 * ctx->timing.slots; ++e) (void)hipEventDestroy(ctx->timing.events[ch][e]);
+            delete[] ctx->timing.events[ch];
+            ctx->timing.events[ch] = nullptr;
+        }
+        ctx->timing.used[ch] = 0;
+    }
+    ctx->timing.slots = 0;
+    if (!slots) return SL_OK;
+    for (int ch = 0; ch < SL_TIMING_CHANNELS; ++ch) {
+        ctx->timing.events[ch] = new (std::nothrow) hipEvent_t[2 * (size_t)slots]();
+        if (!ctx->timing.events[ch]) return sl_fail(ctx, SL_ERR_NOMEM, "sl_timing_configure: out of host memory");
+    }
+    ctx->timing.slots = slots;
+    for (int ch = 0; ch < SL_TIMING_CHANNELS; ++ch)
+        for (int e = 0; e < 2 * slots; ++e) SL_HIP_CHECK(ctx, hipEventCreate(&ctx->timing.events[ch][e]));
+    return SL_OK;
+}
+
+extern "C" int sl_timing_collect(sl_ctx* ctx, int channel, double* h_ms, int capacity, int* count) {
+    if (!ctx || channel < 0 || channel >= SL_TIMING_CHANNELS || !count || capacity < 0 || (capacity && !h_ms))
+        return sl_fail(ctx, SL_ERR_INVALID, "sl_timing_collect: bad argument");
+    SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const int used = ctx->timing.used[channel];
+    int n = 0;
+    for (int s = 0; s < used && n < capacity; ++s, ++n) {
+        float ms = 0.f;
+        SL_HIP_CHECK(ctx, hipEventSynchronize(ctx->timing.events[channel][2 * s + 1]));
+        SL_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->timing.events[channel][2 * s],
+                                              ctx->timing.events[channel][2 * s + 1]));
+        h_ms[n] = (double)ms;
+    }
+    *count = n;
+    ctx->timing.used[channel] = 0;
     return SL_OK;
 }
 
@@ -889,6 +932,7 @@ int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bit
 extern "C" int sl_lyap_sweep(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,
                              const double* d_values, uint64_t* d_neg_bits,
                              sl_sweep_result* d_result, double* d_dbg) {
+    SlTimed timed(ctx, 0);
     return sl_sweep_any(ctx, lo, hi, d_init_bits, d_values, d_neg_bits, d_result, d_dbg, nullptr);
 }
 

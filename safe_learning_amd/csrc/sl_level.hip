@@ -45,7 +45,8 @@ __global__ __launch_bounds__(SL_BLOCK) void k_finalize_dev(
     const SlDevModel M_arg, int64_t lo, int64_t hi, const double* __restrict__ values,
     const uint8_t* __restrict__ init_bytes, const uint8_t* __restrict__ prev_bytes,
     const sl_sweep_result* __restrict__ folded, const sl_key* __restrict__ keep_ptr,
-    uint8_t* __restrict__ safe_bytes, sl_key* __restrict__ partials, int64_t* __restrict__ counts) {
+    uint8_t* __restrict__ safe_bytes, sl_key* __restrict__ partials, int64_t* __restrict__ counts,
+    int span_groups, int vector_ok) {
     __shared__ uint64_t sv[SL_BLOCK / 64];
     __shared__ int64_t si[SL_BLOCK / 64];
     __shared__ int64_t sc[2][SL_BLOCK / 64];
@@ -60,14 +61,31 @@ __global__ __launch_bounds__(SL_BLOCK) void k_finalize_dev(
     int64_t ls_i = -1, mx_i = -1;
     int64_t n_below = 0, n_safe = 0;
     SlRowValues<DT> row;
-    const int64_t span = (int64_t)SL_BLOCK * CPT;
-    for (int64_t base = lo + (int64_t)blockIdx.x * span; base < hi; base += (int64_t)gridDim.x * span) {
-        const int64_t i0 = base + (int64_t)threadIdx.x * CPT;
-        if (i0 >= hi) continue;
-        const unsigned init8 = init_bytes ? init_bytes[(i0 - lo) >> 3] : 0u;
-        const unsigned prev8 = prev_bytes ? prev_bytes[(i0 - lo) >> 3] : 0u;
+    // Rows far above the level (nearly all of a large grid): one bound and one exact value per SPAN
+    // of a row instead of every cell (SlRowValues::span_bounded; the launcher sets span_groups > 0 for
+    // a quadratic V recomputed from the index, not negated, can_shrink = True - no previous set to
+    // keep; with no failing key vstar is NaN and nothing is skipped)
+    const bool bounded = DT > 0 && span_groups > 0;
+    const double vstar = sl_vbits_to_double(star.vbits);
+    const double margin = bounded ? SlRowValues<DT>::error_margin(M) : 0.0;
+    // one group of eight cells (one byte of every mask) -> its safe bits; the statistics go to the
+    // thread's running values.  Indices ascend over a thread's groups: ">=" on the value bits alone
+    // keeps the lexicographic maxima.
+    auto group = [&](int64_t i0, unsigned init8, unsigned prev8) -> unsigned {
         double v8[CPT];
-        row.eight(M, values, lo, hi, i0, v8);
+        if (bounded && i0 + CPT <= hi) {
+            const int top = row.eight_bounded(M, i0, vstar, margin, v8);
+            if (top >= 0) {
+                // every cell is above key*: the safe bits are the initial set's; the cell with the
+                // largest value is the only candidate for the range's largest key
+                const uint64_t vb = sl_vbits_fast(v8[top]);
+                if (vb >= mx_v) { mx_v = vb; mx_i = i0 + top; }
+                n_safe += __popc(init8);
+                return init8;
+            }
+        } else {
+            row.eight(M, values, lo, hi, i0, v8);
+        }
         unsigned safe8 = 0u;
         auto one = [&](int c) {
             const int64_t idx = i0 + c;
@@ -76,8 +94,6 @@ __global__ __launch_bounds__(SL_BLOCK) void k_finalize_dev(
             const bool kept = ((prev8 >> c) & 1u) && !sl_key_less(vb, idx, keep.vbits, keep.index);
             const bool safe = below || kept || ((init8 >> c) & 1u);
             safe8 |= safe ? (1u << c) : 0u;
-            // indices ascend inside a thread (and a thread's cells lie behind those of its
-            // earlier iterations): ">=" on the value bits alone keeps the lexicographic max
             if (below) { ++n_below; if (vb >= ls_v) { ls_v = vb; ls_i = idx; } }
             if (vb >= mx_v) { mx_v = vb; mx_i = idx; }
         };
@@ -87,8 +103,53 @@ __global__ __launch_bounds__(SL_BLOCK) void k_finalize_dev(
         } else {
             for (int c = 0; c < CPT; ++c) if (i0 + c < hi) one(c);
         }
-        safe_bytes[(i0 - lo) >> 3] = (uint8_t)safe8;
         n_safe += __popc(safe8);
+        return safe8;
+    };
+    if (bounded) {
+        // One SPAN of span_groups bytes (a whole row of the last axis, or an aligned part of it: at
+        // most 16 bytes) per thread and iteration: one bound for the span, and where it holds one
+        // exact cell and a copy of the initial set's bytes.  Spans the bound does not clear fall
+        // back to their groups of eight (bounded again one by one, then exact).
+        const int span_cells = span_groups * CPT;
+        const int64_t nthreads = (int64_t)gridDim.x * SL_BLOCK;
+        for (int64_t s = (int64_t)blockIdx.x * SL_BLOCK + threadIdx.x;; s += nthreads) {
+            const int64_t i0 = lo + s * span_cells;
+            if (i0 >= hi) break;
+            const int64_t byte0 = (i0 - lo) >> 3;
+            if (i0 + span_cells <= hi) {
+                double vt;
+                const int top = row.span_bounded(M, i0, span_cells, vstar, margin, &vt);
+                if (top >= 0) {
+                    const uint64_t vb = sl_vbits_fast(vt);
+                    if (vb >= mx_v) { mx_v = vb; mx_i = i0 + top; }
+                    if (span_groups == 16 && vector_ok) {
+                        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+                        if (init_bytes) w = *reinterpret_cast<const uint4*>(init_bytes + byte0);
+                        n_safe += __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+                        *reinterpret_cast<uint4*>(safe_bytes + byte0) = w;
+                    } else {
+                        for (int q = 0; q < span_groups; ++q) {
+                            const unsigned init8 = init_bytes ? init_bytes[byte0 + q] : 0u;
+                            n_safe += __popc(init8);
+                            safe_bytes[byte0 + q] = (uint8_t)init8;
+                        }
+                    }
+                    continue;
+                }
+            }
+            for (int64_t j0 = i0; j0 < i0 + span_cells && j0 < hi; j0 += CPT)
+                safe_bytes[(j0 - lo) >> 3] = (uint8_t)group(j0, init_bytes ? init_bytes[(j0 - lo) >> 3] : 0u, 0u);
+        }
+    } else {
+        const int64_t span = (int64_t)SL_BLOCK * CPT;
+        for (int64_t base = lo + (int64_t)blockIdx.x * span; base < hi; base += (int64_t)gridDim.x * span) {
+            const int64_t i0 = base + (int64_t)threadIdx.x * CPT;
+            if (i0 >= hi) continue;
+            const unsigned init8 = init_bytes ? init_bytes[(i0 - lo) >> 3] : 0u;
+            const unsigned prev8 = prev_bytes ? prev_bytes[(i0 - lo) >> 3] : 0u;
+            safe_bytes[(i0 - lo) >> 3] = (uint8_t)group(i0, init8, prev8);
+        }
     }
     for (int off = 32; off >= 1; off >>= 1) {
         n_below += __shfl_xor((long long)n_below, off, 64);
@@ -344,7 +405,22 @@ extern "C" int sl_lyap_finalize_dev(sl_ctx* ctx, int64_t lo, int64_t hi, const d
     int rc = dim_variant(ctx, d_values, "sl_lyap_finalize_dev", &dt);
     if (rc) return rc;
     SL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const int blocks = (hi == lo) ? 0 : blocks_for(ctx, hi - lo);
+    SlTimed timed(ctx, 1);
+    int blocks = (hi == lo) ? 0 : blocks_for(ctx, hi - lo);
+    // The bounded pass (SlRowValues::span_bounded): a quadratic V recomputed from the index, not
+    // negated, can_shrink = True (no previous set to keep).  A thread's span: the largest part of a
+    // row of the last axis, at most 16 bytes of the masks, that the range starts on a multiple of.
+    int span_groups = 0, vector_ok = 0;
+    if (blocks && dt > 0 && !d_prev_bits && !ctx->h_model.m.value.negate) {
+        const int64_t row_groups = ctx->h_model.m.grid.num_points[dt - 1] / CPT;
+        for (int g = 16; g >= 1 && !span_groups; --g)
+            if (row_groups % g == 0 && lo % ((int64_t)g * CPT) == 0) span_groups = g;
+        vector_ok = (reinterpret_cast<uintptr_t>(d_safe_bits) % 16 == 0) &&
+                    (reinterpret_cast<uintptr_t>(d_init_bits) % 16 == 0);
+        const int64_t spans = (hi - lo + (int64_t)span_groups * CPT - 1) / ((int64_t)span_groups * CPT);
+        const int64_t need = (spans + SL_BLOCK - 1) / SL_BLOCK;
+        if (need < blocks) blocks = (int)need;
+    }
     if (blocks) {
         if ((hi - lo) & 63)     // whole bytes are written: clear the rest of the last mask word first
             SL_HIP_CHECK(ctx, hipMemsetAsync(d_safe_bits + ((hi - lo) >> 6), 0, sizeof(uint64_t), ctx->stream));
@@ -354,7 +430,7 @@ extern "C" int sl_lyap_finalize_dev(sl_ctx* ctx, int64_t lo, int64_t hi, const d
 #define SL_FIN(D_)                                                                                  \
     hipLaunchKernelGGL(k_finalize_dev<D_>, dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream,            \
                        ctx->h_model, lo, hi, d_values, init_bytes, prev_bytes, d_folded, d_keep,    \
-                       safe_bytes, ctx->d_partials, ctx->d_partial_counts)
+                       safe_bytes, ctx->d_partials, ctx->d_partial_counts, span_groups, vector_ok)
         switch (dt) {
             case 1: SL_FIN(1); break;
             case 2: SL_FIN(2); break;

@@ -1297,4 +1297,96 @@ struct SlRowValues {
             v8[c] = cell(M);
         }
     }
+
+    // Rounding-error bound of one computed V on this grid, times a safety factor: every computed
+    // value is within (2 D + 2) u sum_jk |x_j| |P_jk| |x_k| of the real quadratic form (u = 2^-53);
+    // 1e-13 of the same sum with the coordinates replaced by their largest magnitudes on the grid
+    // is 90 times that at D = 4.
+    SL_HD static double error_margin(const SlDevModel& M) {
+        double xmax[D], sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xmax[k] = fmax(fabs(M.m.grid.offset[k]), fabs(M.m.grid.upper[k]));
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int k = 0; k < D; ++k) sum += xmax[j] * fabs(M.m.value.matrix[j][k]) * xmax[k];
+        return 1e-13 * sum;
+    }
+
+    // Are the `ncells` consecutive cells from i0 on (all in ONE row of the last axis) PROVABLY all
+    // above vstar - the level the streaming pass of update_safe_set compares with (lyapunov.py:590-606;
+    // the level set holds 1.3e5 of the 2.7e8 cells of the 128^4 grid: nearly every row lies far outside
+    // it)?  Along the row V is the quadratic c + b t + a t^2 in the last coordinate t.  Where it is
+    // strictly monotone over the span - neighbouring cells apart by more than the rounding of two
+    // computed values, so that the COMPUTED values are monotone too - its smallest value sits at one
+    // end (bounded below by the real-arithmetic value there minus the margin) and its largest at the
+    // other; where the row's minimum lies inside the span (a > 0) the bound is the vertex value and
+    // the largest cell is the end farther from it, if it beats the other end and its own neighbour by
+    // more than the rounding (V is convex: no cell between them is larger than both).  Then only that
+    // largest cell is evaluated, exactly, in the reference's order (it is the span's candidate for
+    // the range's largest key, lyapunov.py:590-595 when the first cell fails): returns its offset
+    // (0 or ncells - 1) with *v_top set; -1: nothing is known, nothing was evaluated.  NaN anywhere
+    // makes the comparisons false.  DT > 0, no negation.  Leaves ijk[L] at the span's first cell.
+    SL_HD int span_bounded(const SlDevModel& M, int64_t i0, int ncells, double vstar, double margin,
+                           double* v_top) {
+        start_row(M, i0);
+        const int first = (int)ijk[L];
+        point(M, L);
+        const double t0 = x[L];
+        ijk[L] = first + (ncells - 1);
+        point(M, L);
+        const double t7 = x[L];
+        ijk[L] = first;
+        const double a = M.m.value.matrix[L][L];
+        double b = L > 0 ? lin_pre[L] : 0.0, c = 0.0;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            b += M.m.value.matrix[L][j] * x[j];
+            c += lin_pre[j] * x[j];
+        }
+        const double vt0 = c + t0 * (b + a * t0), vt7 = c + t7 * (b + a * t7);
+        const double d0 = 2.0 * a * t0 + b, d7 = 2.0 * a * t7 + b;       // V'(t) at the two ends
+        const double h = M.m.grid.unit_maxes[L];
+        const bool monotone = (d0 > 0.0 && d7 > 0.0) || (d0 < 0.0 && d7 < 0.0);
+        int top = -1;
+        double lower = 0.0;
+        if (monotone) {
+            // least step between neighbouring cells: h (min |V'| - |a| h)
+            if (h * (fmin(fabs(d0), fabs(d7)) - fabs(a) * h) > 4.0 * margin) {
+                top = d0 > 0.0 ? ncells - 1 : 0;
+                lower = fmin(vt0, vt7);
+            }
+        } else if (a > 0.0 && d0 < 0.0 && d7 > 0.0) {
+            // the row's minimum lies inside the span (every whole row of a grid around the origin;
+            // one group of eight in sixteen of a 128-cell row): V >= c - b^2 / 4a
+            const bool right = vt7 > vt0;
+            const double dtop = right ? d7 : -d0;
+            if (fabs(vt7 - vt0) > 4.0 * margin && h * (dtop - a * h) > 4.0 * margin) {
+                top = right ? ncells - 1 : 0;
+                lower = c - (b * b) / (4.0 * a) - margin;
+            }
+        }
+        if (top >= 0 && lower - margin > vstar) {
+            ijk[L] = first + top;
+            *v_top = cell(M);
+            ijk[L] = first;
+            return top;
+        }
+        return -1;
+    }
+
+    // eight(), unless span_bounded() proves the eight cells above vstar: returns the position (0 or
+    // 7) of the one evaluated cell with v8[position] set; -1: all eight were evaluated.
+    SL_HD int eight_bounded(const SlDevModel& M, int64_t i0, double vstar, double margin, double* v8) {
+        double vt;
+        const int top = span_bounded(M, i0, SL_ROW_CELLS, vstar, margin, &vt);
+        if (top >= 0) { v8[top] = vt; return top; }
+        const int first = (int)ijk[L];
+#pragma unroll
+        for (int k = 0; k < SL_ROW_CELLS; ++k) {
+            ijk[L] = first + k;
+            v8[k] = cell(M);
+        }
+        return -1;
+    }
 };

@@ -669,15 +669,7 @@ class _HipShardEngine(object):
         ``(vbits, index)``."""
         ly = self.lyap
         self.prior = ly._d_init if can_shrink else ly._d_safe.clone()     # lyapunov.py:500-510
-        events = getattr(ly, 'sweep_events', None)
-        if events is not None:                      # bench.py: HIP events on the kernel's stream
-            import torch
-            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record()
         ly._ctx.lyap_sweep(ly._lo, ly._hi, self.prior, ly._values_arg(), ly._d_neg, ly._d_result)
-        if events is not None:
-            stop.record()
-            events.append((start, stop))
         return ly._d_result
 
     def fold(self, records, count):
@@ -693,19 +685,11 @@ class _HipShardEngine(object):
         """``safe = init | key < key* | (prior & key >= key_keep)`` with ``key*`` = the folded
         record's ``fail`` and ``key_keep`` = the select state's key, both read by the kernel."""
         ly = self.lyap
-        events = getattr(ly, 'finalize_events', None)
-        if events is not None:
-            import torch
-            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record()
         keep = None if keep_state is None else keep_state[_hip.S_KEY_V:_hip.S_KEY_V + 2]
         # (the record the pass reads and the one it writes are two buffers)
         out = ly._d_folded if folded.data_ptr() == ly._d_result.data_ptr() else ly._d_result
         ly._ctx.lyap_finalize_dev(ly._lo, ly._hi, ly._values_arg(), ly._d_init,
                                   self.prior if use_prior else None, folded, keep, ly._d_safe, out)
-        if events is not None:
-            stop.record()
-            events.append((start, stop))
         return out
 
     def _many(self, slot):

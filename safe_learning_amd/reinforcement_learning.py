@@ -91,14 +91,7 @@ class PolicyIteration(object):
             argmax = torch.empty(count, dtype=torch.int32, device=dev)
             if want_q:
                 q = torch.empty((count, actions.shape[0]), dtype=torch.float64, device=dev)
-        events = getattr(self, 'sweep_events', None)
-        if events is not None:                      # bench.py: HIP events on the kernel's stream
-            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record()
         ctx.bellman_sweep(lo, hi, actions, v_new, argmax, q, stats)
-        if events is not None:
-            stop.record()
-            events.append((start, stop))
         return v_new, argmax, q, stats
 
     def _gather(self, shard, width=1):

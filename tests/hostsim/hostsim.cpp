@@ -182,6 +182,53 @@ int hs_row_values(const sl_model_desc* desc, int64_t n, double* rows, double* po
     }
     return 0;
 }
+// the bounded variant of the streaming pass (SlRowValues<D>::eight_bounded): per group of 8 cells
+// top[g] = -1 (all evaluated) or the position of the one evaluated cell, vals[8 g + c] its values
+int hs_row_bounded(const sl_model_desc* desc, int64_t n, double vstar, int32_t* top, double* vals,
+                   double* margin_out) {
+    SlDevModel M;
+    make_model(desc, &M);
+    const int d = M.m.grid.d;
+    if (n % SL_ROW_CELLS) return -1;
+    for (int64_t i0 = 0; i0 < n; i0 += SL_ROW_CELLS) {
+        double v8[SL_ROW_CELLS];
+        for (int c = 0; c < SL_ROW_CELLS; ++c) v8[c] = 0.0;
+        int t = -2;
+        switch (d) {
+            case 1: { SlRowValues<1> r; *margin_out = r.error_margin(M); t = r.eight_bounded(M, i0, vstar, *margin_out, v8); break; }
+            case 2: { SlRowValues<2> r; *margin_out = r.error_margin(M); t = r.eight_bounded(M, i0, vstar, *margin_out, v8); break; }
+            case 3: { SlRowValues<3> r; *margin_out = r.error_margin(M); t = r.eight_bounded(M, i0, vstar, *margin_out, v8); break; }
+            case 4: { SlRowValues<4> r; *margin_out = r.error_margin(M); t = r.eight_bounded(M, i0, vstar, *margin_out, v8); break; }
+            default: return -2;
+        }
+        top[i0 / SL_ROW_CELLS] = t;
+        for (int c = 0; c < SL_ROW_CELLS; ++c) vals[i0 + c] = v8[c];
+    }
+    return 0;
+}
+// SlRowValues::span_bounded over spans of `ncells` cells (ncells divides the last axis): the offset
+// of the evaluated cell (or -1) and its value per span
+int hs_span_bounded(const sl_model_desc* desc, int64_t n, int ncells, double vstar, int32_t* top,
+                    double* vtop) {
+    SlDevModel M;
+    make_model(desc, &M);
+    const int d = M.m.grid.d;
+    if (ncells < 1 || n % ncells || M.m.grid.num_points[d - 1] % ncells) return -1;
+    for (int64_t i0 = 0; i0 < n; i0 += ncells) {
+        double v = 0.0;
+        int t = -2;
+        switch (d) {
+            case 1: { SlRowValues<1> r; t = r.span_bounded(M, i0, ncells, vstar, r.error_margin(M), &v); break; }
+            case 2: { SlRowValues<2> r; t = r.span_bounded(M, i0, ncells, vstar, r.error_margin(M), &v); break; }
+            case 3: { SlRowValues<3> r; t = r.span_bounded(M, i0, ncells, vstar, r.error_margin(M), &v); break; }
+            case 4: { SlRowValues<4> r; t = r.span_bounded(M, i0, ncells, vstar, r.error_margin(M), &v); break; }
+            default: return -2;
+        }
+        top[i0 / ncells] = t;
+        vtop[i0 / ncells] = v;
+    }
+    return 0;
+}
 double hs_vbits_to_double(uint64_t b) { return sl_vbits_to_double(b); }
 
 

@@ -224,3 +224,29 @@ def test_c5_cartpole_64_bellman_sweeps():
     tail = residuals[-12:]
     assert all(b <= a * (1 + 1e-12) for a, b in zip(tail, tail[1:]))
     assert tail[-1] < tail[0]
+
+
+def test_library_records_kernel_durations():
+    """``sl_timing_configure`` / ``sl_timing_collect`` (what bench.py's ``kernel_ms`` / ``finalize_ms``
+    come from): one duration per recorded call and channel, at most ``slots``, none when off."""
+    from safe_learning_amd.benchmarks import build_lyapunov
+    lyap = build_lyapunov(cases.make_case("pendulum", num_points=[64, 64], dynamics="linear"))
+    ctx = lyap._ctx
+    lyap.update_safe_set()
+    assert ctx.timing_collect(ctx.TIMING_LYAP_SWEEP) == []
+    ctx.timing_configure(3)
+    for _ in range(5):
+        lyap.update_safe_set()
+    sweeps, passes = ctx.timing_collect(ctx.TIMING_LYAP_SWEEP), ctx.timing_collect(ctx.TIMING_FINALIZE)
+    assert len(sweeps) == 3 and len(passes) == 3
+    assert all(0.0 < ms < 50.0 for ms in sweeps + passes)
+    assert ctx.timing_collect(ctx.TIMING_LYAP_SWEEP) == []          # emptied
+    lyap.update_safe_set()
+    assert len(ctx.timing_collect(ctx.TIMING_LYAP_SWEEP)) == 1      # ... and recording again
+    assert ctx.timing_collect(ctx.TIMING_BELLMAN) == []
+    ctx.timing_configure(0)
+    lyap.update_safe_set()
+    assert ctx.timing_collect(ctx.TIMING_LYAP_SWEEP) == []
+    safe = lyap.safe_set.copy()
+    lyap.update_safe_set()
+    assert_array_equal(lyap.safe_set, safe)

@@ -374,6 +374,169 @@ def test_row_values_equal_the_value_pass_bit_for_bit(hostsim, name, kw, limits):
     assert_array_equal(rows, -olyap.values)
 
 
+@pytest.mark.parametrize("name,kw,limits,matrix", [
+    ("1d", dict(num_points=1000), None, None),
+    ("pendulum", dict(num_points=[17, 40], dynamics="linear"), None, None),
+    ("pendulum", dict(num_points=[9, 24], dynamics="linear"), [[-1.0, 1.0], [-0.5, 0.75]], None),
+    ("cartpole", dict(num_points=[5, 6, 7, 16], dynamics="linear"), None, None),
+    ("cartpole", dict(num_points=[3, 4, 5, 24], dynamics="linear"), [[-1, 1], [-2, 2], [-0.5, 0.5], [-4, 4]], None),
+    # not symmetric; indefinite; flat along the last axis (ties); a large cross term
+    ("pendulum", dict(num_points=[12, 32], dynamics="linear"), None, [[1.0, 0.7], [-0.2, 0.5]]),
+    ("pendulum", dict(num_points=[12, 32], dynamics="linear"), None, [[1.0, 0.0], [0.0, -0.3]]),
+    ("pendulum", dict(num_points=[12, 32], dynamics="linear"), None, [[1.0, 0.0], [0.0, 0.0]]),
+    ("pendulum", dict(num_points=[12, 32], dynamics="linear"), None, [[1.0, 3.0], [3.0, 1.0]]),
+    ("pendulum", dict(num_points=[12, 32], dynamics="linear"), None, [[1e-9, 0.0], [0.0, 1.0]]),
+])
+def test_bounded_rows_skip_only_what_is_provably_above_the_level(hostsim, name, kw, limits, matrix):
+    """SlRowValues::eight_bounded (the streaming pass of update_safe_set skips rows far above the
+    level): whenever it evaluates ONE cell of a group of eight, all eight exact values exceed the
+    level, the evaluated cell carries the group's largest (value, index) key and its value is the
+    exact one; groups it does not skip are the exact values.  Levels from below the minimum to above
+    the maximum, NaN (no failing key) included."""
+    case = cases.make_case(name, **kw)
+    if limits is not None:
+        case["limits"] = [[float(a), float(b)] for a, b in limits]
+    if matrix is not None:
+        case["P"] = np.array(matrix)
+    grid, desc = _describe(case)
+    n = grid.nindex
+    rows, points = np.zeros(n), np.zeros(n)
+    assert hostsim.hs_row_values(C.byref(desc), C.c_int64(n), rows.ctypes.data_as(C.c_void_p),
+                                 points.ctypes.data_as(C.c_void_p)) == 0
+    exact = rows.reshape(-1, 8)
+    hostsim.hs_row_bounded.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    levels = list(np.quantile(rows, [0.0, 0.001, 0.01, 0.2, 0.5, 0.9, 1.0])) + [rows.min() - 1.0, rows.max() + 1.0,
+                                                                                float("nan")]
+    skipped_any = False
+    for vstar in levels:
+        top = np.zeros(n // 8, dtype=np.int32)
+        vals = np.zeros(n)
+        margin = C.c_double(0.0)
+        assert hostsim.hs_row_bounded(C.byref(desc), C.c_int64(n), C.c_double(vstar), top.ctypes.data_as(C.c_void_p),
+                                      vals.ctypes.data_as(C.c_void_p), C.byref(margin)) == 0
+        vals = vals.reshape(-1, 8)
+        full = top < 0
+        assert_array_equal(vals[full], exact[full])
+        skip = ~full
+        if np.isnan(vstar) or vstar >= rows.max():
+            assert not skip.any()
+        if skip.any():
+            skipped_any = True
+            assert np.all(exact[skip] > vstar)                                   # no cell at or below the level
+            # the evaluated cell: exact value, and the lexicographic maximum (value, index) of its group
+            picked = top[skip]
+            assert set(np.unique(picked)) <= {0, 7}
+            got = vals[skip, picked]
+            assert_array_equal(got, exact[skip, picked])
+            best = np.array([np.flatnonzero(r == r.max())[-1] for r in exact[skip]])
+            assert_array_equal(picked, best)
+            # strictly monotone groups, or convex ones around the row's minimum (one sign change - to +)
+            d = np.diff(exact[skip], axis=1)
+            changes = np.count_nonzero(np.diff(np.sign(d), axis=1) != 0, axis=1)
+            assert np.all(d != 0) and np.all(changes <= 1)
+            assert np.all((changes == 0) | ((d[:, 0] < 0) & (d[:, -1] > 0)))
+    if matrix is None or matrix[1][1] != 0.0:
+        assert skipped_any                      # the bound is not vacuous
+    # the level set's own statistics from the bounded pass equal those of the plain one
+    vstar = float(np.quantile(rows, 0.01))
+    top = np.zeros(n // 8, dtype=np.int32)
+    vals = np.zeros(n)
+    hostsim.hs_row_bounded(C.byref(desc), C.c_int64(n), C.c_double(vstar), top.ctypes.data_as(C.c_void_p),
+                           vals.ctypes.data_as(C.c_void_p), C.byref(margin))
+    vals = vals.reshape(-1, 8)
+    seen = np.where((top >= 0)[:, None], -np.inf, vals)          # cells the pass never looked at: -inf
+    seen[top >= 0, top[top >= 0]] = vals[top >= 0, top[top >= 0]]
+    assert np.count_nonzero(np.where(np.isinf(seen), np.inf, seen) < vstar) == np.count_nonzero(rows < vstar)
+    flat = seen.reshape(-1)
+    assert flat.max() == rows.max() and np.flatnonzero(flat == flat.max())[-1] == np.flatnonzero(rows == rows.max())[-1]
+
+
+@pytest.mark.parametrize("name,kw,matrix", [
+    ("pendulum", dict(num_points=[12, 32], dynamics="linear"), None),
+    ("pendulum", dict(num_points=[9, 128], dynamics="linear"), [[2.0, 0.7], [0.7, 1.0]]),
+    ("pendulum", dict(num_points=[7, 120], dynamics="linear"), [[1.0, 3.0], [3.0, 1.0]]),
+    ("cartpole", dict(num_points=[4, 5, 6, 64], dynamics="linear"), None),
+    ("1d", dict(num_points=256), None),
+    # not symmetric; indefinite; flat along the last axis
+    ("pendulum", dict(num_points=[12, 64], dynamics="linear"), [[1.0, 0.7], [-0.2, 0.5]]),
+    ("pendulum", dict(num_points=[12, 64], dynamics="linear"), [[1.0, 0.0], [0.0, -0.3]]),
+    ("pendulum", dict(num_points=[12, 64], dynamics="linear"), [[1.0, 0.0], [0.0, 0.0]]),
+])
+def test_bounded_spans_of_a_row(hostsim, name, kw, matrix):
+    """SlRowValues::span_bounded on the spans the streaming pass gives a thread (the largest divisor
+    of the row, at most 16 groups of eight, and smaller ones): a span it clears has every exact value
+    above the level, and the one evaluated cell is the exact lexicographic maximum of the span."""
+    case = cases.make_case(name, **kw)
+    if matrix is not None:
+        case["P"] = np.array(matrix)
+    grid, desc = _describe(case)
+    n = grid.nindex
+    rows, points = np.zeros(n), np.zeros(n)
+    assert hostsim.hs_row_values(C.byref(desc), C.c_int64(n), rows.ctypes.data_as(C.c_void_p),
+                                 points.ctypes.data_as(C.c_void_p)) == 0
+    hostsim.hs_span_bounded.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    last = int(grid.num_points[-1])
+    spans = sorted({8 * g for g in range(1, 17) if (last // 8) % g == 0})
+    assert spans[-1] >= 32
+    cleared = 0
+    for ncells in spans:
+        exact = rows.reshape(-1, ncells)
+        for vstar in list(np.quantile(rows, [0.0, 0.01, 0.3, 0.9, 1.0])) + [rows.min() - 1.0, float("nan")]:
+            top = np.zeros(n // ncells, dtype=np.int32)
+            vtop = np.zeros(n // ncells)
+            assert hostsim.hs_span_bounded(C.byref(desc), C.c_int64(n), ncells, C.c_double(vstar),
+                                           top.ctypes.data_as(C.c_void_p), vtop.ctypes.data_as(C.c_void_p)) == 0
+            skip = top >= 0
+            if np.isnan(vstar) or vstar >= rows.max():
+                assert not skip.any()
+            if not skip.any():
+                continue
+            cleared += int(skip.sum())
+            assert np.all(exact[skip] > vstar)
+            assert set(np.unique(top[skip])) <= {0, ncells - 1}
+            assert_array_equal(vtop[skip], exact[skip, top[skip]])
+            best = np.array([np.flatnonzero(r == r.max())[-1] for r in exact[skip]])
+            assert_array_equal(top[skip], best)
+    if matrix is None or matrix[1][1] != 0.0:
+        assert cleared > 0
+
+
+def test_bounded_spans_on_random_quadratics(hostsim):
+    """The same property on 150 random grids, matrices (definite or not) and levels near the values."""
+    rng = np.random.default_rng(5)
+    hostsim.hs_span_bounded.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+    cleared = 0
+    for trial in range(150):
+        groups = int(rng.integers(1, 17))
+        case = cases.make_case("pendulum", num_points=[int(rng.integers(2, 9)), 8 * groups], dynamics="linear")
+        lim = np.sort(rng.normal(size=(2, 2)) * 10.0 ** rng.integers(-3, 3), axis=1)
+        case["limits"] = [[float(a), float(b)] for a, b in lim]
+        P = rng.normal(size=(2, 2))
+        case["P"] = P @ P.T if trial % 3 else P
+        grid, desc = _describe(case)
+        if not hostsim.hs_values_implicit_ok(C.byref(desc)):
+            continue
+        n = grid.nindex
+        rows, points = np.zeros(n), np.zeros(n)
+        assert hostsim.hs_row_values(C.byref(desc), C.c_int64(n), rows.ctypes.data_as(C.c_void_p),
+                                     points.ctypes.data_as(C.c_void_p)) == 0
+        ncells = 8 * max(g for g in range(1, 17) if groups % g == 0)
+        exact = rows.reshape(-1, ncells)
+        for vstar in rng.choice(rows, 4):
+            for shift in (-1e-12 * abs(vstar), 0.0, 1e-12 * abs(vstar)):
+                top = np.zeros(n // ncells, dtype=np.int32)
+                vtop = np.zeros(n // ncells)
+                assert hostsim.hs_span_bounded(C.byref(desc), C.c_int64(n), ncells, C.c_double(vstar + shift),
+                                               top.ctypes.data_as(C.c_void_p), vtop.ctypes.data_as(C.c_void_p)) == 0
+                skip = top >= 0
+                cleared += int(skip.sum())
+                assert np.all(exact[skip] > vstar + shift)
+                assert_array_equal(vtop[skip], exact[skip, top[skip]])
+                best = np.array([np.flatnonzero(r == r.max())[-1] for r in exact[skip]], dtype=np.int32)
+                assert_array_equal(top[skip], best)
+    assert cleared > 100
+
+
 def test_values_stay_explicit_where_the_index_points_differ(hostsim):
     """np.linspace pins the last point of an axis to the upper limit; where index * unit + offset
     rounds to something else (or the last axis is not whole bytes, or V is a table) the passes read V."""

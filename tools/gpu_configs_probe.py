@@ -27,9 +27,10 @@ def lyap_config(label, case, reps=3):
     lyap = build_lyapunov(case)
     torch.cuda.synchronize()
     setup = time.perf_counter() - t0
-    lyap.sweep_events = []
+    lyap._ctx.timing_configure(64)
     sec = timed(lyap.update_safe_set, reps)
-    kern = float(np.mean([a.elapsed_time(b) for a, b in lyap.sweep_events[1:]]))
+    kern = float(np.mean(lyap._ctx.timing_collect(0)[1:]))
+    lyap._ctx.timing_configure(0)
     n = lyap.discretization.nindex
     sec_values = timed(lyap.update_values, reps)
     r = {"config": label, "cells": n, "ms_update_safe_set": sec * 1e3, "ms_sweep_kernel": kern,

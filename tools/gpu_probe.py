@@ -23,13 +23,13 @@ def time_sweep(family, num_points, n_gp, cfg, reps=3):
     lyap = build_lyapunov(case)
     lyap.update_safe_set()
     torch.cuda.synchronize()
-    lyap.sweep_events = []
+    lyap._ctx.timing_configure(64)
     t0 = time.perf_counter()
     for _ in range(reps):
         lyap.update_safe_set()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / reps
-    ms = float(np.mean([a.elapsed_time(b) for a, b in lyap.sweep_events]))
+    ms = float(np.mean(lyap._ctx.timing_collect(0)))
     n = lyap.discretization.nindex
     p, d = case["d"] + 1, case["d"]
     flops = (n_gp * (4 * p + 2) + 2 * n_gp * d + n_gp * n_gp + 2 * n_gp) * n
