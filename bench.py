@@ -818,8 +818,8 @@ def parse_args(argv=None):
 # library (SL_LIB_PATH, tools/build_variant.sh) may skip work (SL_GP4_SKIP, SL_BM_FLAGS, SL_B4P_FLAGS -
 # the shipped library does not read them).  The A/B switches of the shipped kernels are legitimate
 # runs but not the default path: they are listed in the line (config.env_switches).
-REFUSED_ENV = ("SL_LIB_PATH", "SL_GP4_SKIP", "SL_BM_FLAGS", "SL_B4P_FLAGS")
-AB_ENV = ("SL_GP_CFG", "SL_GP_SMALL", "SL_GP_SMALL_WAVES", "SL_DET_ROWS", "SL_GP4_ONE_PANEL", "SL_GP4_SEEDS",
+REFUSED_ENV = ("SL_LIB_PATH", "SL_GP4_SKIP", "SL_BM_FLAGS", "SL_B4P_FLAGS", "SL_GPS_FLAGS")
+AB_ENV = ("SL_GP_CFG", "SL_GP_SMALL", "SL_GP_SMALL_WAVES", "SL_GP_SMALL_SPLIT", "SL_DET_ROWS", "SL_GP4_ONE_PANEL", "SL_GP4_SEEDS",
           "SL_GP4_TICKETS", "SL_BELLMAN_MFMA", "SL_BELLMAN4", "SL_BELLMAN4_POLICY", "SL_BELLMAN4_POLICY_CACHE",
           "SL_BELLMAN4_RAGGED", "SL_BELLMAN4_QUARTER", "SL_BELLMAN4_SPLIT", "SL_BELLMAN4_ROUND",
           "SL_BELLMAN4_SHARED", "SL_SUCC_CACHE", "SL_FORCE_COLLECTIVES")

@@ -34,6 +34,7 @@ struct SlEnv {
     int gp_cfg = -1;                 // SL_GP_CFG=0..3: force a GP-sweep configuration
     int gp_small = -1;               // SL_GP_SMALL=0: small training sets stay on k_gp_sweep
     int gp_small_waves = -1;         // SL_GP_SMALL_WAVES=8
+    int gp_small_split = -1;         // SL_GP_SMALL_SPLIT
     int det_rows = -1;               // SL_DET_ROWS=0: linear dynamics on k_det_sweep
     int gp4_one_panel = -1;          // SL_GP4_ONE_PANEL=0: 193..256 points stay on k_gp_small
     int gp4_seeds = -1;              // SL_GP4_SEEDS=0: every k_x chunk from the exponentials

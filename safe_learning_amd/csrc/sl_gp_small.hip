@@ -41,6 +41,8 @@ constexpr int PRB = 8;            // row blocks (of 16 rows) per pass: 128 rows
 // fragment pairs (1 KiB each: two slabs of 4 training points x 16 rows) of the lower triangle in
 // front of row block I: row block i needs the slab pairs 0 .. 2 i + 1
 __host__ __device__ constexpr int tri_offset(int I) { return I * (I + 1); }
+// LDS doubles of a head's kernel description (sum-of-products heads only)
+constexpr int KERNEL_DOUBLES = (int)((sizeof(sl_gp_kernel) + 15) / 16) * 2;
 }  // namespace gps
 
 // ALDS: the A fragments are read from the workgroup's LDS copy (else from L2).
@@ -51,8 +53,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
     const SlDevModel M, const SlGpDev gp, SlAux aux_arg, int64_t lo, int64_t hi, int64_t ntiles,
     const uint64_t* __restrict__ init_bits, const double* __restrict__ values,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
-    int head_doubles, const double* __restrict__ points, unsigned long long* __restrict__ ticket) {
+    int head_doubles, const double* __restrict__ points, unsigned long long* __restrict__ ticket,
+    int diag) {
     using namespace gps;
+#ifdef SL_DIAG
+    const int dg = diag;         // development builds (tools/build_variant.sh): phases switched off for timing attribution -
+                                 // 1 no kernel evaluation, 2 no MFMAs, 4 no fragment loads, 8 no check, 16 no policy
+#else
+    constexpr int dg = 0;
+    (void)diag;
+#endif
     __shared__ SlTriLds<GENERAL> tri_lds;
     __shared__ uint64_t sv[WAVES];
     __shared__ int64_t si[WAVES];
@@ -85,6 +95,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
             dst += (p * n_pad + 1) & ~1;
             for (int k = tid; k < n_pad * hd.dout; k += 64 * WAVES) dst[k] = hd.alpha[k];
             dst += (n_pad * hd.dout + 1) & ~1;
+            if (KERN && hd.kernel) {
+                // the kernel description: read at every slab pair of every tile
+                const double* src = reinterpret_cast<const double*>(hd.kernel);
+                for (int k = tid; k < (int)(sizeof(sl_gp_kernel) / sizeof(double)); k += 64 * WAVES) dst[k] = src[k];
+                dst += KERNEL_DOUBLES;
+            }
             if (ALDS) {
                 // row block I, slab pair s2 (s2 <= 2 I + 1): 128 doubles at tri_offset(I) + s2
                 for (int I = 0; I < nrb; ++I) {
@@ -120,6 +136,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
         // ---- GP input [x, policy(x)] of this lane's cell (kept for the check) ----------------------
         double x[SL_P], u[SL_M];
         sl_cell_state(M, d, gidx, points, x);
+        if (dg & 16) { for (int a = 0; a < SL_M; ++a) u[a] = 0.0; } else
         sl_policy_any<GENERAL>(M, nd, aux.tri, gidx, x, u);
         sl_append_action(nd, u, x);
 
@@ -129,10 +146,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
         const int n_pad = hd.n_pad, dout = hd.dout, nslab2 = hd.nslab2, col0 = hd.col0;
         const int nrb = (hd.n + 15) / 16, npass = (nrb + PRB - 1) / PRB;
         const double variance = hd.variance;
-        const sl_gp_kernel* __restrict__ kern = KERN ? hd.kernel : nullptr;   // null: the RBF of sl_gp_set_head
         const double* xs_l = head_base;                              // [p][n_pad]
         const double* alpha_l = xs_l + ((p * n_pad + 1) & ~1);       // [n_pad][dout]
-        const double* a_l = alpha_l + ((n_pad * dout + 1) & ~1);     // lower-triangle fragments (ALDS)
+        const double* kern_l = alpha_l + ((n_pad * dout + 1) & ~1);  // kernel description (KERN heads)
+        // null: the RBF of sl_gp_set_head
+        const sl_gp_kernel* kern = (KERN && hd.kernel) ? reinterpret_cast<const sl_gp_kernel*>(kern_l) : nullptr;
+        const double* a_l = kern_l + (kern ? KERNEL_DOUBLES : 0);    // lower-triangle fragments (ALDS)
         head_base = a_l + (ALDS ? (size_t)tri_offset(nrb) * 128 : 0);
         // this head's scaled inputs of the tile's cells (own lengthscales per head)
         __builtin_amdgcn_wave_barrier();
@@ -172,7 +191,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
                         }
                     }
                     double k0, k1;
-                    if (kern) {                                 // sum-of-products kernel, unscaled inputs
+                    if (dg & 1) {
+                        k0 = z0; k1 = z1;
+                    } else if (kern) {                          // sum-of-products kernel, unscaled inputs
                         double xa[SL_P], xb[SL_P];
 #pragma unroll
                         for (int q = 0; q < SL_P; ++q) {
@@ -181,8 +202,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
                         }
                         // the padding columns of the tables are zero; their fragments of the
                         // factor and of alpha' are zero as well
-                        k0 = sl_kernel_eval(*kern, p, xa, xg);
-                        k1 = sl_kernel_eval(*kern, p, xb, xg);
+                        sl_kernel_eval2(*kern, p, xa, xb, xg, &k0, &k1);
                     } else {
                         k0 = variance * sl_exp_nonpos(-0.5 * z0);
                         k1 = variance * sl_exp_nonpos(-0.5 * z1);
@@ -203,10 +223,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
                         if (r >= rmin && r < rbn) {
                             const int I = rb0 + r;
                             sl_d2 a;
-                            if (ALDS)
+                            if (dg & 4)
+                                a = (sl_d2){1.0, 1.0};
+                            else if (ALDS)
                                 a = *reinterpret_cast<const sl_d2*>(a_l + (size_t)(tri_offset(I) + s2) * 128 + lane * 2);
                             else
                                 a = *reinterpret_cast<const sl_d2*>(hd.mpack + ((size_t)I * nslab2 + s2) * 128 + lane * 2);
+                            if (dg & 2) { acc[r].x += a.x * k0; acc[r].y += a.y * k1; continue; }
                             acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, k0, acc[r], 0, 0, 0);
                             acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, k1, acc[r], 0, 0, 0);
                         }
@@ -266,7 +289,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
                     err[k] = err_w[lane * d + k];
                 }
             }
-            if (valid) {
+            if (valid && !(dg & 8)) {
                 SlCellCheck c = sl_cell_check<SlSweepFlavour<GENERAL>::value>(M, d, aux, x, mean, err);
                 negative = c.negative;
                 v_x = values ? values[idx - lo] : c.v_x;               // ordering key: lyapunov.py:512
@@ -300,7 +323,8 @@ static size_t small_lds_doubles(sl_ctx* ctx, int p, int d) {
     size_t small = 0;
     for (int k = 0; k < ctx->h_gp.nheads; ++k) {
         const SlGpHeadHost& h = ctx->gp_heads[k];
-        small += (size_t)((p * h.n_pad + 1) & ~1) + (size_t)((h.n_pad * h.dout + 1) & ~1);
+        small += (size_t)((p * h.n_pad + 1) & ~1) + (size_t)((h.n_pad * h.dout + 1) & ~1) +
+                 (h.d_kernel ? gps::KERNEL_DOUBLES : 0);
     }
     return small + (size_t)gps::WAVES_MIN * 64 * (p + 1 + 2 * d);
 }
@@ -334,7 +358,8 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
     size_t small = 0, tri = 0;
     for (int k = 0; k < ctx->h_gp.nheads; ++k) {
         const SlGpHeadHost& h = ctx->gp_heads[k];
-        small += (size_t)((p * h.n_pad + 1) & ~1) + (size_t)((h.n_pad * h.dout + 1) & ~1);
+        small += (size_t)((p * h.n_pad + 1) & ~1) + (size_t)((h.n_pad * h.dout + 1) & ~1) +
+                 (h.d_kernel ? KERNEL_DOUBLES : 0);
         tri += (size_t)tri_offset((h.n + 15) / 16) * 128;         // row blocks with training points
     }
     const size_t cap = lds_capacity(GENERAL);
@@ -373,7 +398,8 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * W_), lds, ctx->stream, model,   \
                            ctx->h_gp, aux, lo, hi, ntiles, d_init_bits, d_values, d_neg_bits,      \
-                           ctx->d_partials, d_dbg, head_doubles, d_points, ticket);             \
+                           ctx->d_partials, d_dbg, head_doubles, d_points, ticket,              \
+                           sl_diag_flags("SL_GPS_FLAGS"));                                      \
     } while (0)
     if constexpr (DT > 0) {
         if (waves == WAVES_MAX) { if (alds) SL_GPS_GO(true, WAVES_MAX); else SL_GPS_GO(false, WAVES_MAX); }

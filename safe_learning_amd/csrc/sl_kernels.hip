@@ -58,6 +58,7 @@ void sl_env_read(SlEnv* e) {
     if (e->gp_cfg > 3) e->gp_cfg = -1;
     e->gp_small = env_int("SL_GP_SMALL");
     e->gp_small_waves = env_int("SL_GP_SMALL_WAVES");
+    e->gp_small_split = env_int("SL_GP_SMALL_SPLIT");
     e->det_rows = env_int("SL_DET_ROWS");
     e->gp4_one_panel = env_int("SL_GP4_ONE_PANEL");
     e->gp4_seeds = env_int("SL_GP4_SEEDS");
@@ -787,12 +788,16 @@ static SlDevModel sl_posterior_only(const SlDevModel& full) {
 // k_gp_sweep4: action table + posterior records + check instead of k_gp_sweep's 16x16x4 structure
 static bool sl_gp_three_pass(sl_ctx* ctx) {
     const SlDevModel& M = ctx->h_model;
-    if (M.m.value.kind == SL_V_NETWORK || !sl_model_is_general(M) || ctx->gp_cfg != 2) return false;
-    for (int h = 0; h < ctx->h_gp.nheads; ++h)
-        if (ctx->gp_heads[h].d_kernel) return false;
+    if (M.m.value.kind == SL_V_NETWORK || !sl_model_is_general(M)) return false;
+    bool other_kernels = false;
+    for (int h = 0; h < ctx->h_gp.nheads; ++h) other_kernels = other_kernels || ctx->gp_heads[h].d_kernel;
     SlDevModel po = sl_posterior_only(M);
     if (po.m.policy.kind == SL_POLICY_TRI) po.m.policy.kind = SL_POLICY_TABLE;
-    return sl_gp4_supports(po);
+    if (ctx->gp_cfg == 2 && !other_kernels && sl_gp4_supports(po)) return true;
+    // small training sets (k_gp_small, the notebooks' regime): the same split
+    if (ctx->env.gp_small_split == 1 && (other_kernels || ctx->gp_cfg == 0) && sl_gp_small_supports(ctx, po))
+        return true;
+    return false;
 }
 
 int sl_sweep_any(sl_ctx* ctx, int64_t lo, int64_t hi, const uint64_t* d_init_bits,

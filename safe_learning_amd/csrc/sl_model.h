@@ -1039,6 +1039,68 @@ SL_HD double sl_kernel_eval(const sl_gp_kernel& ks, int p, const double* a, cons
     }
     return total + prod;
 }
+// a wavefront-uniform int as a scalar (the factor kinds of a kernel description read from LDS:
+// the branches on them stay scalar branches)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SL_UNIFORM_INT(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define SL_UNIFORM_INT(x) (x)
+#endif
+
+// k(a0, b) and k(a1, b) in one walk over the factors (k_gp_small: the two training points a lane
+// holds of a slab pair; the description is read once for both - from the workgroup's LDS copy).
+// The same operations in the same order as sl_kernel_eval for each of the two.
+SL_HD void sl_kernel_eval2(const sl_gp_kernel& ks, int p, const double* a0, const double* a1,
+                           const double* b, double* k0, double* k1) {
+    double total0 = 0.0, prod0 = 1.0, total1 = 0.0, prod1 = 1.0;
+    int cur = 0;
+    const int nfactors = SL_UNIFORM_INT(ks.nfactors);
+    for (int f = 0; f < nfactors; ++f) {
+        const sl_gp_kernel_factor& fac = ks.factor[f];
+        const int kind = SL_UNIFORM_INT(fac.kind), product = SL_UNIFORM_INT(fac.product);
+        if (product != cur) {
+            total0 += prod0; total1 += prod1;
+            prod0 = 1.0; prod1 = 1.0;
+            cur = product;
+        }
+        double v0 = 0.0, v1 = 0.0;
+        if (kind == SL_KERNEL_LINEAR) {
+#pragma unroll
+            for (int q = 0; q < SL_P; ++q) {
+                if (q < p) {
+                    const double var = fac.variance[q];
+                    v0 = fma(a0[q] * var, b[q], v0);
+                    v1 = fma(a1[q] * var, b[q], v1);
+                }
+            }
+        } else {
+            double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < SL_P; ++q) {
+                if (q < p) {
+                    const double inv = fac.inv_lengthscales[q];
+                    const double d0 = (a0[q] - b[q]) * inv, d1 = (a1[q] - b[q]) * inv;
+                    r0 = fma(d0, d0, r0);
+                    r1 = fma(d1, d1, r1);
+                }
+            }
+            const double var = fac.variance[0];
+            if (kind == SL_KERNEL_RBF) {
+                v0 = var * sl_exp_nonpos(-0.5 * r0);
+                v1 = var * sl_exp_nonpos(-0.5 * r1);
+            } else {                                    // Matern32, euclid_dist's 1e-12
+                const double s0 = 1.7320508075688772 * sqrt(r0 + 1e-12);
+                const double s1 = 1.7320508075688772 * sqrt(r1 + 1e-12);
+                v0 = var * (1.0 + s0) * sl_exp_nonpos(-s0);
+                v1 = var * (1.0 + s1) * sl_exp_nonpos(-s1);
+            }
+        }
+        prod0 *= v0;
+        prod1 *= v1;
+    }
+    *k0 = total0 + prod0;
+    *k1 = total1 + prod1;
+}
 // k(x, x) as kern.Kdiag states it (Stationary.Kdiag: the variance itself, not K through
 // euclid_dist; Linear.Kdiag: sum_q variance_q x_q^2)
 SL_HD double sl_kernel_diag(const sl_gp_kernel& ks, int p, const double* x) {

@@ -248,4 +248,22 @@ int hs_kernel_matrix(const sl_gp_kernel* ks, int p, const double* a, int na, con
     }
     return 0;
 }
+// sl_kernel_eval2 (two training points in one walk over the factors - what k_gp_small evaluates)
+// against sl_kernel_eval: number of pairs whose values differ in any bit
+int hs_kernel_eval2_mismatches(const sl_gp_kernel* ks, int p, const double* a, int na, const double* b, int nb) {
+    int bad = 0;
+    for (int i = 0; i + 1 < na; i += 2) {
+        double x0[SL_P] = {}, x1[SL_P] = {};
+        for (int q = 0; q < p; ++q) { x0[q] = a[i * p + q]; x1[q] = a[(i + 1) * p + q]; }
+        for (int j = 0; j < nb; ++j) {
+            double xb[SL_P] = {};
+            for (int q = 0; q < p; ++q) xb[q] = b[j * p + q];
+            double k0, k1;
+            sl_kernel_eval2(*ks, p, x0, x1, xb, &k0, &k1);
+            const double e0 = sl_kernel_eval(*ks, p, x0, xb), e1 = sl_kernel_eval(*ks, p, x1, xb);
+            if (memcmp(&k0, &e0, 8) || memcmp(&k1, &e1, 8)) ++bad;
+        }
+    }
+    return bad;
+}
 }  // extern "C"

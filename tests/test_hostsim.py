@@ -595,3 +595,6 @@ def test_kernel_family_device_functions(hostsim):
             okern = kernel_from_spec(products, oracle)
             assert_allclose(out, okern.K(A, B), rtol=1e-12, atol=1e-16)
             assert_allclose(diag, okern.Kdiag(A), rtol=1e-14)
+            # the paired evaluation k_gp_small uses: the same bits as one point at a time
+            assert hostsim.hs_kernel_eval2_mismatches(C.byref(ks), 3, A.ctypes.data_as(C.c_void_p), len(A),
+                                                      B.ctypes.data_as(C.c_void_p), len(B)) == 0
