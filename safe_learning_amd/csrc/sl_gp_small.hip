@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
     using namespace gps;
 #ifdef SL_DIAG
     const int dg = diag;         // development builds (tools/build_variant.sh): phases switched off for timing attribution -
-                                 // 1 no kernel evaluation, 2 no MFMAs, 4 no fragment loads, 8 no check, 16 no policy
+                                 // 1 no kernel evaluation, 2 no MFMAs, 4 no fragment loads, 8 no check, 16 no policy, 32 no GEMM passes
 #else
     constexpr int dg = 0;
     (void)diag;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
             if (q < p) cin[lane * p + q] = x[q] * hd.inv_ls[q];
         __builtin_amdgcn_wave_barrier();
 
-        for (int pass = 0; pass < npass; ++pass) {
+        for (int pass = 0; pass < ((dg & 32) ? 0 : npass); ++pass) {
             const int rb0 = pass * PRB;                         // first row block of the pass
             const int rbn = nrb - rb0 < PRB ? nrb - rb0 : PRB;  // row blocks in it
             const int ns2 = 2 * (rb0 + rbn);                    // slab pairs up to its diagonal
