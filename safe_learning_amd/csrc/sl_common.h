@@ -103,7 +103,9 @@ struct sl_ctx {
     size_t records_bytes = 0;
     sl_key* d_partials = nullptr;      // SL_MAX_GRID entries x 4 keys
     int64_t* d_partial_counts = nullptr;
-    unsigned long long* d_ticket = nullptr;   // tile counter of k_gp_small (zeroed per launch)
+    unsigned long long* d_ticket = nullptr;   // [0]: tile counter of k_gp_small (zeroed per launch); the
+                                              // first word of [1]: finished workgroups of k_finalize_dev
+                                              // (its last workgroup reduces and resets it)
     double* d_actions = nullptr;       // bellman action list
     int num_cu = 256;
     void* comm = nullptr;              // RCCL communicator (sl_comm.hip), optional

@@ -109,6 +109,7 @@ extern "C" int sl_ctx_create(int device, void* hip_stream, sl_ctx** out) {
     SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_partial_counts, sizeof(int64_t) * 2 * SL_MAX_GRID));
     SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_ticket, 16));
     SL_HIP_CHECK(ctx, hipMalloc(&ctx->d_actions, sizeof(double) * 1024));
+    SL_HIP_CHECK(ctx, hipMemset(ctx->d_ticket, 0, 16));
     SL_HIP_CHECK(ctx, hipMemset(ctx->d_tri, 0, 2 * sizeof(SlTri)));
     SL_HIP_CHECK(ctx, hipMemset(ctx->d_net, 0, sizeof(SlNet)));
     SL_HIP_CHECK(ctx, hipMemset(ctx->d_gp, 0, sizeof(SlGpDev)));

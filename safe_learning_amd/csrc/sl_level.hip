@@ -39,14 +39,21 @@ __device__ __forceinline__ void constants_to_vgprs(SlDevModel& M) {
     }
 }
 
+__device__ __forceinline__ void reduce_finalize_block(
+    const sl_key* partials, const int64_t* counts, int n, const sl_sweep_result* folded,
+    sl_sweep_result* result, uint64_t* sv, int64_t* si, int64_t (*sc)[SL_BLOCK / 64]);
+
 // ---- safe_i = init_i | key_i < key* | (prev_i & key_i >= key_keep) ------------------------------
+// On small grids (`done` given) the workgroup that finishes LAST reduces the partials of all of them
+// into the result record - one launch less per update, a fifth of such a step; on large ones the
+// device-wide fence of 2048 workgroups costs more (0.016 ms at 128^4) than the launch it saves.
 template <int DT>
 __global__ __launch_bounds__(SL_BLOCK) void k_finalize_dev(
     const SlDevModel M_arg, int64_t lo, int64_t hi, const double* __restrict__ values,
     const uint8_t* __restrict__ init_bytes, const uint8_t* __restrict__ prev_bytes,
     const sl_sweep_result* __restrict__ folded, const sl_key* __restrict__ keep_ptr,
-    uint8_t* __restrict__ safe_bytes, sl_key* __restrict__ partials, int64_t* __restrict__ counts,
-    int span_groups, int vector_ok) {
+    uint8_t* __restrict__ safe_bytes, sl_key* partials, int64_t* counts,
+    int span_groups, int vector_ok, unsigned int* done, sl_sweep_result* __restrict__ result) {
     __shared__ uint64_t sv[SL_BLOCK / 64];
     __shared__ int64_t si[SL_BLOCK / 64];
     __shared__ int64_t sc[2][SL_BLOCK / 64];
@@ -166,16 +173,28 @@ __global__ __launch_bounds__(SL_BLOCK) void k_finalize_dev(
         for (int w = 0; w < SL_BLOCK / 64; ++w) { a += sc[0][w]; b += sc[1][w]; }
         counts[2 * blockIdx.x] = a; counts[2 * blockIdx.x + 1] = b;
     }
+    // last workgroup done: its partials are visible device-wide before the count goes up, the
+    // reader's fence makes it see everybody else's
+    __shared__ int last;
+    if (!done) return;                       // (large grids: k_reduce_finalize_dev follows)
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last) {
+        __threadfence();
+        reduce_finalize_block(partials, counts, (int)gridDim.x, folded, result, sv, si, sc);
+        if (threadIdx.x == 0) *done = 0u;
+    }
 }
 
 // partials of k_finalize_dev -> last_safe, max_key, count_below, count_safe of the result record;
-// `fail` is carried over from the folded record the pass was given (a later fold keeps it)
-__global__ __launch_bounds__(SL_BLOCK) void k_reduce_finalize_dev(
-    const sl_key* __restrict__ partials, const int64_t* __restrict__ counts, int n,
-    const sl_sweep_result* __restrict__ folded, sl_sweep_result* __restrict__ result) {
-    __shared__ uint64_t sv[SL_BLOCK / 64];
-    __shared__ int64_t si[SL_BLOCK / 64];
-    __shared__ int64_t sc[2][SL_BLOCK / 64];
+// `fail` is carried over from the folded record the pass was given (a later fold keeps it).  One
+// workgroup: the last one of k_finalize_dev to finish, or k_reduce_finalize_dev (empty ranges).
+__device__ __forceinline__ void reduce_finalize_block(
+    const sl_key* partials, const int64_t* counts, int n, const sl_sweep_result* folded,
+    sl_sweep_result* result, uint64_t* sv, int64_t* si, int64_t (*sc)[SL_BLOCK / 64]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t ls_v = 0ull, mx_v = 0ull;
     int64_t ls_i = -1, mx_i = -1, a = 0, b = 0;
@@ -188,6 +207,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_reduce_finalize_dev(
         a += __shfl_xor((long long)a, off, 64);
         b += __shfl_xor((long long)b, off, 64);
     }
+    __syncthreads();                                   // (the callers' use of the scratch is over)
     if (lane == 0) { sc[0][wave] = a; sc[1][wave] = b; }
     sl_block_reduce_key<false>(ls_v, ls_i, sv, si);
     __syncthreads();
@@ -201,6 +221,15 @@ __global__ __launch_bounds__(SL_BLOCK) void k_reduce_finalize_dev(
         for (int w = 0; w < SL_BLOCK / 64; ++w) { ta += sc[0][w]; tb += sc[1][w]; }
         result->count_below = ta; result->count_safe = tb;
     }
+}
+
+__global__ __launch_bounds__(SL_BLOCK) void k_reduce_finalize_dev(
+    const sl_key* __restrict__ partials, const int64_t* __restrict__ counts, int n,
+    const sl_sweep_result* __restrict__ folded, sl_sweep_result* __restrict__ result) {
+    __shared__ uint64_t sv[SL_BLOCK / 64];
+    __shared__ int64_t si[SL_BLOCK / 64];
+    __shared__ int64_t sc[2][SL_BLOCK / 64];
+    reduce_finalize_block(partials, counts, n, folded, result, sv, si, sc);
 }
 
 // Refinement N(x) after a NON-adaptive update that must not shrink (lyapunov.py:507-510, 531,
@@ -413,14 +442,18 @@ extern "C" int sl_lyap_finalize_dev(sl_ctx* ctx, int64_t lo, int64_t hi, const d
     int span_groups = 0, vector_ok = 0;
     if (blocks && dt > 0 && !d_prev_bits && !ctx->h_model.m.value.negate) {
         const int64_t row_groups = ctx->h_model.m.grid.num_points[dt - 1] / CPT;
+        // (long spans only where they leave the device enough threads: a 256 x 256 grid is 8192
+        // groups of eight - one thread each, as in the unbounded pass)
         for (int g = 16; g >= 1 && !span_groups; --g)
-            if (row_groups % g == 0 && lo % ((int64_t)g * CPT) == 0) span_groups = g;
+            if (row_groups % g == 0 && lo % ((int64_t)g * CPT) == 0 &&
+                (g == 1 || (hi - lo) / ((int64_t)g * CPT) >= 65536)) span_groups = g;
         vector_ok = (reinterpret_cast<uintptr_t>(d_safe_bits) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(d_init_bits) % 16 == 0);
         const int64_t spans = (hi - lo + (int64_t)span_groups * CPT - 1) / ((int64_t)span_groups * CPT);
         const int64_t need = (spans + SL_BLOCK - 1) / SL_BLOCK;
         if (need < blocks) blocks = (int)need;
     }
+    const bool fold_tail = blocks <= 256;
     if (blocks) {
         if ((hi - lo) & 63)     // whole bytes are written: clear the rest of the last mask word first
             SL_HIP_CHECK(ctx, hipMemsetAsync(d_safe_bits + ((hi - lo) >> 6), 0, sizeof(uint64_t), ctx->stream));
@@ -430,7 +463,8 @@ extern "C" int sl_lyap_finalize_dev(sl_ctx* ctx, int64_t lo, int64_t hi, const d
 #define SL_FIN(D_)                                                                                  \
     hipLaunchKernelGGL(k_finalize_dev<D_>, dim3(blocks), dim3(SL_BLOCK), 0, ctx->stream,            \
                        ctx->h_model, lo, hi, d_values, init_bytes, prev_bytes, d_folded, d_keep,    \
-                       safe_bytes, ctx->d_partials, ctx->d_partial_counts, span_groups, vector_ok)
+                       safe_bytes, ctx->d_partials, ctx->d_partial_counts, span_groups, vector_ok, \
+                       fold_tail ? reinterpret_cast<unsigned int*>(ctx->d_ticket + 1) : nullptr, d_result)
         switch (dt) {
             case 1: SL_FIN(1); break;
             case 2: SL_FIN(2); break;
@@ -441,9 +475,11 @@ extern "C" int sl_lyap_finalize_dev(sl_ctx* ctx, int64_t lo, int64_t hi, const d
 #undef SL_FIN
         SL_HIP_CHECK(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_reduce_finalize_dev, dim3(1), dim3(SL_BLOCK), 0, ctx->stream,
-                       ctx->d_partials, ctx->d_partial_counts, blocks, d_folded, d_result);
-    SL_HIP_CHECK(ctx, hipGetLastError());
+    if (!blocks || !fold_tail) {                        // (an empty range: the record of no cells)
+        hipLaunchKernelGGL(k_reduce_finalize_dev, dim3(1), dim3(SL_BLOCK), 0, ctx->stream,
+                           ctx->d_partials, ctx->d_partial_counts, blocks, d_folded, d_result);
+        SL_HIP_CHECK(ctx, hipGetLastError());
+    }
     return SL_OK;
 }
 

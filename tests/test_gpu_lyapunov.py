@@ -1241,3 +1241,72 @@ def test_one_panel_training_sets_run_on_the_4x4x4_kernel(sl, name, kw, monkeypat
     assert lyap._ctx.last_kernel().startswith("k_gp_small<"), lyap._ctx.last_kernel()
     assert_allclose(rec, rec_small, rtol=1e-9, atol=1e-13)
     _check_masks(neg, neg_small, rec, rec_small, allowed=0)
+
+
+def test_bounded_streaming_pass_equals_the_plain_one(sl):
+    """``sl_lyap_finalize_dev`` with ``can_shrink = True`` and a quadratic V bounds whole spans of a
+    row and evaluates one cell of those far above the level (``SlRowValues::span_bounded``); with a
+    previous set given (all zeros here: nothing to keep) it evaluates every cell.  Same safe words,
+    same record (last safe key, largest key, counters) bit for bit - over row lengths from 8 to 256
+    cells, ranges that start and end inside rows, levels from below the minimum to above the maximum
+    and matrices that are not positive definite; and both equal NumPy on the exact values."""
+    import torch
+    from np_shard_engine import np_vbits
+    from safe_learning_amd import _hip
+    from safe_learning_amd.benchmarks import build_lyapunov
+    rng = np.random.default_rng(12)
+    shapes = [("1d", dict(num_points=1000)), ("pendulum", dict(num_points=[37, 8], dynamics="linear")),
+              ("pendulum", dict(num_points=[33, 136], dynamics="linear")),
+              ("pendulum", dict(num_points=[300, 256], dynamics="linear")),
+              ("cartpole", dict(num_points=[5, 6, 7, 24], dynamics="linear")),
+              ("cartpole", dict(num_points=[9, 8, 12, 128], dynamics="linear"))]
+    for name, kw in shapes:
+        for trial in range(3):
+            case = cases.make_case(name, **kw)
+            d = len(case["num_points"])
+            if trial:
+                A = rng.normal(size=(d, d))
+                case["P"] = A @ A.T if trial == 1 else A          # trial 2: indefinite, not symmetric
+            lyap = build_lyapunov(case)
+            lyap.update_safe_set()                                  # uploads the model and the initial set
+            assert lyap._values_implicit
+            ctx, dev, n = lyap._ctx, lyap._ctx.torch_device, lyap.discretization.nindex
+            values = lyap.values
+            keys = np_vbits(values)
+            init_words = lyap._d_init.clone()
+            init = np.unpackbits(init_words.cpu().numpy().view(np.uint8), bitorder="little")[:n].astype(bool)
+            ranges = [(0, n)]
+            if n > 4096:
+                ranges += [(64 * 3, n - 8 * 5), (64 * int(rng.integers(1, n // 128)), n)]
+            picks = [int(np.argmin(values)), int(np.argmax(values))] + [int(j) for j in rng.choice(n, 4)]
+            for lo, hi in ranges:
+                words = (hi - lo + 63) // 64
+                shard_init = None
+                if lo == 0:
+                    shard_init = init_words
+                for star in [(keys[j], j) for j in picks] + [(np.uint64(0), -1), (~np.uint64(0), (1 << 63) - 1)]:
+                    folded = torch.zeros(_hip.RESULT_WORDS, dtype=torch.int64, device=dev)
+                    folded[_hip.R_FAIL_V] = int(np.uint64(star[0]).view(np.int64))
+                    folded[_hip.R_FAIL_I] = int(star[1])
+                    outs = []
+                    for prev in (None, torch.zeros(words + 1, dtype=torch.int64, device=dev)):
+                        safe = torch.full((words + 1,), -1, dtype=torch.int64, device=dev)
+                        record = torch.zeros(_hip.RESULT_WORDS, dtype=torch.int64, device=dev)
+                        ctx.lyap_finalize_dev(lo, hi, None, shard_init, prev, folded, None, safe, record)
+                        outs.append((safe[:words].cpu().numpy(), record.cpu().numpy()))
+                    assert_array_equal(outs[0][0], outs[1][0])
+                    assert_array_equal(outs[0][1], outs[1][1])
+                    # ... and NumPy on the exact values
+                    idx = np.arange(lo, hi)
+                    below = (keys[lo:hi] < star[0]) | ((keys[lo:hi] == star[0]) & (idx < star[1]))
+                    want = below | (init[lo:hi] if shard_init is not None else False)
+                    got = np.unpackbits(outs[0][0].view(np.uint8), bitorder="little")[:hi - lo].astype(bool)
+                    assert_array_equal(got, want)
+                    rec = outs[0][1]
+                    assert rec[_hip.R_BELOW] == below.sum() and rec[_hip.R_SAFE] == want.sum()
+                    order = np.lexsort((idx, keys[lo:hi]))
+                    assert rec[_hip.R_MAX_I] == idx[order[-1]]
+                    assert np.uint64(rec[_hip.R_MAX_V].view(np.uint64)) == keys[idx[order[-1]]]
+                    if below.any():
+                        last = idx[below][np.lexsort((idx[below], keys[lo:hi][below]))[-1]]
+                        assert rec[_hip.R_LAST_I] == last

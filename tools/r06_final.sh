@@ -1,6 +1,8 @@
 #!/bin/bash
-# Round 6, final GPU call: the records kept under profiles/ - GPU test suite, smoke, the driver's bench
-# command, every BASELINE configuration, SURVEY 8d's literal GP variant, profiles of the shipped kernels.
+# Round 6: the records kept under profiles/ - GPU test suite, smoke, the driver's bench command, every
+# BASELINE configuration, SURVEY 8d's literal GP variant, the host time of a small step, profiles of the
+# shipped kernels.   gpurun --timeout 3000 -- 'bash tools/r06_final.sh'   then copy gpurun_out/r06_final/*
+# into profiles/ and run tools/profiles_index.py.
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/r06_final; mkdir -p $OUT
@@ -18,6 +20,7 @@ echo "survey rc=$?"
 bash tools/bench_configs.sh > $OUT/r06_configs_table.txt 2>&1
 cp gpurun_out/configs.jsonl $OUT/r06_configs.jsonl
 cat $OUT/r06_configs_table.txt
+timeout -k 5 300 python tools/step_probe.py C1 3000 2>&1 | grep "us/step" > $OUT/r06_step_host_time.txt; cat $OUT/r06_step_host_time.txt
 bash tools/profile_r06.sh headline valu c5 > $OUT/profile.log 2>&1
 echo "profiles rc=$?"
 cp gpurun_out/r06_prof/*.md gpurun_out/r06_prof/*.txt gpurun_out/r06_prof/*.json $OUT/ 2>/dev/null
