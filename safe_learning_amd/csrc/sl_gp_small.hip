@@ -33,8 +33,9 @@ typedef double sl_d2 __attribute__((ext_vector_type(2)));
 namespace gps {
 // wavefronts per workgroup: 8 (two per SIMD), or 12 - three per SIMD, which caps the kernel at 168
 // registers (a handful of spills in the table check of the general flavour) and hides more of the
-// latency of its table look-ups; taken when the per-wavefront scratch of 12 wavefronts still fits LDS
-constexpr int WAVES_MIN = 8, WAVES_MAX = 12;
+// latency of its table look-ups; taken when the per-wavefront scratch of 12 wavefronts still fits LDS;
+// or 16 - four per SIMD at 128 registers, the factor read from L2 - on large sweeps (launch_small)
+constexpr int WAVES_MIN = 8, WAVES_MAX = 12, WAVES_TOP = 16;
 // (a 10-wavefront workgroup - what fits beside a factor in LDS - measured SLOWER than 8 on the
 // single-head table sweep: 2.31 against 2.22 ms, profiles/r04_configs.jsonl vs r04_gp_small_waves_ab.txt)
 constexpr int PRB = 8;            // row blocks (of 16 rows) per pass: 128 rows
@@ -368,11 +369,27 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
         return sizeof(double) * (small + (with_tri ? tri : 0) + scratch_of(waves)) <= cap;
     };
     // the factor in LDS matters most, then the third wavefront per SIMD
-    const int wmax = ctx->env.gp_small_waves >= 0 ? ctx->env.gp_small_waves : WAVES_MAX;
+    const int wmax = ctx->env.gp_small_waves >= 0 ? ctx->env.gp_small_waves : WAVES_TOP;
     int waves = WAVES_MIN;
     bool alds = fits(WAVES_MIN, true);
     // (the runtime-dimension instantiations need all 256 registers: two wavefronts per SIMD)
     if (DT > 0 && wmax >= WAVES_MAX && fits(WAVES_MAX, alds)) waves = WAVES_MAX;
+    // Large sweeps: FOUR wavefronts per SIMD (sixteen per workgroup, 128 registers - the spills that
+    // costs land in the per-cell check, none in the slab-pair loop): a wavefront's time per tile is a
+    // sum of latencies that only other wavefronts cover.  With the factor in LDS if that still fits;
+    // else with the factor read from L2, which beats two wavefronts per SIMD with it in LDS and three
+    // without (2001 x 1501 cells, 128 points, table flavour: 2.00 against 2.18 ms; two heads 3.41
+    // against 3.55; 48^4 cells, 192 points: 6.19 against 6.95) but not three with it in LDS (2048^2
+    // cells, 128 points: 2.28 against 2.11).  Below four tiles per wavefront of a full device the
+    // smaller workgroups reach more CUs (251 x 251 cells: 0.12 ms on 8 wavefronts, 0.18 on 16).
+    if (DT > 0 && wmax >= WAVES_TOP && ntiles >= (int64_t)4 * ctx->num_cu * WAVES_TOP) {
+        if (alds && fits(WAVES_TOP, true)) {
+            waves = WAVES_TOP;
+        } else if (!(alds && waves == WAVES_MAX) && fits(WAVES_TOP, false)) {
+            waves = WAVES_TOP;
+            alds = false;
+        }
+    }
     const size_t scratch = scratch_of(waves);
     const int head_doubles = (int)(small + (alds ? tri : 0));
     const size_t lds = sizeof(double) * ((size_t)head_doubles + scratch);
@@ -403,6 +420,9 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
     } while (0)
     if constexpr (DT > 0) {
         if (waves == WAVES_MAX) { if (alds) SL_GPS_GO(true, WAVES_MAX); else SL_GPS_GO(false, WAVES_MAX); }
+    }
+    if constexpr (DT > 0) {
+        if (waves == WAVES_TOP) { if (alds) SL_GPS_GO(true, WAVES_TOP); else SL_GPS_GO(false, WAVES_TOP); }
     }
     if (waves == WAVES_MIN) { if (alds) SL_GPS_GO(true, WAVES_MIN); else SL_GPS_GO(false, WAVES_MIN); }
 #undef SL_GPS_GO

@@ -250,3 +250,40 @@ def test_library_records_kernel_durations():
     safe = lyap.safe_set.copy()
     lyap.update_safe_set()
     assert_array_equal(lyap.safe_set, safe)
+
+
+@pytest.mark.parametrize("flags", [
+    dict(config="C2-table-large"),                                  # table flavour, factor from L2
+    dict(config="C2-notebook"),                                     # two heads, sum-of-products kernels
+    dict(config="C2", num_points=2048, n_gp=128),                   # fast path, factor in LDS
+    dict(config="C4", num_points=48, n_gp=192),                     # four state dimensions, factor from L2
+])
+def test_sixteen_wavefront_workgroups_of_the_small_gp_kernel(flags, monkeypatch):
+    """Large sweeps on small training sets run ``k_gp_small`` with sixteen wavefronts per workgroup
+    (four per SIMD, 128 registers; ``launch_small``): per-cell records, mask words and the failing
+    key must be the very bits the 8 / 12-wavefront kernels give (``SL_GP_SMALL_WAVES=12``, the
+    kernels every other test of this suite checks against the oracle)."""
+    import torch
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = _workload(**flags)
+    outs = []
+    for cap in (None, "12"):
+        if cap:
+            monkeypatch.setenv("SL_GP_SMALL_WAVES", cap)              # read when the context is created
+        lyap = build_lyapunov(case)
+        lyap._upload_model()
+        n, d = lyap.discretization.nindex, lyap.discretization.ndim
+        dev = lyap._ctx.torch_device
+        dbg = torch.zeros((n, 2 + 2 * d), dtype=torch.float64, device=dev)
+        bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+        record = torch.zeros_like(lyap._d_result)
+        lyap._refresh_init_bits()
+        lyap._ctx.lyap_sweep(0, n, lyap._d_init, lyap._values_arg(), bits, record, dbg)
+        kernel = lyap._ctx.last_kernel()
+        assert "k_gp_small" in kernel and ("16 wavefronts" in kernel) == (cap is None), kernel
+        outs.append((dbg, bits, record))
+        del lyap
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert torch.equal(outs[0][0].view(torch.int64), outs[1][0].view(torch.int64))
+    assert int((outs[0][0][:, 0] < outs[0][0][:, 1]).sum()) > 1000       # a mask that is not vacuous
