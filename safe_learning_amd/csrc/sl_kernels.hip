@@ -504,8 +504,11 @@ extern "C" int sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values) 
 // (k_policy_table), k_gp_sweep4 writes the posterior records of the closed loop with that table as
 // its policy, and k_check_records runs the decrease check with the real V and L_v on the records
 // (56 bytes per cell written and read back at d = 2, against ~0.5 MFLOP per cell at n = 512).
+#ifndef SL_GEN_WAVES
+#define SL_GEN_WAVES 2
+#endif
 template <bool GENERAL, int DT, int MT>
-__global__ __launch_bounds__(SL_BLOCK) void k_policy_table(const SlDevModel M_arg, SlAux aux_arg,
+__global__ __launch_bounds__(SL_BLOCK, GENERAL ? SL_GEN_WAVES : 1) void k_policy_table(const SlDevModel M_arg, SlAux aux_arg,
                                                            int64_t lo, int64_t hi,
                                                            const double* __restrict__ points,
                                                            double* __restrict__ actions) {
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(SL_BLOCK) void k_policy_table(const SlDevModel M_ar
 
 // records: [decrease, threshold, mean[d], err[d]] per cell of [lo, hi) from the posterior-only pass
 template <bool GENERAL, int DT, int MT>
-__global__ __launch_bounds__(SL_BLOCK) void k_check_records(
+__global__ __launch_bounds__(SL_BLOCK, GENERAL ? SL_GEN_WAVES : 1) void k_check_records(
     const SlDevModel M_arg, SlAux aux_arg, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
     const double* __restrict__ values, const double* __restrict__ records,
     uint64_t* __restrict__ neg_bits, sl_key* __restrict__ partials, double* __restrict__ dbg,
@@ -626,7 +629,7 @@ __device__ __forceinline__ void sl_constants_to_vgprs(SlDevModel& L) {
 // (three code paths, 64-bit shifts, operands read back from spilled scalar registers with
 // v_readlane) cost as much as the FP64 arithmetic of the check.  No explicit points, no records.
 template <bool GENERAL, int DT, int MT, int DYN, bool POW2 = false>
-__global__ __launch_bounds__(SL_BLOCK) void k_det_sweep(
+__global__ __launch_bounds__(SL_BLOCK, GENERAL ? SL_GEN_WAVES : 1) void k_det_sweep(
     const SlDevModel M_arg, SlAux aux_arg, int64_t lo, int64_t hi, const uint64_t* __restrict__ init_bits,
     const double* __restrict__ values, uint64_t* __restrict__ neg_bits,
     sl_key* __restrict__ partials, double* __restrict__ dbg, const double* __restrict__ points) {
