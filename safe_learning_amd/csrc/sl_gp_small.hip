@@ -36,6 +36,9 @@ namespace gps {
 // latency of its table look-ups; taken when the per-wavefront scratch of 12 wavefronts still fits LDS;
 // or 16 - four per SIMD at 128 registers, the factor read from L2 - on large sweeps (launch_small)
 constexpr int WAVES_MIN = 8, WAVES_MAX = 12, WAVES_TOP = 16;
+// ... or 4 on sweeps with fewer tiles than a device of 8-wavefront workgroups has wavefronts (the
+// notebooks' coarse 251 x 251 grids: 985 tiles): the workgroups then reach every CU (launch_small)
+constexpr int WAVES_TINY = 4;
 // (a 10-wavefront workgroup - what fits beside a factor in LDS - measured SLOWER than 8 on the
 // single-head table sweep: 2.31 against 2.22 ms, profiles/r04_configs.jsonl vs r04_gp_small_waves_ab.txt)
 constexpr int PRB = 8;            // row blocks (of 16 rows) per pass: 128 rows
@@ -73,13 +76,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
     const int d = nd.d, p = nd.p;
     const int nheads = gp.nheads;
     // LDS: per head [xs p x n_pad | alpha' n_pad x dout | lower-triangle fragments (ALDS)], then the
-    // wavefronts' scratch: cin [64][p], ssq [64], mean [64][d], err [64][d]
+    // wavefronts' scratch: ssq [64], mean [64][d], err [64][d] (the scaled inputs of a cell block
+    // travel between lanes by ds_bpermute: no LDS copy - 1.5 KB per wavefront at p = 3, which is what
+    // lets the factor of a 128-point table model sit in LDS beside sixteen wavefronts)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lcol = lane & 15, lk = lane >> 4;
-    const int wstride = 64 * (p + 1 + 2 * d);
-    double* cin = smem + head_doubles + wave * wstride;
-    double* ssq_w = cin + 64 * p;
+    const int wstride = 64 * (1 + 2 * d);
+    double* ssq_w = smem + head_doubles + wave * wstride;
     double* mean_w = ssq_w + 64;
     double* err_w = mean_w + 64 * d;
 
@@ -154,12 +158,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
         const sl_gp_kernel* kern = (KERN && hd.kernel) ? reinterpret_cast<const sl_gp_kernel*>(kern_l) : nullptr;
         const double* a_l = kern_l + (kern ? KERNEL_DOUBLES : 0);    // lower-triangle fragments (ALDS)
         head_base = a_l + (ALDS ? (size_t)tri_offset(nrb) * 128 : 0);
-        // this head's scaled inputs of the tile's cells (own lengthscales per head)
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < SL_P; ++q)
-            if (q < p) cin[lane * p + q] = x[q] * hd.inv_ls[q];
-        __builtin_amdgcn_wave_barrier();
 
         for (int pass = 0; pass < ((dg & 32) ? 0 : npass); ++pass) {
             const int rb0 = pass * PRB;                         // first row block of the pass
@@ -169,7 +167,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
             for (int cb = 0; cb < 4; ++cb) {
                 double xg[SL_P];
 #pragma unroll
-                for (int q = 0; q < SL_P; ++q) xg[q] = (q < p) ? cin[(16 * cb + lcol) * p + q] : 0.0;
+                for (int q = 0; q < SL_P; ++q)      // this head's scaled inputs (own lengthscales) of cell 16 cb + lcol
+                    xg[q] = (q < p) ? __shfl(x[q] * hd.inv_ls[q], 16 * cb + lcol, 64) : 0.0;
                 sl_d4 acc[PRB];
 #pragma unroll
                 for (int r = 0; r < PRB; ++r) acc[r] = (sl_d4){0.0, 0.0, 0.0, 0.0};
@@ -327,7 +326,7 @@ static size_t small_lds_doubles(sl_ctx* ctx, int p, int d) {
         small += (size_t)((p * h.n_pad + 1) & ~1) + (size_t)((h.n_pad * h.dout + 1) & ~1) +
                  (h.d_kernel ? gps::KERNEL_DOUBLES : 0);
     }
-    return small + (size_t)gps::WAVES_MIN * 64 * (p + 1 + 2 * d);
+    return small + (size_t)gps::WAVES_MIN * 64 * (1 + 2 * d);
 }
 
 static size_t lds_capacity(bool general) {
@@ -364,7 +363,7 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
         tri += (size_t)tri_offset((h.n + 15) / 16) * 128;         // row blocks with training points
     }
     const size_t cap = lds_capacity(GENERAL);
-    auto scratch_of = [&](int waves) { return (size_t)waves * 64 * (p + 1 + 2 * d); };
+    auto scratch_of = [&](int waves) { return (size_t)waves * 64 * (1 + 2 * d); };
     auto fits = [&](int waves, bool with_tri) {
         return sizeof(double) * (small + (with_tri ? tri : 0) + scratch_of(waves)) <= cap;
     };
@@ -373,7 +372,17 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
     int waves = WAVES_MIN;
     bool alds = fits(WAVES_MIN, true);
     // (the runtime-dimension instantiations need all 256 registers: two wavefronts per SIMD)
-    if (DT > 0 && wmax >= WAVES_MAX && fits(WAVES_MAX, alds)) waves = WAVES_MAX;
+    // Twelve only when the sweep fills a device of such workgroups: smaller workgroups reach more CUs
+    // (251 x 251 cells = 985 tiles: 0.128 ms on 8 wavefronts, 0.153 on 12).
+    if (DT > 0 && wmax >= WAVES_MAX && fits(WAVES_MAX, alds) && ntiles >= (int64_t)ctx->num_cu * WAVES_MAX)
+        waves = WAVES_MAX;
+    const int wtiny = ctx->env.gp_small_waves >= 0 ? ctx->env.gp_small_waves : WAVES_TINY;
+    // Fewer tiles than a device of 8-wavefront workgroups has wavefronts (a tile per wavefront at most):
+    // four per workgroup, so that they spread over twice the CUs (251 x 251 cells, 128 points, table
+    // flavour: 0.113 against 0.128 ms; two notebook heads: 0.32 against 0.36; with the factor read
+    // from L2 instead of staged by every workgroup: 0.131 - profiles/r06_gp_small_lds_ab.txt).
+    // SL_GP_SMALL_WAVES=8 keeps eight.
+    if (DT > 0 && wtiny == WAVES_TINY && ntiles < (int64_t)ctx->num_cu * WAVES_MIN) waves = WAVES_TINY;
     // Large sweeps: FOUR wavefronts per SIMD (sixteen per workgroup, 128 registers - the spills that
     // costs land in the per-cell check, none in the slab-pair loop): a wavefront's time per tile is a
     // sum of latencies that only other wavefronts cover.  With the factor in LDS if that still fits;
@@ -423,6 +432,9 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
     }
     if constexpr (DT > 0) {
         if (waves == WAVES_TOP) { if (alds) SL_GPS_GO(true, WAVES_TOP); else SL_GPS_GO(false, WAVES_TOP); }
+    }
+    if constexpr (DT > 0) {
+        if (waves == WAVES_TINY) { if (alds) SL_GPS_GO(true, WAVES_TINY); else SL_GPS_GO(false, WAVES_TINY); }
     }
     if (waves == WAVES_MIN) { if (alds) SL_GPS_GO(true, WAVES_MIN); else SL_GPS_GO(false, WAVES_MIN); }
 #undef SL_GPS_GO

@@ -253,7 +253,7 @@ def test_library_records_kernel_durations():
 
 
 @pytest.mark.parametrize("flags", [
-    dict(config="C2-table-large"),                                  # table flavour, factor from L2
+    dict(config="C2-table-large"),                                  # table flavour, factor in LDS (round 6)
     dict(config="C2-notebook"),                                     # two heads, sum-of-products kernels
     dict(config="C2", num_points=2048, n_gp=128),                   # fast path, factor in LDS
     dict(config="C4", num_points=48, n_gp=192),                     # four state dimensions, factor from L2
@@ -287,3 +287,38 @@ def test_sixteen_wavefront_workgroups_of_the_small_gp_kernel(flags, monkeypatch)
     assert torch.equal(outs[0][2], outs[1][2])
     assert torch.equal(outs[0][0].view(torch.int64), outs[1][0].view(torch.int64))
     assert int((outs[0][0][:, 0] < outs[0][0][:, 1]).sum()) > 1000       # a mask that is not vacuous
+
+
+@pytest.mark.parametrize("flags", [
+    dict(config="C2-table"),                                        # table flavour, 985 tiles
+    dict(config="C2-notebook", num_points=251),                     # two heads, sum-of-products kernels
+    dict(config="C2", num_points=128, n_gp=128),                    # fast path
+])
+def test_four_wavefront_workgroups_of_the_small_gp_kernel(flags, monkeypatch):
+    """Sweeps with fewer tiles than a device of 8-wavefront workgroups has wavefronts run ``k_gp_small``
+    with four wavefronts per workgroup (``launch_small``): the same bits as the 8-wavefront kernels
+    (``SL_GP_SMALL_WAVES=8``)."""
+    import torch
+    from safe_learning_amd.benchmarks import build_lyapunov
+    case = _workload(**flags)
+    outs = []
+    for cap in (None, "8"):
+        if cap:
+            monkeypatch.setenv("SL_GP_SMALL_WAVES", cap)              # read when the context is created
+        lyap = build_lyapunov(case)
+        lyap._upload_model()
+        n, d = lyap.discretization.nindex, lyap.discretization.ndim
+        dev = lyap._ctx.torch_device
+        dbg = torch.zeros((n, 2 + 2 * d), dtype=torch.float64, device=dev)
+        bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+        record = torch.zeros_like(lyap._d_result)
+        lyap._refresh_init_bits()
+        lyap._ctx.lyap_sweep(0, n, lyap._d_init, lyap._values_arg(), bits, record, dbg)
+        kernel = lyap._ctx.last_kernel()
+        assert "k_gp_small" in kernel and ("4 wavefronts" in kernel) == (cap is None), kernel
+        outs.append((dbg, bits, record))
+        del lyap
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert torch.equal(outs[0][0].view(torch.int64), outs[1][0].view(torch.int64))
+    assert int((outs[0][0][:, 0] < outs[0][0][:, 1]).sum()) > 100       # a mask that is not vacuous

@@ -1132,26 +1132,29 @@ def test_row_kernel_is_bit_identical(sl, name, kw, monkeypatch):
     assert lyap.c_max == olyap.c_max == ref.c_max
 
 
-def test_six_dimensional_stack_of_six_heads_falls_back_to_the_wide_kernel(sl):
+@pytest.mark.parametrize("m", [2, 1])
+def test_six_dimensional_stack_of_six_heads_falls_back_to_the_wide_kernel(sl, m):
     """A 6-D FunctionStack of six single-output GPs with 250 training points each (padded capacity
-    256, p = 7): the heads' inputs and alpha' (98 KB) plus the check's scratch (82 KB) exceed the
-    160 KB of LDS k_gp_small needs them in, so the sweep must take k_gp_sweep instead of failing
-    (advisor finding, round 3) - and agree with the oracle."""
+    256).  Two actions (p = 8): the heads' inputs and alpha' (110.6 KB) plus the check's scratch of
+    eight wavefronts (53.2 KB) exceed the 160 KB of LDS k_gp_small needs them in, so the sweep must
+    take k_gp_sweep instead of failing (advisor finding, round 3) - and agree with the oracle.  One
+    action (p = 7, 98 KB + 53 KB): fits since the scaled inputs left the scratch (round 6; it was
+    82 KB), k_gp_small takes it."""
     d, n_gp = 6, 250
     rng = np.random.default_rng(5)
     limits, num_points = [[-1.0, 1.0]] * d, [4] * d
     A = np.eye(d) * 0.9 + 0.02 * rng.normal(size=(d, d))
-    B = 0.1 * rng.normal(size=(d, 1))
-    K = -0.2 * rng.normal(size=(1, d))
+    B = 0.1 * rng.normal(size=(d, m))
+    K = -0.2 * rng.normal(size=(m, d))
     P = np.eye(d)
-    X = rng.uniform(-1, 1, (n_gp, d + 1))
+    X = rng.uniform(-1, 1, (n_gp, d + m))
     prior = np.hstack((A, B))
     Y = X @ prior.T + 1e-3 * np.sin(3 * X[:, :d]) + rng.normal(0, 2e-4, (n_gp, d))
     models = {}
     for ns in (sl, oracle):
         heads = []
         for k in range(d):
-            kern = ns.RBF(d + 1, 1e-6, np.full(d + 1, 1.0 + 0.1 * k), ARD=True)
+            kern = ns.RBF(d + m, 1e-6, np.full(d + m, 1.0 + 0.1 * k), ARD=True)
             gp = ns.GPRCached(X, Y[:, [k]], kern, ns.LinearSystem((prior[[k], :],)),
                               likelihood_variance=4e-8)
             heads.append(ns.GaussianProcess(gp, 2.0))
@@ -1165,7 +1168,7 @@ def test_six_dimensional_stack_of_six_heads_falls_back_to_the_wide_kernel(sl):
                                 ns.Saturation(ns.LinearSystem((K,)), -1.0, 1.0), initial_set=init)
     lyap, olyap = lyaps[sl], lyaps[oracle]
     values, neg, rec = _engine_records(lyap)
-    assert lyap._ctx.last_kernel().startswith("k_gp_sweep<"), lyap._ctx.last_kernel()
+    assert lyap._ctx.last_kernel().startswith("k_gp_sweep<" if m == 2 else "k_gp_small<"), lyap._ctx.last_kernel()
     ref_rec, ref_neg = _oracle_all(olyap)
     assert_array_equal(values, olyap.values)
     assert_allclose(rec[:, 2:2 + d], ref_rec[:, 2:2 + d], rtol=RTOL_GP, atol=1e-12)
@@ -1174,7 +1177,7 @@ def test_six_dimensional_stack_of_six_heads_falls_back_to_the_wide_kernel(sl):
     _check_masks(neg, ref_neg, rec, ref_rec)
     # four heads (1 + 1 + 2 + 2 outputs) of the same size still fit: the small kernel keeps them
     def head(cols):
-        return sl.GaussianProcess(sl.GPRCached(X, Y[:, cols], sl.RBF(d + 1, 1e-6, np.ones(d + 1), ARD=True),
+        return sl.GaussianProcess(sl.GPRCached(X, Y[:, cols], sl.RBF(d + m, 1e-6, np.ones(d + m), ARD=True),
                                                sl.LinearSystem((prior[cols, :],)),
                                                likelihood_variance=4e-8), 2.0)
     stack4 = sl.FunctionStack([head([0]), head([1]), head([2, 3]), head([4, 5])])
