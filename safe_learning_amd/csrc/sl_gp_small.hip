@@ -160,8 +160,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_gp_small(
         head_base = a_l + (ALDS ? (size_t)tri_offset(nrb) * 128 : 0);
 
         for (int pass = 0; pass < ((dg & 32) ? 0 : npass); ++pass) {
-            const int rb0 = pass * PRB;                         // first row block of the pass
-            const int rbn = nrb - rb0 < PRB ? nrb - rb0 : PRB;  // row blocks in it
+            // The SHORT pass comes first: a pass regenerates k_x up to its diagonal, and the top of the
+            // triangle needs the fewest slab pairs (130 points, nine row blocks: 2 + 18 slab pairs with
+            // the one-block pass in front, 16 + 18 with it behind).
+            const int first = nrb - (npass - 1) * PRB;          // row blocks of pass 0 (1 .. PRB)
+            const int rb0 = pass == 0 ? 0 : first + (pass - 1) * PRB;   // first row block of the pass
+            const int rbn = pass == 0 ? first : PRB;            // row blocks in it
             const int ns2 = 2 * (rb0 + rbn);                    // slab pairs up to its diagonal
             const int new_s2 = 2 * rb0;                         // training points not seen before
             for (int cb = 0; cb < 4; ++cb) {
