@@ -68,8 +68,10 @@ def test_sweep_kernels_reproduce_the_reference_posterior(spec, fixture):
     d = case["d"]
     dynamics = reference_gp_model(F, spec, case, fixture)
     policy, _, value, lv = build_specs(case)
+    mask = initial_safe_mask(case)
+    mask.flags.writeable = False          # identified by object identity, not hashed (256 MB at C4)
     lyap = sl.Lyapunov(sl.GridWorld(case["limits"], case["num_points"]), value, dynamics, case["lf"],
-                       lv, case["tau"], policy, initial_set=initial_safe_mask(case))
+                       lv, case["tau"], policy, initial_set=mask)
     lyap._upload_model()
     lyap._refresh_init_bits()
     tol = reference_gp_tolerance(float(fixture[name + "/cond"]))
