@@ -278,8 +278,11 @@ __global__ __launch_bounds__(256) void k_bellman_cached(
 // reference's interpolation rule extrapolates from a neighbouring simplex (functions.py:1103-1158:
 // rectangle by digitize, simplex by x mod unit_maxes) - go to the miss list (at most `cap` of them
 // are recorded, misses[0] counts all): k_succ_policy_miss evaluates them one by one.
+#ifndef SL_SUCC_SELECT_WAVES
+#define SL_SUCC_SELECT_WAVES 4
+#endif
 template <int DT>
-__global__ __launch_bounds__(256) void k_succ_select(const SlDevModel M, SlAux aux, const SlSuccDev sc,
+__global__ __launch_bounds__(256, SL_SUCC_SELECT_WAVES) void k_succ_select(const SlDevModel M, SlAux aux, const SlSuccDev sc,
                                                      int64_t lo, int64_t hi, int n_actions,
                                                      double* __restrict__ usel, int8_t* __restrict__ asel,
                                                      unsigned long long* __restrict__ misses,

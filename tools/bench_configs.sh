@@ -3,8 +3,11 @@
 mkdir -p gpurun_out
 : > gpurun_out/configs.jsonl
 for c in ${@:-C1 C2 C2-table C2-table-large C2-table-stack C2-notebook C2-table-det C3 C4-lin C4-det C5 C5-policy}; do
-  steps=10; [ "$c" = C3 ] && steps=3
-  timeout 600 python bench.py --config $c --steps $steps --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{' >> gpurun_out/configs.jsonl
+  # steps: 3 (C3, 0.27 s each), 10 (10 ms and more), 200 for the sub-10-ms configurations - 10 steps of a 0.4 ms
+  # update end before the clocks have settled (C2: 0.37 ms kernel over 10 steps, 0.33 over 200)
+  steps=200; warm=20
+  case $c in C3) steps=3; warm=2;; C4-det|C5) steps=10; warm=2;; esac
+  timeout 600 python bench.py --config $c --steps $steps --warmup $warm --no-cpu-baseline 2>/dev/null | grep '^{' >> gpurun_out/configs.jsonl
 done
 python - <<'PY'
 import json
