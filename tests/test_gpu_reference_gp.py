@@ -68,8 +68,8 @@ def test_sweep_kernels_reproduce_the_reference_posterior(spec, fixture):
     d = case["d"]
     dynamics = reference_gp_model(F, spec, case, fixture)
     policy, _, value, lv = build_specs(case)
-    mask = initial_safe_mask(case)
-    mask.flags.writeable = False          # identified by object identity, not hashed (256 MB at C4)
+    mask = np.array(initial_safe_mask(case), copy=True)   # an array of its own (no writable base) ...
+    mask.flags.writeable = False          # ... read-only: identified by object identity, not hashed (256 MB at C4)
     lyap = sl.Lyapunov(sl.GridWorld(case["limits"], case["num_points"]), value, dynamics, case["lf"],
                        lv, case["tau"], policy, initial_set=mask)
     lyap._upload_model()
