@@ -376,17 +376,36 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
     int waves = WAVES_MIN;
     bool alds = fits(WAVES_MIN, true);
     // (the runtime-dimension instantiations need all 256 registers: two wavefronts per SIMD)
-    // Twelve only when the sweep fills a device of such workgroups: smaller workgroups reach more CUs
-    // (251 x 251 cells = 985 tiles: 0.128 ms on 8 wavefronts, 0.153 on 12).
-    if (DT > 0 && wmax >= WAVES_MAX && fits(WAVES_MAX, alds) && ntiles >= (int64_t)ctx->num_cu * WAVES_MAX)
+    const int wcap = ctx->env.gp_small_waves;        // SL_GP_SMALL_WAVES: 8 = eight only, 12 = no sixteen, 4 = four or eight
+    auto allowed = [&](int w) {
+        return w == WAVES_MIN || wcap < 0 || (w > WAVES_MIN && w <= wcap) || (w == WAVES_TINY && wcap == WAVES_TINY);
+    };
+    if (DT > 0 && ntiles < (int64_t)4 * ctx->num_cu * WAVES_TOP) {
+        // Below four rounds of the largest workgroups a sweep is a handful of ROUNDS of one tile per
+        // wavefront, and a round lasts as long as its slowest tile: the workgroup size with the least
+        // (rounds x time of a full round) - 0.105 / 0.128 / 0.16 / 0.22 ms for 4 / 8 / 12 / 16 wavefronts
+        // per workgroup on the 128-point table model (0.19 on sixteen when the factor comes from L2
+        // anyway: more wavefronts cover more of that latency), not rounded up where the tile counter is
+        // on (more than four tiles per wavefront: 12 688 tiles take 0.66 ms on twelve, 0.79 on
+        // sixteen).  Measured (profiles/r06_gp_small_lds_ab.txt; tiles: ms before -> after): 1 416:
+        // 0.203 -> 0.133, 2 513: 0.247 -> 0.167, 3 922: 0.305 -> 0.245, 7 678: 0.455 -> 0.429; two
+        // notebook heads on 2 513: 0.706 -> 0.445; 985 tiles on four wavefronts 0.113 (0.128 on eight;
+        // 0.131 with the factor read from L2 instead of staged in LDS by every workgroup).
+        const int sizes[4] = {WAVES_TINY, WAVES_MIN, WAVES_MAX, WAVES_TOP};
+        const int weight[4] = {105, 128, 160, fits(WAVES_TOP, true) ? 220 : 190};
+        int64_t best = -1;
+        for (int k = 0; k < 4; ++k) {
+            if (!allowed(sizes[k]) || !fits(sizes[k], false)) continue;
+            const int64_t per_round = (int64_t)sizes[k] * ctx->num_cu;
+            // (eight wavefronts with the counter on: 10 026 tiles in 0.61 ms against 0.595 in four rounds of twelve)
+            const int64_t cost = ntiles > 4 * per_round ? ntiles * (weight[k] + (k == 1 ? 12 : 0)) / per_round
+                                                        : ((ntiles + per_round - 1) / per_round) * weight[k];
+            if (best < 0 || cost < best) { best = cost; waves = sizes[k]; }
+        }
+        alds = fits(waves, true);
+    } else if (DT > 0 && allowed(WAVES_MAX) && fits(WAVES_MAX, alds)) {
         waves = WAVES_MAX;
-    const int wtiny = ctx->env.gp_small_waves >= 0 ? ctx->env.gp_small_waves : WAVES_TINY;
-    // Fewer tiles than a device of 8-wavefront workgroups has wavefronts (a tile per wavefront at most):
-    // four per workgroup, so that they spread over twice the CUs (251 x 251 cells, 128 points, table
-    // flavour: 0.113 against 0.128 ms; two notebook heads: 0.32 against 0.36; with the factor read
-    // from L2 instead of staged by every workgroup: 0.131 - profiles/r06_gp_small_lds_ab.txt).
-    // SL_GP_SMALL_WAVES=8 keeps eight.
-    if (DT > 0 && wtiny == WAVES_TINY && ntiles < (int64_t)ctx->num_cu * WAVES_MIN) waves = WAVES_TINY;
+    }
     // Large sweeps: FOUR wavefronts per SIMD (sixteen per workgroup, 128 registers - the spills that
     // costs land in the per-cell check, none in the slab-pair loop): a wavefront's time per tile is a
     // sum of latencies that only other wavefronts cover.  With the factor in LDS if that still fits;
