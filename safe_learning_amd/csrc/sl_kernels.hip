@@ -454,7 +454,8 @@ static inline int sl_dim_variant(const SlDevModel& M) {
 #ifndef SL_GEN_WAVES
 #define SL_GEN_WAVES 2
 #endif
-// ... and the kernels that ONLY look a table up (k_values, k_policy_table of the general flavour)
+// ... and the kernels that ONLY look a table up (k_values, k_policy_table of the general flavour with
+// compile-time dimensions; the runtime-dimension fallbacks need the registers)
 #ifndef SL_TABLE_WAVES
 #define SL_TABLE_WAVES 4
 #endif
@@ -462,7 +463,7 @@ static inline int sl_dim_variant(const SlDevModel& M) {
 // values: V(x_i)                                             (lyapunov.py:305-322)
 // =============================================================================================
 template <bool GENERAL, int DT, int MT>
-__global__ __launch_bounds__(SL_BLOCK, GENERAL ? SL_TABLE_WAVES : 1) void k_values(const SlDevModel M_arg, SlAux aux_arg, int64_t lo,
+__global__ __launch_bounds__(SL_BLOCK, GENERAL ? (DT > 0 ? SL_TABLE_WAVES : SL_GEN_WAVES) : 1) void k_values(const SlDevModel M_arg, SlAux aux_arg, int64_t lo,
                                                      int64_t hi, double* __restrict__ values) {
     __shared__ SlTriLds<GENERAL> tri_lds;
     const SlAux aux = sl_stage_aux<GENERAL>(tri_lds, aux_arg);
@@ -515,7 +516,7 @@ extern "C" int sl_values(sl_ctx* ctx, int64_t lo, int64_t hi, double* d_values) 
 // its policy, and k_check_records runs the decrease check with the real V and L_v on the records
 // (56 bytes per cell written and read back at d = 2, against ~0.5 MFLOP per cell at n = 512).
 template <bool GENERAL, int DT, int MT>
-__global__ __launch_bounds__(SL_BLOCK, GENERAL ? SL_TABLE_WAVES : 1) void k_policy_table(const SlDevModel M_arg, SlAux aux_arg,
+__global__ __launch_bounds__(SL_BLOCK, GENERAL ? (DT > 0 ? SL_TABLE_WAVES : SL_GEN_WAVES) : 1) void k_policy_table(const SlDevModel M_arg, SlAux aux_arg,
                                                            int64_t lo, int64_t hi,
                                                            const double* __restrict__ points,
                                                            double* __restrict__ actions) {
