@@ -672,13 +672,19 @@ int sl_gp_sweep_launch(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_t
     if (other_kernels && sl_gp_small_supports(ctx, model))
         return sl_gp_small_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,
                                   d_dbg, d_points);
-    // 193 .. 256 training points per head (capacity exactly one 256-row panel of k_gp_sweep4): the
-    // factor no longer fits LDS, k_gp_small waits for its fragments from L2 (2.0 ms at 256 points on
+    // 225 .. 256 training points per head (capacity exactly one 256-row panel of k_gp_sweep4): the
+    // factor no longer fits LDS, k_gp_small waits for its fragments from L2 (1.9 ms at 256 points on
     // 1024^2 cells, 0.6 ms at 128) while k_gp_sweep4 prefetches them two slab pairs ahead - fast-path
-    // models with RBF heads take it on ONE panel (SL_GP4_ONE_PANEL=0: keep k_gp_small).
+    // models with RBF heads take it on ONE panel (SL_GP4_ONE_PANEL=0: keep k_gp_small).  k_gp_small
+    // pays for the row blocks that hold training points, the panel for its 256 rows: at 224 points
+    // the two meet, below k_gp_small wins (round 6, sixteen wavefronts and the short pass first:
+    // 1024^2 cells 1.39 / 1.54 / 1.71 / 1.91 ms at 200 / 224 / 240 / 256 points against 1.50 - 1.52 on the
+    // panel; 48^4: 6.90 / 7.78 / 9.66 against 7.95 - profiles/r06_one_panel_ab.txt; round 5 had the
+    // crossing at 200, profiles/r05_one_panel_ab.txt).
     if (ctx->gp_cfg == 0 && !other_kernels && sl_gp4_supports(model)) {
         bool one_panel = true;
-        for (int h = 0; h < ctx->h_gp.nheads; ++h) one_panel = one_panel && ctx->gp_heads[h].n_pad == 256;
+        for (int h = 0; h < ctx->h_gp.nheads; ++h)
+            one_panel = one_panel && ctx->gp_heads[h].n_pad == 256 && ctx->gp_heads[h].n > 224;
         if (ctx->env.gp4_one_panel == 0) one_panel = false;
         if (one_panel)
             return sl_gp4_sweep_launch(ctx, model, lo, hi, d_init_bits, d_values, d_neg_bits, nblocks,

@@ -1218,15 +1218,16 @@ def test_gp4_sequence_seeds_are_bit_identical(sl, monkeypatch):
 
 
 @pytest.mark.parametrize("name,kw", [
-    ("pendulum", dict(num_points=48, n_gp=200, tau_scale=0.01)),
+    ("pendulum", dict(num_points=48, n_gp=225, tau_scale=0.01)),
     ("pendulum", dict(num_points=[40, 64], n_gp=256, tau_scale=0.01)),
     ("cartpole", dict(num_points=[5, 6, 5, 32], n_gp=230, tau_scale=0.0)),
-    ("cartpole", dict(num_points=7, n_gp=200, tau_scale=0.0, stack=True)),
+    ("cartpole", dict(num_points=7, n_gp=240, tau_scale=0.0, stack=True)),
 ])
 def test_one_panel_training_sets_run_on_the_4x4x4_kernel(sl, name, kw, monkeypatch):
-    """193 ... 256 training points per head = exactly one 256-row panel: k_gp_sweep4 (whose factor
-    fragments are prefetched from L2) instead of k_gp_small (whose factor no longer fits LDS) - the
-    same records as the oracle's and, bit for bit in the masks, as k_gp_small's."""
+    """225 ... 256 training points per head = one 256-row panel that is nearly full: k_gp_sweep4 (whose
+    factor fragments are prefetched from L2) instead of k_gp_small (whose factor no longer fits LDS;
+    up to 224 points it is the faster one all the same, round 6) - the same records as the oracle's
+    and, bit for bit in the masks, as k_gp_small's."""
     from gp_cases import INFORMED, TIGHT
     from safe_learning_amd.benchmarks import build_lyapunov
     case = cases.make_case(name, **dict(kw, **(TIGHT if name == "cartpole" else INFORMED)))
@@ -1244,6 +1245,17 @@ def test_one_panel_training_sets_run_on_the_4x4x4_kernel(sl, name, kw, monkeypat
     assert lyap._ctx.last_kernel().startswith("k_gp_small<"), lyap._ctx.last_kernel()
     assert_allclose(rec, rec_small, rtol=1e-9, atol=1e-13)
     _check_masks(neg, neg_small, rec, rec_small, allowed=0)
+
+
+def test_up_to_224_training_points_stay_on_the_small_kernel(sl):
+    """193 ... 224 points: the padded capacity is one 256-row panel, but k_gp_small - which pays for the
+    row blocks that hold training points - is the faster kernel (``sl_gp.hip``)."""
+    from gp_cases import INFORMED
+    from safe_learning_amd.benchmarks import build_lyapunov
+    for n_gp in (193, 224):
+        lyap = build_lyapunov(cases.make_case("pendulum", num_points=48, n_gp=n_gp, tau_scale=0.01, **INFORMED))
+        lyap.update_safe_set()
+        assert lyap._ctx.last_kernel().startswith("k_gp_small<"), (n_gp, lyap._ctx.last_kernel())
 
 
 def test_bounded_streaming_pass_equals_the_plain_one(sl):
