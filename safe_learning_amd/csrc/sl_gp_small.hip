@@ -392,7 +392,9 @@ static int launch_small(sl_ctx* ctx, const SlDevModel& model, int64_t lo, int64_
         // notebook heads on 2 513: 0.706 -> 0.445; 985 tiles on four wavefronts 0.113 (0.128 on eight;
         // 0.131 with the factor read from L2 instead of staged in LDS by every workgroup).
         const int sizes[4] = {WAVES_TINY, WAVES_MIN, WAVES_MAX, WAVES_TOP};
-        const int weight[4] = {105, 128, 160, fits(WAVES_TOP, true) ? 220 : 190};
+        // (sixteen WITHOUT the factor in LDS where twelve would have it: the large-sweep rule below
+        // keeps twelve in that case - 2.28 against 2.11 ms - and so does the weight)
+        const int weight[4] = {105, 128, 160, fits(WAVES_TOP, true) ? 220 : (fits(WAVES_MAX, true) ? 240 : 190)};
         int64_t best = -1;
         for (int k = 0; k < 4; ++k) {
             if (!allowed(sizes[k]) || !fits(sizes[k], false)) continue;
