@@ -3,7 +3,8 @@
 
 A spec is evaluated by putting it into the slot of a throw-away engine model that matches its
 role (value function, policy, dynamics); all arithmetic runs in the same device functions as
-the grid sweeps."""
+the grid sweeps.  The payloads (GP factors, tables, networks) stay on the evaluation context
+between calls and are uploaded again only when their version tokens change."""
 
 import numpy as np
 
@@ -41,9 +42,24 @@ def _on_device(x):
     return isinstance(x, torch.Tensor)
 
 
+_persistent_builder = None
+_dummy_grids = {}
+
+
 def _builder(d):
+    """The evaluation context's ONE builder (it remembers which GP heads / tables / networks the
+    context holds - version tokens, ``_model.py`` - so a spec that did not change is not packed and
+    uploaded again by every call: ``get_safe_sample`` evaluates the same GP, value table and policy
+    every iteration of the exploration loop) with a throw-away grid of ``d`` dimensions."""
+    global _persistent_builder
+    import copy
     ctx = _ctx()
-    return ctx, ModelBuilder(ctx, _dummy_grid(d))
+    if _persistent_builder is None:
+        _persistent_builder = ModelBuilder(ctx, None)
+    if d not in _dummy_grids:
+        _dummy_grids[d] = _dummy_grid(d)
+    _persistent_builder.grid = copy.copy(_dummy_grids[d])     # (dynamics() edits its nindex)
+    return ctx, _persistent_builder
 
 
 def value(spec, points, lipschitz=None):
