@@ -439,6 +439,17 @@ SL_API int  sl_lyapunov_region(sl_ctx* ctx, const double* d_values, int64_t star
 /* Bit mask <-> byte mask helpers for the bool[N] safe_set of the reference (lyapunov.py:187). */
 SL_API int  sl_bits_to_bytes(sl_ctx* ctx, int64_t n, const uint64_t* d_bits, uint8_t* d_bytes);
 SL_API int  sl_bytes_to_bits(sl_ctx* ctx, int64_t n, const uint8_t* d_bytes, uint64_t* d_bits);
+/* np.where(safe_set) (lyapunov.py:729, the first step of get_safe_sample): the flat indices of the set
+ * bits of a mask of n cells, ascending.  Two calls, because the caller sizes d_indices by the count:
+ *   sl_bits_count      d_block_counts [ceil(ceil(n/64)/256)] and d_offsets [that + 1] are scratch it fills
+ *                      (set bits per 16 384 cells, their exclusive prefix sums); *total_out (HOST) = number
+ *                      of set bits - one 8-byte copy and a stream synchronisation;
+ *   sl_bits_to_indices d_indices [total] out, with the d_offsets of the count call.
+ * Bits of the last word beyond n are ignored. */
+SL_API int  sl_bits_count(sl_ctx* ctx, int64_t n, const uint64_t* d_bits, uint32_t* d_block_counts,
+                          int64_t* d_offsets, int64_t* total_out);
+SL_API int  sl_bits_to_indices(sl_ctx* ctx, int64_t n, const uint64_t* d_bits, const int64_t* d_offsets,
+                               int64_t* d_indices);
 
 /* ---- dynamic programming (reinforcement_learning.py:65-140, 213-279) --------------------- */
 /* One Jacobi sweep over vertices [lo,hi) of the value grid (auxiliary grid #0):

@@ -123,7 +123,7 @@ EXPORTS = [
     "sl_adaptive_sort_keys", "sl_adaptive_analyse", "sl_adaptive_apply", "sl_adaptive_scatter",
     "sl_index_to_state", "sl_perturb_pairs", "sl_rows_sort_key", "sl_rows_duplicate_flags",
     "sl_sample_bounds", "sl_state_membership", "sl_argmax_masked", "sl_argmax_rows_masked", "sl_lyapunov_region",
-    "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bellman_sweep", "sl_successor_cache_configure",
+    "sl_bits_to_bytes", "sl_bytes_to_bits", "sl_bits_count", "sl_bits_to_indices", "sl_bellman_sweep", "sl_successor_cache_configure",
     "sl_successor_cache_info", "sl_eval_points", "sl_timing_configure", "sl_timing_collect",
     "sl_comm_unique_id", "sl_comm_init", "sl_comm_destroy", "sl_allreduce_result", "sl_allgather",
     "sl_allreduce_sum_u64", "sl_allreduce_max_f64",
@@ -210,6 +210,8 @@ def load_library():
     lib.sl_argmax_rows_masked.argtypes = [vp, i64, C.c_int, vp, vp, i64, vp]
     lib.sl_lyapunov_region.argtypes = [vp, vp, i64, vp, vp, C.POINTER(C.c_int)]
     lib.sl_bits_to_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.sl_bits_count.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.sl_bits_to_indices.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sl_bytes_to_bits.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sl_bellman_sweep.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, c_double_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -534,6 +536,19 @@ class Context(object):
     def bits_to_bytes(self, n, d_bits, d_bytes):
         self.check(self.lib.sl_bits_to_bytes(self.handle, n, _ptr(d_bits), _ptr(d_bytes)),
                    "sl_bits_to_bytes")
+
+    def bits_count(self, n, d_bits, d_block_counts, d_offsets):
+        """-> number of set bits among the first ``n`` (``sl_bits_count``; fills the two scratch arrays)."""
+        total = C.c_int64(0)
+        self.check(self.lib.sl_bits_count(self.handle, n, _ptr(d_bits), _ptr(d_block_counts), _ptr(d_offsets),
+                                          C.byref(total)), "sl_bits_count")
+        return total.value
+
+    def bits_to_indices(self, n, d_bits, d_offsets, d_indices):
+        if d_indices.numel() == 0:               # no bit set: nothing to write
+            return
+        self.check(self.lib.sl_bits_to_indices(self.handle, n, _ptr(d_bits), _ptr(d_offsets), _ptr(d_indices)),
+                   "sl_bits_to_indices")
 
     def bytes_to_bits(self, n, d_bytes, d_bits):
         self.check(self.lib.sl_bytes_to_bits(self.handle, n, _ptr(d_bytes), _ptr(d_bits)),

@@ -1037,13 +1037,16 @@ class _SampleKernels(object):
         return self.torch.empty(shape, dtype=dtype or self.torch.int64, device=self.dev)
 
     def safe_indices(self, words, n):
-        """Flat indices of the set bits, ascending (``np.where(safe_set)``, lyapunov.py:729)."""
-        d_bytes = self._empty(max(-(-n // 8) * 8, 8), dtype=self.torch.uint8)
-        self.ctx.bits_to_bytes(n, words, d_bytes)
-        perm, buckets = self._empty(n), self._empty(256)
-        self.ctx.partition_by_digit(n, d_bytes, perm, buckets, self.counts)   # unsafe cells first
-        count = int(buckets[1])
-        return perm[n - count:]
+        """Flat indices of the set bits, ascending (``np.where(safe_set)``, lyapunov.py:729): counted
+        and written from the mask words (``sl_bits_count`` / ``sl_bits_to_indices``: n / 8 bytes read,
+        8 bytes per safe cell written - not a partition of all n cells)."""
+        nblocks = -(-(-(-n // 64)) // 256)
+        block_counts = self._empty(max(nblocks, 1), dtype=self.torch.int32)
+        offsets = self._empty(nblocks + 1)
+        count = self.ctx.bits_count(n, words, block_counts, offsets)
+        out = self._empty(max(count, 1))[:count]
+        self.ctx.bits_to_indices(n, words, offsets, out)
+        return out
 
     def take(self, rows, picks):
         """``rows[picks]`` for a 1-D or 2-D int64 / float64 tensor (``sl_gather_rows``)."""

@@ -167,3 +167,30 @@ def test_get_safe_sample_over_an_action_grid(sl, positive):
         opair, obound = oracle.get_safe_sample(olyap, None, None, positive=positive, actions=actions)
     assert_array_equal(pair, opair)
     assert_allclose(bound, obound, rtol=1e-7)
+
+
+@pytest.mark.parametrize("n,density", [(1, 1.0), (63, 0.5), (64, 0.0), (1000, 0.3), (16384, 1.0), (16385, 0.01),
+                                       (70001, 0.5), (3003501, 0.03), (3003501, 1.0)])
+def test_safe_indices_are_numpy_where(sl, n, density):
+    """``np.where(safe_set)`` of get_safe_sample (``lyapunov.py:729``) from the mask words
+    (``sl_bits_count`` + ``sl_bits_to_indices``): every set bit, ascending, bits beyond n ignored."""
+    import torch
+    from safe_learning_amd import _hip
+    rng = np.random.default_rng(n)
+    mask = rng.random(n) < density
+    ctx = _hip.Context()
+    dev = ctx.torch_device
+    nwords = (n + 63) // 64
+    padded = np.zeros(nwords * 64, dtype=bool)
+    padded[:n] = mask
+    padded[n:] = True                                   # garbage beyond n must not be reported
+    words = torch.from_numpy(np.packbits(padded, bitorder="little").view(np.int64).copy()).to(dev)
+    nblocks = -(-nwords // 256)
+    counts = torch.empty(nblocks, dtype=torch.int32, device=dev)
+    offsets = torch.empty(nblocks + 1, dtype=torch.int64, device=dev)
+    total = ctx.bits_count(n, words, counts, offsets)
+    want = np.flatnonzero(mask)
+    assert total == len(want)
+    out = torch.empty(max(total, 1), dtype=torch.int64, device=dev)[:total]
+    ctx.bits_to_indices(n, words, offsets, out)
+    assert_array_equal(out.cpu().numpy(), want)
