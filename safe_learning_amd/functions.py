@@ -642,6 +642,7 @@ class Triangulation(DeterministicFunction):
         self.name = name
         self._parameters = None
         self._device_table = None
+        self._table_thunk = None                   # (callable, columns): a device table not built yet
         self._table_version = next(_TOKENS)
         self._structure_token = next(_TOKENS)      # grid + unit-cell simplices never change
         if vertex_values is not None:
@@ -677,6 +678,8 @@ class Triangulation(DeterministicFunction):
             return self._parameters.shape[1]
         if self._device_table is not None:
             return int(self._device_table.shape[1])
+        if self._table_thunk is not None:
+            return int(self._table_thunk[1])
         return None
 
     @property
@@ -690,11 +693,13 @@ class Triangulation(DeterministicFunction):
         self._parameters = np.ascontiguousarray(
             np.asarray(values, dtype=config.np_dtype).reshape(self.nindex, -1))
         self._device_table = None
+        self._table_thunk = None
         self._table_version = next(_TOKENS)
 
     def _device(self, ctx):
         """Device copy of the vertex table (uploaded lazily)."""
         import torch
+        self._resolve_table()
         if self._device_table is None or self._device_table.device != ctx.torch_device:
             self._device_table = torch.from_numpy(self._host_parameters()).to(ctx.torch_device)
         return self._device_table
@@ -702,10 +707,27 @@ class Triangulation(DeterministicFunction):
     def _adopt_device_table(self, tensor):
         """Make a device tensor the truth (value iteration keeps V on the GPU)."""
         self._device_table = tensor.reshape(self.nindex, -1)
+        self._table_thunk = None
         self._parameters = None
         self._table_version = next(_TOKENS)
 
+    def _adopt_lazy_device_table(self, build, columns):
+        """Like ``_adopt_device_table`` with a table that is only built (``build()`` -> device
+        tensor) when somebody reads it: the greedy policy of a value-iteration sweep is replaced by
+        the next sweep's before anything looked at it."""
+        self._device_table = None
+        self._table_thunk = (build, int(columns))
+        self._parameters = None
+        self._table_version = next(_TOKENS)
+
+    def _resolve_table(self):
+        if self._table_thunk is not None:
+            build, _ = self._table_thunk
+            self._table_thunk = None
+            self._device_table = build().reshape(self.nindex, -1)
+
     def _host_parameters(self):
+        self._resolve_table()
         if self._parameters is None and self._device_table is not None:
             self._parameters = self._device_table.cpu().numpy().reshape(self.nindex, -1)
         return self._parameters

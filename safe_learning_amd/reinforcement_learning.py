@@ -82,6 +82,13 @@ class PolicyIteration(object):
         # a full shard's capacity on every rank: the gathers are one all_gather_into_tensor of
         # equal pieces (distributed.allgather_equal), no pad copy
         count = max(self._bounds[1] - self._bounds[0] if dist_utils.is_distributed() else hi - lo, 1)
+        if actions is not None:
+            # a sweep over an action set never evaluates the policy: a constant stands in its slot, so
+            # that a greedy table adopted by the previous sweep is neither built nor uploaded for it
+            width = int(np.atleast_2d(np.asarray(actions)).shape[1])
+            if getattr(self, '_placeholder_policy', None) is None or self._placeholder_policy.output_dim != width:
+                self._placeholder_policy = ConstantFunction(np.zeros(width))
+            policy = self._placeholder_policy
         self._upload(policy)
         v_new = torch.empty(count, dtype=torch.float64, device=dev)
         stats = torch.zeros(2, dtype=torch.float64, device=dev)
@@ -198,12 +205,15 @@ class PolicyIteration(object):
         if getattr(self, '_actions_dev_key', None) != key:
             self._actions_dev = torch.from_numpy(np.ascontiguousarray(action_space)).to(best.device)
             self._actions_dev_key = key
-        # (index_select takes the int32 indices as they are; `actions[best]` first converts them to
-        # int64 - a second 16.7 M-element kernel per sweep at 64^4)
-        table = torch.index_select(self._actions_dev, 0, best.reshape(-1))
         if not isinstance(self.policy, Triangulation):
             self.policy = Triangulation(self.discretization)
-        self.policy._adopt_device_table(table.contiguous())
+        actions_dev, picks = self._actions_dev, best.reshape(-1)
+        # The table is built when somebody reads it (the next policy evaluation, `policy.parameters`):
+        # in a value-iteration loop the next sweep replaces it unread.  (index_select takes the int32
+        # indices as they are; `actions[best]` first converts them to int64 - a second 16.7 M-element
+        # kernel at 64^4.)
+        self.policy._adopt_lazy_device_table(
+            lambda: torch.index_select(actions_dev, 0, picks).contiguous(), actions_dev.shape[1])
 
     def bellmann_error(self, states=None):
         """``sum (future_values - V)^2`` (``:116-133``): over the grid in one sweep, or at the given
