@@ -726,6 +726,10 @@ class Triangulation(DeterministicFunction):
             self._table_thunk = None
             self._device_table = build().reshape(self.nindex, -1)
 
+    def __getstate__(self):
+        self._resolve_table()                      # a table that is not built yet is a closure: build it
+        return self.__dict__
+
     def _host_parameters(self):
         self._resolve_table()
         if self._parameters is None and self._device_table is not None:

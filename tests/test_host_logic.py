@@ -107,3 +107,33 @@ def test_unit_cell_tables_frozen_fixture_and_live_scipy_agree():
         want = [[int(sum(((c >> k) & 1) * strides[k] for k in range(d))) for c in s]
                 for s in UNIT_CELL_SIMPLICES[d]]
         assert np.asarray(otri.unit_simplices).tolist() == want
+
+
+def test_a_lazy_vertex_table_is_built_when_it_is_read():
+    """``Triangulation._adopt_lazy_device_table`` (the greedy policy of a Bellman max sweep): nothing is
+    built until somebody reads the table - ``parameters``, ``output_dim`` without building, pickling."""
+    import pickle
+    import torch
+    import safe_learning_amd as sl
+    grid = sl.GridWorld([[-1., 1.], [-1., 1.]], [3, 4])
+    tri = sl.Triangulation(grid, np.zeros((12, 1)))
+    built = []
+
+    def build():
+        built.append(1)
+        return torch.arange(24, dtype=torch.float64).reshape(12, 2)
+
+    version = tri._table_version
+    tri._adopt_lazy_device_table(build, 2)
+    assert tri._table_version != version and tri.output_dim == 2 and not built
+    tri._adopt_lazy_device_table(build, 2)                 # replaced unread: still nothing built
+    assert not built
+    clone = pickle.loads(pickle.dumps(tri))
+    assert built == [1]
+    np.testing.assert_array_equal(clone.parameters, np.arange(24.).reshape(12, 2))
+    np.testing.assert_array_equal(tri.parameters, np.arange(24.).reshape(12, 2))
+    assert built == [1]
+    tri.parameters = np.ones((12, 1))                      # a host table drops a pending one
+    tri._adopt_lazy_device_table(build, 2)
+    tri.parameters = np.ones((12, 1))
+    assert built == [1] and tri.output_dim == 1
