@@ -17,7 +17,7 @@
 namespace {
 
 __device__ __forceinline__ double pnet_act(int a, double x) {
-    if (a == 1) return tanh(x);
+    if (a == 1) return sl_tanh(x);                 // (sl_model.h: the device routine of the network activations)
     if (a == 2) return x > 0.0 ? x : 0.0;
     if (a == 3) return 1.0 / (1.0 + exp(-x));
     return x;
